@@ -1,0 +1,155 @@
+/*
+ * fastmpc.h -- C ABI of the MI355X-native fastMPC inner solver.
+ *
+ * This is the drop-in boundary for ONE path of jinsungkim96/MPC-SensorlessAO: the call
+ *     obj   = Fast_MPC2(Q,R,S,Qf,q,r,qf,xmin,xmax,umin,umax,dumin,dumax,T,x0,x0_pre,u_prev,
+ *                       A1,A2,B,w,xf,x_init)              Fast_MPC/VAR_2/Fast_MPC2.m:28-55
+ *     x_opt = obj.mpc_fixed_log_newton(nw,k)              Fast_MPC/VAR_2/Fast_MPC2.m:124-130
+ * as issued once per timestep by the notebook loop (README.md:548,555), plus the caller-side
+ * unpack of x_opt (README.md:558-570,589).  Everything behind that call -- fast_mpc_init.m,
+ * fast_mpc_objective.m, fast_mpc_eq_const.m, fast_mpc_ineq_const.m, inf_newton_KKT_H.m,
+ * inf_newton_solver.m, backtracking_inf_newton.m -- runs as HIP kernels on gfx950.
+ *
+ * Conventions
+ *   - All matrices are fp64 COLUMN-MAJOR with leading dimension = rows, exactly as MATLAB
+ *     stores them (M(r,c) = M[r + c*rows]).  "n x batch" arrays are therefore one contiguous
+ *     n-vector per problem.
+ *   - z layout is the reference's interleaved vector [u0;x1;u1;x2;...;u_{T-1};x_T]
+ *     (fast_mpc_init.m:22-25), N_z = T*(n+m).
+ *   - nu has `fmpc_nu_len()` = n*(T + (xf given ? 1 : 0)) entries (length(b),
+ *     inf_newton_solver.m:2).
+ *   - Caller owns every buffer.  The handle copies the shared model to the device once and is
+ *     immutable afterwards.  No pointer passed to a solve call is retained.
+ *   - Functions return FMPC_OK (0), a negative error, or a positive warning; nothing throws.
+ *   - There is NO CPU fallback: without a usable HIP device fmpc_create fails with
+ *     FMPC_E_NO_DEVICE / FMPC_E_HIP.
+ */
+#ifndef FASTMPC_H
+#define FASTMPC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMPC_VERSION 100  /* 0.1.0 */
+
+/* status codes */
+#define FMPC_OK               0
+#define FMPC_W_LINESEARCH     1   /* backtracking collapsed to t = 0 (reference: t underflows,
+                                     backtracking_inf_newton.m:3-8)         */
+#define FMPC_E_NULL          -1   /* required pointer missing (fast_mpc_eq_const.m:19-25)     */
+#define FMPC_E_DIM           -2   /* size mismatch (fast_mpc_eq_const.m:27-32,
+                                     fast_mpc_ineq_const.m:4-9, fast_mpc_objective.m:17-47,
+                                     fast_mpc_init.m:13-14)                                    */
+#define FMPC_E_UNSUPPORTED   -3   /* valid for the reference, not implemented on the device
+                                     yet (non-diagonal Q/R/Qf, sizes beyond the LDS budget)   */
+#define FMPC_E_NOT_PD_PHI    -4   /* chol(KKT_H) would fail (inf_newton_solver.m:24)          */
+#define FMPC_E_NOT_PD_SCHUR  -5   /* chol(Schur) would fail (inf_newton_solver.m:30)          */
+#define FMPC_E_HIP           -6   /* HIP runtime error                                         */
+#define FMPC_E_ALLOC         -7
+#define FMPC_E_NO_DEVICE     -8   /* no HIP device: this library has no CPU path              */
+
+typedef struct fmpc_handle_s* fmpc_handle;
+
+int         fmpc_version(void);
+const char* fmpc_strerror(int code);
+
+/*
+ * Shared model ("handle").  Replaces the property copy of the Fast_MPC2 constructor for
+ * everything that does not change between timesteps (Fast_MPC2.m:30-54) and the constant part
+ * of the assembly (fast_mpc_objective.m:50-65, fast_mpc_eq_const.m:38-49,
+ * fast_mpc_ineq_const.m:46-56).
+ *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
+ *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
+ *   Q,R,Qf     n x n, m x m, n x n.  Must be diagonal for now (else FMPC_E_UNSUPPORTED);
+ *              diagonal entries must be > 0 (else FMPC_E_NOT_PD_PHI).
+ *   q,r,qf     NULL = zeros (fast_mpc_objective.m:26-47).
+ *   x_min/max  only used for the cold start (state bounds are not constraints,
+ *              fast_mpc_ineq_const.m:25-40).
+ *   xf         NULL = no terminal equality (fast_mpc_eq_const.m:67-71).
+ *   device     HIP device ordinal (>= 0).
+ */
+int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
+                const double* A1, const double* A2, const double* B,
+                const double* Q, const double* R, const double* Qf,
+                const double* q, const double* r, const double* qf,
+                const double* x_min, const double* x_max,
+                const double* u_min, const double* u_max,
+                const double* xf, int device);
+int fmpc_destroy(fmpc_handle h);
+
+int fmpc_dims(fmpc_handle h, int* n, int* m, int* T, int* nz, int* nu_len);
+
+/*
+ * One inf_newton_solver call per problem (inf_newton_solver.m:1-43) for `batch` independent
+ * problems; batch = 1 is the reference call.  HOST buffers; synchronous.
+ *   x0, x0_pre  n x batch (x0_pre may be NULL = zeros; ignored for var_order 1)
+ *   w           (T*n) x batch, NULL = zeros (superset of fast_mpc_eq_const.m:33-35, D7)
+ *   z_init      N_z x batch, NULL = cold start at mid-box (fast_mpc_init.m:19-25)
+ *   nu0         nu_len x batch, NULL = zeros.  The reference draws nu = rand(...)
+ *               (inf_newton_solver.m:2); the caller draws it and passes it here.
+ *   n_newton    fixed Newton-step count; <= 0 means the reference's nw = [] mode:
+ *               at most 1000 iterations (inf_newton_solver.m:4-8).
+ *               The tolerance exit (:19-22) is active in both modes, as in the reference.
+ *   k           barrier weight
+ *   z_out       N_z x batch
+ *   nu_out      nu_len x batch, nullable
+ *   status      batch, nullable: per-problem code
+ *   iters       batch, nullable: Newton steps taken
+ *   step        step_ld x batch, nullable: accepted t of every Newton step (unused tail = -1);
+ *               step_ld = fmpc_step_ld(n_newton)
+ * Returns the worst per-problem status (most negative error, else largest warning).
+ */
+int fmpc_solve(fmpc_handle h, int batch,
+               const double* x0, const double* x0_pre, const double* w,
+               const double* z_init, const double* nu0,
+               int n_newton, double k,
+               double* z_out, double* nu_out, int* status, int* iters, double* step);
+
+int fmpc_step_ld(int n_newton);
+
+/*
+ * Same call with DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*;
+ * NULL = the default stream).  `status`/`iters` are device int arrays.  The return value only
+ * covers argument and launch errors; per-problem codes are in `status`.
+ */
+int fmpc_solve_device(fmpc_handle h, int batch,
+                      const double* x0, const double* x0_pre, const double* w,
+                      const double* z_init, const double* nu0,
+                      int n_newton, double k,
+                      double* z_out, double* nu_out, int* status, int* iters, double* step,
+                      void* stream);
+
+/*
+ * Caller-side unpack of x_opt (README.md:558-570) and u_prev = U(1:nu) (README.md:589):
+ * z (N_z x batch) -> U (T*m x batch), X (T*n x batch), u0 (m x batch); any output may be NULL.
+ */
+int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U, double* X, double* u0);
+int fmpc_unpack_device(fmpc_handle h, int batch, const double* z, double* U, double* X,
+                       double* u0, void* stream);
+
+/*
+ * One-shot form taking the reference's full 23-argument constructor set
+ * (Fast_MPC/VAR_2/Fast_MPC2.m:28-29) plus (nw, k) of mpc_fixed_log_newton (:124) and nu0.
+ * S, x_min/x_max (beyond the cold start), du_min, du_max, u_prev are accepted and ignored as
+ * in the reference.  Empty MATLAB arguments are NULL.  x_opt: N_z.
+ * var_order 1 ignores x0_pre/A2.
+ */
+int fmpc_solve_once(int n, int m, int T, int var_order,
+                    const double* Q, const double* R, const double* S, const double* Qf,
+                    const double* q, const double* r, const double* qf,
+                    const double* x_min, const double* x_max,
+                    const double* u_min, const double* u_max,
+                    const double* du_min, const double* du_max,
+                    const double* x0, const double* x0_pre, const double* u_prev,
+                    const double* A1, const double* A2, const double* B,
+                    const double* w, const double* xf, const double* x_init,
+                    const double* nu0, int nw, double k, int device,
+                    double* x_opt, int* iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTMPC_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of the C-ABI shared library (include/fastmpc.h).
+
+The library is built in-tree (`mpc-sensorlessao_amd/lib/libfastmpc.so`, see csrc/Makefile).  If it
+is missing this module raises: there is no Python or CPU fallback for the solve path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfastmpc.so")
+
+FMPC_OK = 0
+FMPC_W_LINESEARCH = 1
+FMPC_E_NULL = -1
+FMPC_E_DIM = -2
+FMPC_E_UNSUPPORTED = -3
+FMPC_E_NOT_PD_PHI = -4
+FMPC_E_NOT_PD_SCHUR = -5
+FMPC_E_HIP = -6
+FMPC_E_ALLOC = -7
+FMPC_E_NO_DEVICE = -8
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/fastmpc.h declares
+SIGNATURES = {
+    "fmpc_version": (C.c_int, []),
+    "fmpc_strerror": (C.c_char_p, [C.c_int]),
+    "fmpc_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int] + [_vp] * 14 + [C.c_int]),
+    "fmpc_destroy": (C.c_int, [_vp]),
+    "fmpc_dims": (C.c_int, [_vp, _ip, _ip, _ip, _ip, _ip]),
+    "fmpc_solve": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 5),
+    "fmpc_step_ld": (C.c_int, [C.c_int]),
+    "fmpc_solve_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 5 + [_vp]),
+    "fmpc_unpack": (C.c_int, [_vp, C.c_int] + [_vp] * 4),
+    "fmpc_unpack_device": (C.c_int, [_vp, C.c_int] + [_vp] * 4 + [_vp]),
+    "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
+}
+
+_lib = None
+
+
+class FastMPCError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = int(code)
+        msg = strerror(code)
+        super().__init__(f"{where}: [{self.code}] {msg}" if where else f"[{self.code}] {msg}")
+
+
+def load():
+    """Load the shared library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C mpc-sensorlessao_amd/csrc`). "
+            "This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code):
+    try:
+        return load().fmpc_strerror(int(code)).decode()
+    except Exception:   # library absent: still give the number
+        return f"fastmpc status {code}"

@@ -1,0 +1,429 @@
+// C-ABI of the MI355X fastMPC solver (include/fastmpc.h): handle, host-side assembly of the
+// iteration-invariant blocks, launches.  No CPU solve path exists in this library.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/fastmpc.h"
+#include "fmpc_device.h"
+
+// kernels / launchers (fmpc_kernel_generic.hip)
+size_t fmpc_generic_lds_bytes(int n, int m);
+hipError_t fmpc_generic_prepare(size_t lds_bytes);
+hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const double* x0,
+                               const double* x0p, const double* w, const double* zinit,
+                               const double* nu0, int max_iter, double kbar, double* zout,
+                               double* nuout, int* status, int* iters, double* step, int step_ld,
+                               double* ws, size_t ws_stride, hipStream_t stream);
+hipError_t fmpc_launch_unpack(int n, int m, int T, int batch, const double* z, double* U,
+                              double* X, double* u0, hipStream_t stream);
+
+#define FMPC_LDS_LIMIT (160 * 1024)
+
+struct fmpc_handle_s {
+    int n, m, T, nb, var_order, has_xf, device;
+    int num_cu;
+    FmpcDevModel dev;            // device pointers into `pool`
+    double* pool_d;              // one allocation for all shared doubles
+    int* pool_i;                 // and one for the index arrays
+    size_t lds_bytes;
+    int wg_per_cu;
+    // workspace, grown on demand; guarded because a handle may be shared between threads
+    std::mutex mu;
+    std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
+    double* ws;
+    size_t ws_doubles;
+    // staging for the host-pointer entry points
+    void* stage;
+    size_t stage_bytes;
+};
+
+extern "C" int fmpc_version(void) { return FMPC_VERSION; }
+
+extern "C" const char* fmpc_strerror(int code) {
+    switch (code) {
+        case FMPC_OK: return "ok";
+        case FMPC_W_LINESEARCH: return "line search collapsed to t = 0";
+        case FMPC_E_NULL: return "Define the state dynamics/equality constrained matrix";
+        case FMPC_E_DIM: return "size mismatch";
+        case FMPC_E_UNSUPPORTED: return "not supported by the device path yet";
+        case FMPC_E_NOT_PD_PHI: return "Matrix must be positive definite (KKT_H)";
+        case FMPC_E_NOT_PD_SCHUR: return "Matrix must be positive definite (Schur)";
+        case FMPC_E_HIP: return "HIP runtime error";
+        case FMPC_E_ALLOC: return "allocation failed";
+        case FMPC_E_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+        default: return "unknown fastmpc status";
+    }
+}
+
+extern "C" int fmpc_step_ld(int n_newton) { return n_newton > 0 ? n_newton : 1000; }
+
+namespace {
+
+// column-major (MATLAB) element
+inline double cm(const double* M, int rows, int r, int c) { return M[(size_t)r + (size_t)c * rows]; }
+
+bool is_diag(const double* M, int n) {
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r)
+            if (r != c && cm(M, n, r, c) != 0.0) return false;
+    return true;
+}
+
+// out (row-major n x n) += A diag(x) B'   with A, B row-major n x n
+void add_AxBt(std::vector<double>& out, const std::vector<double>& A, const std::vector<double>& x,
+              const std::vector<double>& B, int n, double sign) {
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double t = 0.0;
+            for (int c = 0; c < n; ++c) t += A[a * n + c] * x[c] * B[b * n + c];
+            out[a * n + b] += sign * t;
+        }
+}
+
+}  // namespace
+
+extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
+                           const double* A1, const double* A2, const double* B,
+                           const double* Q, const double* R, const double* Qf,
+                           const double* q, const double* r, const double* qf,
+                           const double* x_min, const double* x_max,
+                           const double* u_min, const double* u_max,
+                           const double* xf, int device) {
+    if (!out) return FMPC_E_NULL;
+    *out = nullptr;
+    if (n <= 0 || m <= 0 || T <= 0 || (var_order != 1 && var_order != 2)) return FMPC_E_DIM;
+    if (!A1 || !B || (var_order == 2 && !A2)) return FMPC_E_NULL;   // fast_mpc_eq_const.m:19-25
+    if (!Q || !R || !Qf || !x_min || !x_max || !u_min || !u_max) return FMPC_E_NULL;
+    if (device < 0) return FMPC_E_NO_DEVICE;
+    if (!is_diag(Q, n) || !is_diag(Qf, n) || !is_diag(R, m)) return FMPC_E_UNSUPPORTED;
+    for (int i = 0; i < n; ++i)
+        if (!(cm(Q, n, i, i) > 0.0) || !(cm(Qf, n, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
+    for (int i = 0; i < m; ++i)
+        if (!(cm(R, m, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
+    if (n > 64) return FMPC_E_UNSUPPORTED;
+    const size_t lds = fmpc_generic_lds_bytes(n, m);
+    if (lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FMPC_E_NO_DEVICE;
+    if (device >= ndev) return FMPC_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FMPC_E_HIP;
+
+    fmpc_handle h = new (std::nothrow) fmpc_handle_s();
+    if (!h) return FMPC_E_ALLOC;
+    h->n = n; h->m = m; h->T = T; h->var_order = var_order; h->has_xf = xf ? 1 : 0;
+    h->nb = T + h->has_xf; h->device = device;
+    h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
+    h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->wg_per_cu = (int)(FMPC_LDS_LIMIT / lds);
+    if (h->wg_per_cu < 1) h->wg_per_cu = 1;
+    if (h->wg_per_cu > 8) h->wg_per_cu = 8;
+
+    const bool var2 = var_order == 2;
+    const int nn = n * n;
+    // ---- row-major copies
+    std::vector<double> a1(nn), a2(nn, 0.0), a1t(nn), a2t(nn, 0.0), bt((size_t)m * n);
+    for (int rr = 0; rr < n; ++rr)
+        for (int c = 0; c < n; ++c) {
+            a1[rr * n + c] = cm(A1, n, rr, c);
+            a1t[c * n + rr] = a1[rr * n + c];
+            if (var2) {
+                a2[rr * n + c] = cm(A2, n, rr, c);
+                a2t[c * n + rr] = a2[rr * n + c];
+            }
+        }
+    for (int rr = 0; rr < n; ++rr)
+        for (int c = 0; c < m; ++c) bt[(size_t)c * n + rr] = cm(B, n, rr, c);
+    std::vector<double> R2(m), Q2(n), Qf2(n), X(n), Xf(n);
+    for (int i = 0; i < m; ++i) R2[i] = 2.0 * cm(R, m, i, i);
+    for (int i = 0; i < n; ++i) {
+        Q2[i] = 2.0 * cm(Q, n, i, i);
+        Qf2[i] = 2.0 * cm(Qf, n, i, i);
+        X[i] = 1.0 / Q2[i];
+        Xf[i] = 1.0 / Qf2[i];
+    }
+    // ---- iteration-invariant Y blocks, deduplicated
+    //   Yd_i = X_{i+1} + [i>=1] A1 X_i A1' + [i>=2] A2 X_{i-1} A2'
+    //   Y1_i = -X_{i+1} A1' + [i>=1] A1 X_i A2'      (rows i, i+1 < T)
+    //   Y2_i = -X_{i+1} A2'                          (rows i, i+2 < T)
+    //   xf:   Yd_T = Xf, Y1_{T-1} = Xf
+    std::vector<std::vector<double>> blocks;
+    std::vector<int> idxD(h->nb, -1), idx1(h->nb, -1), idx2(h->nb, -1);
+    auto intern = [&](const std::vector<double>& blk) {
+        for (size_t k = 0; k < blocks.size(); ++k)
+            if (memcmp(blocks[k].data(), blk.data(), nn * sizeof(double)) == 0) return (int)k;
+        blocks.push_back(blk);
+        return (int)blocks.size() - 1;
+    };
+    auto Xj = [&](int j) -> const std::vector<double>& { return j == T ? Xf : X; };
+    for (int i = 0; i < T; ++i) {
+        std::vector<double> d(nn, 0.0);
+        for (int a = 0; a < n; ++a) d[a * n + a] = Xj(i + 1)[a];
+        if (i >= 1) add_AxBt(d, a1, Xj(i), a1, n, 1.0);
+        if (i >= 2 && var2) add_AxBt(d, a2, Xj(i - 1), a2, n, 1.0);
+        idxD[i] = intern(d);
+        if (i + 1 < T) {
+            std::vector<double> o(nn, 0.0);
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) o[a * n + b] = -Xj(i + 1)[a] * a1[b * n + a];
+            if (i >= 1 && var2) add_AxBt(o, a1, Xj(i), a2, n, 1.0);
+            idx1[i] = intern(o);
+        }
+        if (i + 2 < T && var2) {
+            std::vector<double> o(nn, 0.0);
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b < n; ++b) o[a * n + b] = -Xj(i + 1)[a] * a2[b * n + a];
+            idx2[i] = intern(o);
+        }
+    }
+    if (xf) {
+        std::vector<double> d(nn, 0.0);
+        for (int a = 0; a < n; ++a) d[a * n + a] = Xf[a];
+        idxD[T] = intern(d);
+        idx1[T - 1] = idxD[T];
+    }
+    // ---- pack the pool
+    std::vector<double> pool;
+    auto push = [&](const double* p, size_t cnt) {
+        size_t off = pool.size();
+        pool.insert(pool.end(), p, p + cnt);
+        while (pool.size() % 2) pool.push_back(0.0);   // keep 16-byte alignment
+        return off;
+    };
+    auto push_opt = [&](const double* p, size_t cnt) {
+        std::vector<double> z(cnt, 0.0);
+        return push(p ? p : z.data(), cnt);
+    };
+    const size_t oA1 = push(a1.data(), nn), oA2 = push(a2.data(), nn);
+    const size_t oA1t = push(a1t.data(), nn), oA2t = push(a2t.data(), nn);
+    const size_t oBt = push(bt.data(), bt.size());
+    const size_t oR2 = push(R2.data(), m), oQ2 = push(Q2.data(), n), oQf2 = push(Qf2.data(), n);
+    const size_t orl = push_opt(r, m), oql = push_opt(q, n), oqfl = push_opt(qf, n);
+    const size_t oumin = push(u_min, m), oumax = push(u_max, m);
+    std::vector<double> umid(m), xmid(n);
+    for (int i = 0; i < m; ++i) umid[i] = (u_min[i] + u_max[i]) / 2;    // fast_mpc_init.m:19-20
+    for (int i = 0; i < n; ++i) xmid[i] = (x_min[i] + x_max[i]) / 2;
+    const size_t oumid = push(umid.data(), m), oxmid = push(xmid.data(), n);
+    const size_t oxf = push_opt(xf, n);
+    // blocks are indexed as Yblk + idx*n*n by the kernels: pack them without padding
+    std::vector<double> yall;
+    for (auto& bk : blocks) yall.insert(yall.end(), bk.begin(), bk.end());
+    const size_t oY = push(yall.data(), yall.size());
+
+    std::vector<int> ipool;
+    ipool.insert(ipool.end(), idxD.begin(), idxD.end());
+    ipool.insert(ipool.end(), idx1.begin(), idx1.end());
+    ipool.insert(ipool.end(), idx2.begin(), idx2.end());
+
+    if (hipMalloc((void**)&h->pool_d, pool.size() * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&h->pool_i, ipool.size() * sizeof(int)) != hipSuccess) {
+        fmpc_destroy(h);
+        return FMPC_E_ALLOC;
+    }
+    if (hipMemcpy(h->pool_d, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->pool_i, ipool.data(), ipool.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        fmpc_destroy(h);
+        return FMPC_E_HIP;
+    }
+    FmpcDevModel& D = h->dev;
+    D.n = n; D.m = m; D.T = T; D.nb = h->nb; D.has_xf = h->has_xf; D.var2 = var2 ? 1 : 0;
+    D.A1 = h->pool_d + oA1; D.A2 = h->pool_d + oA2; D.A1t = h->pool_d + oA1t; D.A2t = h->pool_d + oA2t;
+    D.Bt = h->pool_d + oBt; D.R2 = h->pool_d + oR2; D.Q2 = h->pool_d + oQ2; D.Qf2 = h->pool_d + oQf2;
+    D.rl = h->pool_d + orl; D.ql = h->pool_d + oql; D.qfl = h->pool_d + oqfl;
+    D.umin = h->pool_d + oumin; D.umax = h->pool_d + oumax; D.umid = h->pool_d + oumid;
+    D.xmid = h->pool_d + oxmid; D.xf = h->pool_d + oxf; D.Yblk = h->pool_d + oY;
+    D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
+
+    if (fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+    *out = h;
+    return FMPC_OK;
+}
+
+extern "C" int fmpc_destroy(fmpc_handle h) {
+    if (!h) return FMPC_E_NULL;
+    (void)hipSetDevice(h->device);
+    if (h->pool_d) (void)hipFree(h->pool_d);
+    if (h->pool_i) (void)hipFree(h->pool_i);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->stage) (void)hipFree(h->stage);
+    delete h;
+    return FMPC_OK;
+}
+
+extern "C" int fmpc_dims(fmpc_handle h, int* n, int* m, int* T, int* nz, int* nu_len) {
+    if (!h) return FMPC_E_NULL;
+    if (n) *n = h->n;
+    if (m) *m = h->m;
+    if (T) *T = h->T;
+    if (nz) *nz = h->T * (h->n + h->m);
+    if (nu_len) *nu_len = h->nb * h->n;
+    return FMPC_OK;
+}
+
+static int fmpc_grid_for(fmpc_handle h, int batch) {
+    int cap = h->num_cu * h->wg_per_cu;
+    return batch < cap ? batch : cap;
+}
+
+// grows the per-workgroup workspace; caller holds h->mu
+static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
+    const FmpcWsLayout L = fmpc_ws_layout(h->n, h->m, h->T, h->nb);
+    *stride = L.total;
+    const size_t need = L.total * (size_t)grid;
+    if (need > h->ws_doubles) {
+        if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_doubles = 0; }
+        if (hipMalloc((void**)&h->ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->ws_doubles = need;
+    }
+    return FMPC_OK;
+}
+
+extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
+                                 const double* x0, const double* x0_pre, const double* w,
+                                 const double* z_init, const double* nu0,
+                                 int n_newton, double k,
+                                 double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                 void* stream) {
+    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int grid = fmpc_grid_for(h, batch);
+    size_t stride = 0;
+    int rc = fmpc_ensure_ws(h, h->num_cu * h->wg_per_cu, &stride);   // full size once: no regrowth
+    if (rc != FMPC_OK) return rc;
+    const int max_iter = n_newton > 0 ? n_newton : 1000;
+    hipError_t e = fmpc_launch_generic(h->dev, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                                       z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
+                                       h->ws, stride, (hipStream_t)stream);
+    return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_solve(fmpc_handle h, int batch,
+                          const double* x0, const double* x0_pre, const double* w,
+                          const double* z_init, const double* nu0,
+                          int n_newton, double k,
+                          double* z_out, double* nu_out, int* status, int* iters, double* step) {
+    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> host_lk(h->host_mu);
+    const size_t n = h->n, Nz = (size_t)h->T * (h->n + h->m), nbn = (size_t)h->nb * h->n;
+    const size_t Tn = (size_t)h->T * h->n, sld = fmpc_step_ld(n_newton), B = batch;
+    // one device staging block: inputs then outputs
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_x0 = take(n * B * 8), o_x0p = take(n * B * 8), o_w = take(Tn * B * 8);
+    const size_t o_zi = take(Nz * B * 8), o_nu0 = take(nbn * B * 8), o_z = take(Nz * B * 8);
+    const size_t o_nu = take(nbn * B * 8), o_st = take(B * 4), o_it = take(B * 4), o_step = take(sld * B * 8);
+    char* base;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (off > h->stage_bytes) {
+            if (h->stage) { (void)hipDeviceSynchronize(); (void)hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+            if (hipMalloc(&h->stage, off) != hipSuccess) return FMPC_E_ALLOC;
+            h->stage_bytes = off;
+        }
+        base = (char*)h->stage;
+    }
+    auto up = [&](size_t o, const double* src, size_t cnt) -> const double* {
+        if (!src) return nullptr;
+        if (hipMemcpy(base + o, src, cnt * 8, hipMemcpyHostToDevice) != hipSuccess) return (const double*)-1;
+        return (const double*)(base + o);
+    };
+    const double* d_x0 = up(o_x0, x0, n * B);
+    const double* d_x0p = up(o_x0p, x0_pre, n * B);
+    const double* d_w = up(o_w, w, Tn * B);
+    const double* d_zi = up(o_zi, z_init, Nz * B);
+    const double* d_nu0 = up(o_nu0, nu0, nbn * B);
+    const double* bad = (const double*)-1;
+    if (d_x0 == bad || d_x0p == bad || d_w == bad || d_zi == bad || d_nu0 == bad) return FMPC_E_HIP;
+    int* d_st = (int*)(base + o_st);
+    int* d_it = (int*)(base + o_it);
+    int rc = fmpc_solve_device(h, batch, d_x0, d_x0p, d_w, d_zi, d_nu0, n_newton, k,
+                               (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
+                               step ? (double*)(base + o_step) : nullptr, nullptr);
+    if (rc != FMPC_OK) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
+    std::vector<int> st(B);
+    if (hipMemcpy(z_out, base + o_z, Nz * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    if (nu_out && hipMemcpy(nu_out, base + o_nu, nbn * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    if (hipMemcpy(st.data(), d_st, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    if (iters && hipMemcpy(iters, d_it, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    if (step && hipMemcpy(step, base + o_step, sld * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    int worst = FMPC_OK;
+    for (size_t i = 0; i < B; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] < 0) { if (worst >= 0 || st[i] < worst) worst = st[i]; }
+        else if (worst >= 0 && st[i] > worst) worst = st[i];
+    }
+    return worst;
+}
+
+extern "C" int fmpc_unpack_device(fmpc_handle h, int batch, const double* z, double* U, double* X,
+                                  double* u0, void* stream) {
+    if (!h || !z) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    return fmpc_launch_unpack(h->n, h->m, h->T, batch, z, U, X, u0, (hipStream_t)stream) == hipSuccess
+               ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U, double* X, double* u0) {
+    if (!h || !z) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    const size_t B = batch, Nz = (size_t)h->T * (h->n + h->m), Tm = (size_t)h->T * h->m, Tn = (size_t)h->T * h->n;
+    double *dz = nullptr, *dU = nullptr, *dX = nullptr, *du0 = nullptr;
+    int rc = FMPC_OK;
+    if (hipMalloc((void**)&dz, Nz * B * 8) != hipSuccess) return FMPC_E_ALLOC;
+    if ((U && hipMalloc((void**)&dU, Tm * B * 8) != hipSuccess) ||
+        (X && hipMalloc((void**)&dX, Tn * B * 8) != hipSuccess) ||
+        (u0 && hipMalloc((void**)&du0, h->m * B * 8) != hipSuccess)) rc = FMPC_E_ALLOC;
+    if (rc == FMPC_OK && hipMemcpy(dz, z, Nz * B * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK) rc = fmpc_unpack_device(h, batch, dz, dU, dX, du0, nullptr);
+    if (rc == FMPC_OK && hipDeviceSynchronize() != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK && U && hipMemcpy(U, dU, Tm * B * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK && X && hipMemcpy(X, dX, Tn * B * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK && u0 && hipMemcpy(u0, du0, h->m * B * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMPC_E_HIP;
+    (void)hipFree(dz);
+    if (dU) (void)hipFree(dU);
+    if (dX) (void)hipFree(dX);
+    if (du0) (void)hipFree(du0);
+    return rc;
+}
+
+extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
+                               const double* Q, const double* R, const double* S, const double* Qf,
+                               const double* q, const double* r, const double* qf,
+                               const double* x_min, const double* x_max,
+                               const double* u_min, const double* u_max,
+                               const double* du_min, const double* du_max,
+                               const double* x0, const double* x0_pre, const double* u_prev,
+                               const double* A1, const double* A2, const double* B,
+                               const double* w, const double* xf, const double* x_init,
+                               const double* nu0, int nw, double k, int device,
+                               double* x_opt, int* iters) {
+    (void)S; (void)du_min; (void)du_max; (void)u_prev;     // unused by the reference too (D8)
+    if (!x0 || (var_order == 2 && !x0_pre)) return FMPC_E_DIM;   // fast_mpc_eq_const.m:27-30
+    fmpc_handle h = nullptr;
+    int rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max,
+                         u_min, u_max, xf, device);
+    if (rc != FMPC_OK) return rc;
+    int st = 0;
+    rc = fmpc_solve(h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+    fmpc_destroy(h);
+    return rc;
+}

@@ -1,0 +1,54 @@
+// Device-side view of the shared model and of the per-problem workspace.
+// Internal to the library (the public boundary is include/fastmpc.h).
+#pragma once
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+
+struct FmpcDevModel {
+    int n, m, T, nb;          // nb = block rows of C / Y = T + (xf ? 1 : 0)
+    int has_xf, var2;         // var2: A2 present (VAR(2)); 0 -> Y is block-tridiagonal
+    const double* A1;         // row-major n x n           A1[r*n+c]
+    const double* A2;
+    const double* A1t;        // transposes, row-major     A1t[c*n+r] = A1[r][c]
+    const double* A2t;
+    const double* Bt;         // m x n                     Bt[c*n+r]  = B[r][c]
+    const double* R2;         // 2*diag(R)  (m)            Phi u-block without the barrier term
+    const double* Q2;         // 2*diag(Q)  (n)
+    const double* Qf2;        // 2*diag(Qf) (n)
+    const double* rl;         // linear cost r (m), q (n), qf (n)
+    const double* ql;
+    const double* qfl;
+    const double* umin;
+    const double* umax;
+    const double* umid;       // cold start (fast_mpc_init.m:19-20)
+    const double* xmid;
+    const double* xf;
+    const double* Yblk;       // unique iteration-invariant Y blocks, each n x n row-major
+    const int* idxD;          // per block row: index into Yblk of the constant part of Y_ii
+    const int* idx1;          //                of Y_{i,i+1} (-1: none)
+    const int* idx2;          //                of Y_{i,i+2} (-1: none)
+};
+
+// Per-workgroup scratch in HBM (doubles).  The factor tiles are written during the forward
+// sweep and streamed back once, in reverse, by the backward sweep.
+struct FmpcWsLayout {
+    size_t b, nu, hess, winv, rdu, rdx, rp, y, dnu, fac, total;
+};
+
+__host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int T, int nb) {
+    FmpcWsLayout L;
+    size_t o = 0;
+    const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
+    L.b = o;    o += nbn;
+    L.nu = o;   o += nbn;
+    L.hess = o; o += Tm;
+    L.winv = o; o += Tm;
+    L.rdu = o;  o += Tm;
+    L.rdx = o;  o += Tn;
+    L.rp = o;   o += nbn;
+    L.y = o;    o += nbn;
+    L.dnu = o;  o += nbn;
+    L.fac = o;  o += (size_t)nb * 3 * n * (n + 1);
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}

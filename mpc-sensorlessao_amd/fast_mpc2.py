@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's solver facade, `Fast_MPC2`
+(Fast_MPC/VAR_2/Fast_MPC2.m:1-146; VAR_1/Fast_MPC2.m for the 21-argument form).
+
+Same constructor argument order, same driver names, same meaning of `[]` (here: None or an empty
+array), same return value (x_opt = interleaved z).  Every solve goes through the C ABI
+(include/fastmpc.h) to the HIP kernels; nothing is solved on the host.
+
+What is different from the reference, on purpose:
+  * `nu = rand(length(b),1)` (inf_newton_solver.m:2) is drawn here (numpy Generator passed as
+    `rng`, or an explicit `nu0`) and handed to the device, so the caller controls the stream.
+  * The object is cheap to rebuild every timestep as the notebook does (README.md:548): device
+    handles are cached on the content of the shared model.
+  * `matlab_solve` / `fomulate_mpc` (fmincon, Fast_MPC2.m:68-87) are outside the path.
+  * The dense builders `objective_function` / `inequality_const` / `equality_const`
+    (Fast_MPC2.m:56-64) are not provided: the device path never forms H, P or C.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import FastMPCError
+from .handle import FastMPCHandle
+
+_HANDLE_CACHE: "OrderedDict[str, FastMPCHandle]" = OrderedDict()
+_HANDLE_CACHE_MAX = 8
+
+
+def _empty(v):
+    return v is None or np.asarray(v).size == 0
+
+
+def _vec(v):
+    return None if _empty(v) else np.asarray(v, dtype=np.float64).reshape(-1)
+
+
+def _mat(v):
+    if _empty(v):
+        return None
+    a = np.asarray(v, dtype=np.float64)
+    return a.reshape(1, 1) if a.ndim == 0 else a
+
+
+def _digest(*arrays):
+    hsh = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        if a is None:
+            hsh.update(b"\x00none")
+        else:
+            a = np.ascontiguousarray(a)
+            hsh.update(str(a.shape).encode())
+            hsh.update(a.tobytes())
+    return hsh.hexdigest()
+
+
+def deinterleave(z, n, m, T):
+    """Caller-side unpack (README.md:558-570): z=[u0;x1;u1;x2;...] -> (U, X)."""
+    Z = np.asarray(z).reshape(T, m + n)
+    return Z[:, :m].reshape(-1).copy(), Z[:, m:].reshape(-1).copy()
+
+
+class Fast_MPC2:
+    """obj = Fast_MPC2(Q,R,S,Qf,q,r,qf,xmin,xmax,umin,umax,dumin,dumax,T,x0,x0_pre,u_prev,
+                       A1,A2,B,w,xf,x_init)                       (VAR_2/Fast_MPC2.m:28-29)"""
+
+    var_order = 2
+
+    def __init__(self, Q, R, S, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, x0_pre,
+                 u_prev, A1, A2, B, w, xf, x_init, *, device=0, rng=None):
+        self.Q, self.R, self.S, self.Qf = _mat(Q), _mat(R), S, _mat(Qf)
+        self.q, self.r, self.qf = _vec(q), _vec(r), _vec(qf)
+        self.x_min, self.x_max = _vec(xmin), _vec(xmax)
+        self.u_min, self.u_max = _vec(umin), _vec(umax)
+        self.du_min, self.du_max = _vec(dumin), _vec(dumax)      # unused in VAR_2 (D8)
+        self.T = int(T)
+        self.x0, self.x0_pre, self.u_prev = _vec(x0), _vec(x0_pre), _vec(u_prev)
+        self.A1, self.A2, self.B = _mat(A1), _mat(A2), _mat(B)
+        self.w = _vec(w)
+        self.x_final = _vec(xf)
+        self.x_init = _vec(x_init)
+        self.device = int(device)
+        self.rng = rng
+        self.last_info = None
+
+    # ---------------------------------------------------------------- validation
+    def _check(self):
+        """The reference's error() calls, in the order its drivers hit them."""
+        E = lambda msg: FastMPCError(_lib.FMPC_E_DIM, msg)
+        Q, R, Qf = self.Q, self.R, self.Qf
+        if Q is None or R is None or Qf is None:
+            raise FastMPCError(_lib.FMPC_E_NULL, "Q, R, Qf are required")
+        n, m, T = Q.shape[0], R.shape[0], self.T
+        # fast_mpc_init.m:13-14
+        if self.x_init is not None and self.x_init.shape[0] != T * (n + m):
+            raise E("Initialization size mismatch (T*(n+m))")
+        # fast_mpc_objective.m:17-47
+        if Q.shape[0] != Q.shape[1] or Qf.shape[0] != Qf.shape[1]:
+            raise E("State stage cost must a square matrix")
+        if R.shape[0] != R.shape[1]:
+            raise E("Control stage cost must a square matrix")
+        if self.q is not None and self.q.shape[0] != n:
+            raise E("Linear state cost needs to be a vector of size n")
+        if self.r is not None and self.r.shape[0] != m:
+            raise E("Linear control cost needs to be a vector of size n")
+        if self.qf is not None and self.qf.shape[0] != n:
+            raise E("State terminal linear cost needs to be a vector of size n")
+        # fast_mpc_ineq_const.m:4-9
+        if self.x_min is None or self.x_max is None or self.x_min.shape[0] != n or self.x_max.shape[0] != n:
+            raise E("Check the state inequality constraints dimensions")
+        if self.u_min is None or self.u_max is None or self.u_min.shape[0] != m or self.u_max.shape[0] != m:
+            raise E("Check cotrol iequality constraint dimension")
+        # fast_mpc_eq_const.m:19-32
+        if self.A1 is None or (self.var_order == 2 and self.A2 is None):
+            raise FastMPCError(_lib.FMPC_E_NULL, "Define the state dynamics/equality constrained matrix")
+        if self.B is None:
+            raise FastMPCError(_lib.FMPC_E_NULL, "Define the control dynamics/equality constrained matrix")
+        if self.x0 is None or self.A1.shape[1] != self.x0.shape[0]:
+            raise E("The equality state dynamics matrix size does not match")
+        if self.var_order == 2 and (self.x0_pre is None or self.A2.shape[1] != self.x0_pre.shape[0]):
+            raise E("The equality state dynamics matrix size does not match")
+        if self.B.shape[1] != R.shape[1]:
+            raise E("The equality control dynamics matrix size does not match")
+        if self.A1.shape != (n, n) or self.B.shape[0] != n:
+            raise E("The equality state dynamics matrix size does not match")
+        if self.w is not None and self.w.shape[0] != T * n:
+            # the reference indexes w(n*i+1:n*(i+1)) for every stage (fast_mpc_eq_const.m:44,47)
+            raise E("Index exceeds the number of array elements (w must have T*n entries)")
+        if self.w is None and T > 1:
+            # fast_mpc_eq_const.m:33-35 makes w only n long and then indexes past it (D7);
+            # zeros(T*n) is the documented superset.
+            pass
+        if self.x_final is not None and self.x_final.shape[0] != n:
+            raise E("Terminal state size mismatch")
+        return n, m, T
+
+    def _handle(self):
+        n, m, T = self._check()
+        key = _digest(np.array([n, m, T, self.var_order, self.device]), self.A1,
+                      self.A2 if self.var_order == 2 else None, self.B, self.Q, self.R, self.Qf,
+                      self.q, self.r, self.qf, self.x_min, self.x_max, self.u_min, self.u_max,
+                      self.x_final)
+        h = _HANDLE_CACHE.get(key)
+        if h is None:
+            h = FastMPCHandle(self.A1, self.A2 if self.var_order == 2 else None, self.B, self.Q,
+                              self.R, self.Qf, self.u_min, self.u_max, self.x_min, self.x_max, T,
+                              q=self.q, r=self.r, qf=self.qf, xf=self.x_final,
+                              var_order=self.var_order, device=self.device)
+            _HANDLE_CACHE[key] = h
+            while len(_HANDLE_CACHE) > _HANDLE_CACHE_MAX:
+                _HANDLE_CACHE.popitem(last=False)[1].close()
+        else:
+            _HANDLE_CACHE.move_to_end(key)
+        return h
+
+    def _draw_nu0(self, h, nu0):
+        if nu0 is not None:
+            return np.asarray(nu0, dtype=np.float64).reshape(-1)
+        rng = self.rng if self.rng is not None else np.random.default_rng()
+        return rng.random(h.nu_len)                 # nu = rand(length(b),1), inf_newton_solver.m:2
+
+    def _solve(self, h, z_init, nw, k, nu0):
+        z, info = h.solve(self.x0, self.x0_pre if self.var_order == 2 else None, self.w,
+                          z_init=z_init, nu0=self._draw_nu0(h, nu0), n_newton=nw, k=k,
+                          return_info=True)
+        st = int(info["status"][0])
+        if st < 0:                                   # chol() error in the reference
+            raise FastMPCError(st, "inf_newton_solver")
+        return z, info
+
+    # ---------------------------------------------------------------- reference API
+    def initialize(self):
+        """fast_mpc_init.m:12-27."""
+        n, m, T = self._check()
+        if self.x_init is not None:
+            return self.x_init.copy()
+        z = np.zeros((T, m + n))
+        z[:, :m] = (self.u_min + self.u_max) / 2
+        z[:, m:] = (self.x_min + self.x_max) / 2
+        return z.reshape(-1)
+
+    def mpc_fixed_log_newton(self, nw, k, nu0=None):
+        """Fast_MPC2.m:124-130 -- the hot entry (README.md:555)."""
+        h = self._handle()
+        z, self.last_info = self._solve(h, self.x_init, int(nw), float(k), nu0)
+        return z
+
+    def mpc_fixed_log(self, k, nu0=None):
+        """Fast_MPC2.m:116-123 -- nw = []: <= 1000 iterations, tolerance exit."""
+        h = self._handle()
+        z, self.last_info = self._solve(h, self.x_init, 0, float(k), nu0)
+        return z
+
+    def _k_schedule(self, nw, nu0s):
+        h = self._handle()
+        z = self.initialize()
+        k, mu = 1.0, 1.0 / 10
+        infos = []
+        x_opt = z
+        it = 0
+        while k * z.shape[0] >= 10e-3:               # Fast_MPC2.m:108,138
+            nu0 = None if nu0s is None else nu0s[it]
+            x_opt, info = self._solve(h, z, nw, k, nu0)
+            info["k"] = k
+            infos.append(info)
+            k = mu * k
+            z = x_opt
+            it += 1
+        self.last_info = infos
+        return x_opt
+
+    def mpc_solve_full(self, nu0s=None):
+        """Fast_MPC2.m:100-115."""
+        return self._k_schedule(0, nu0s)
+
+    def mpc_fixed_newton(self, nw, nu0s=None):
+        """Fast_MPC2.m:131-144."""
+        return self._k_schedule(int(nw), nu0s)
+
+    def mpc_solve_check(self, k_min, k_max, nu0s=None):
+        """Fast_MPC2.m:88-99."""
+        h = self._handle()
+        z = self.initialize()
+        infos = []
+        x_opt = z
+        for i, k in enumerate(np.linspace(k_max, k_min, 5)):
+            nu0 = None if nu0s is None else nu0s[i]
+            x_opt, info = self._solve(h, z, 0, float(k), nu0)
+            info["k"] = float(k)
+            infos.append(info)
+            z = x_opt
+        self.last_info = infos
+        return x_opt
+
+    def matlab_solve(self):
+        raise NotImplementedError("fmincon path (Fast_MPC2.m:76-87) is outside the fastMPC hot path")
+
+    fomulate_mpc = matlab_solve
+
+
+class Fast_MPC2_VAR1(Fast_MPC2):
+    """VAR(1) form: Fast_MPC2(Q,R,S,Qf,q,r,qf,xmin,xmax,umin,umax,dumin,dumax,T,x0,u_prev,
+    A,B,w,xf,x_init)  (VAR_1/Fast_MPC2.m:26-27).
+
+    The device path solves the *intended* VAR(1) dynamics (VAR_2 code with A2 = 0; the reference's
+    misplaced row block VAR_1/fast_mpc_eq_const.m:36 is not reproduced).
+    VAR_1's ramp-rate rows (VAR_1/fast_mpc_ineq_const.m:58-76) are not on the device yet, so the
+    caller has to opt out of them explicitly with ramp=False; otherwise every driver raises
+    FMPC_E_UNSUPPORTED rather than silently solving a different problem."""
+
+    var_order = 1
+
+    def __init__(self, Q, R, S, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, u_prev,
+                 A, B, w, xf, x_init, *, ramp=True, device=0, rng=None):
+        super().__init__(Q, R, S, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, None,
+                         u_prev, A, None, B, w, xf, x_init, device=device, rng=rng)
+        self.ramp = bool(ramp)
+
+    def _handle(self):
+        if self.ramp:
+            raise FastMPCError(_lib.FMPC_E_UNSUPPORTED,
+                               "VAR_1 ramp-rate constraints are not on the device yet (pass ramp=False)")
+        return super()._handle()

@@ -1,0 +1,183 @@
+"""Shared-model handle: the batched entry point above the C ABI.
+
+`FastMPCHandle` owns one `fmpc_handle` (include/fastmpc.h).  `solve` takes host numpy arrays
+(problem-major: shape (batch, len), which is MATLAB's len x batch column-major layout);
+`solve_device` takes torch tensors that already live in HBM and launches on torch's current
+stream, so inputs stay resident between MPC steps and `torch.cuda.Event` timing sees the kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FastMPCError
+
+
+def _f64(a, shape=None, name="array"):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and a.size != int(np.prod(shape)):
+        raise FastMPCError(_lib.FMPC_E_DIM, f"{name}: expected {shape}, got {a.shape}")
+    return a
+
+
+def _colmajor(M, rows, cols, name):
+    """Flatten a matrix to MATLAB's column-major order."""
+    if M is None:
+        return None
+    M = np.asarray(M, dtype=np.float64)
+    if M.ndim == 0:
+        M = M.reshape(1, 1)
+    if M.shape != (rows, cols):
+        raise FastMPCError(_lib.FMPC_E_DIM, f"{name}: expected {(rows, cols)}, got {M.shape}")
+    return np.ascontiguousarray(M.T).reshape(-1)      # C-order of M' == column-major of M
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FastMPCHandle:
+    """Everything that does not change between timesteps (Fast_MPC2.m:30-54 minus x0, x0_pre,
+    w, x_init): A1, A2, B, Q, R, Qf, q, r, qf, bounds, xf, T."""
+
+    def __init__(self, A1, A2, B, Q, R, Qf, u_min, u_max, x_min, x_max, T, q=None, r=None,
+                 qf=None, xf=None, var_order=2, device=0):
+        lib = _lib.load()
+        A1 = np.asarray(A1, dtype=np.float64)
+        B = np.asarray(B, dtype=np.float64)
+        if A1.ndim != 2 or A1.shape[0] != A1.shape[1] or B.ndim != 2 or B.shape[0] != A1.shape[0]:
+            raise FastMPCError(_lib.FMPC_E_DIM, "A1/B")
+        n, m = A1.shape[0], B.shape[1]
+        self.n, self.m, self.T = n, m, int(T)
+        self.var_order = int(var_order)
+        self.has_xf = xf is not None
+        self.nz = self.T * (n + m)
+        self.nu_len = n * (self.T + (1 if self.has_xf else 0))
+        self.device = int(device)
+        args = [
+            _colmajor(A1, n, n, "A1"), _colmajor(A2, n, n, "A2"), _colmajor(B, n, m, "B"),
+            _colmajor(Q, n, n, "Q"), _colmajor(R, m, m, "R"), _colmajor(Qf, n, n, "Qf"),
+            _f64(q, (n,), "q"), _f64(r, (m,), "r"), _f64(qf, (n,), "qf"),
+            _f64(x_min, (n,), "x_min"), _f64(x_max, (n,), "x_max"),
+            _f64(u_min, (m,), "u_min"), _f64(u_max, (m,), "u_max"), _f64(xf, (n,), "xf"),
+        ]
+        h = C.c_void_p()
+        rc = lib.fmpc_create(C.byref(h), n, m, self.T, self.var_order, *[_ptr(a) for a in args],
+                             self.device)
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_create")
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ host buffers
+    def solve(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
+              return_info=False, check=True):
+        """One `inf_newton_solver` per problem.  x0: (batch, n) or (n,).  Returns z (batch, N_z)
+        (or (N_z,) for a single vector input); with return_info also a dict nu/status/iters/step."""
+        single = np.asarray(x0).ndim == 1
+        x0 = _f64(x0)
+        batch = 1 if single else x0.shape[0]
+        x0 = _f64(x0, (batch, self.n), "x0")
+        x0_pre = _f64(x0_pre, (batch, self.n), "x0_pre")
+        w = _f64(w, (batch, self.T * self.n), "w")
+        z_init = _f64(z_init, (batch, self.nz), "z_init")
+        nu0 = _f64(nu0, (batch, self.nu_len), "nu0")
+        n_newton = 0 if n_newton is None else int(n_newton)
+        sld = self._lib.fmpc_step_ld(n_newton)
+        z = np.empty((batch, self.nz))
+        nu = np.empty((batch, self.nu_len))
+        status = np.zeros(batch, dtype=np.int32)
+        iters = np.zeros(batch, dtype=np.int32)
+        step = np.empty((batch, sld))
+        rc = self._lib.fmpc_solve(self._h, batch, _ptr(x0), _ptr(x0_pre), _ptr(w), _ptr(z_init),
+                                  _ptr(nu0), n_newton, float(k), _ptr(z), _ptr(nu), _ptr(status),
+                                  _ptr(iters), _ptr(step))
+        if rc < 0 and check:
+            raise FastMPCError(rc, "fmpc_solve")
+        zr = z[0] if single else z
+        if return_info:
+            return zr, {"nu": nu[0] if single else nu, "status": status, "iters": iters,
+                        "step": step, "rc": rc}
+        return zr
+
+    def unpack(self, z):
+        """README.md:558-570,589: z -> (U, X, u0)."""
+        z = _f64(z)
+        single = z.ndim == 1
+        batch = 1 if single else z.shape[0]
+        z = _f64(z, (batch, self.nz), "z")
+        U = np.empty((batch, self.T * self.m))
+        X = np.empty((batch, self.T * self.n))
+        u0 = np.empty((batch, self.m))
+        rc = self._lib.fmpc_unpack(self._h, batch, _ptr(z), _ptr(U), _ptr(X), _ptr(u0))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_unpack")
+        return (U[0], X[0], u0[0]) if single else (U, X, u0)
+
+    # ------------------------------------------------------------------ device tensors
+    def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
+                     z_out=None, nu_out=None, status=None, iters=None, step=None):
+        """Asynchronous solve on torch CUDA(HIP) tensors, on torch's current stream.
+        Returns (z_out, status, iters).  Nothing is copied through the host."""
+        import torch
+
+        def chk(t, cols, name, dtype=torch.float64):
+            if t is None:
+                return None
+            if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+                raise FastMPCError(_lib.FMPC_E_DIM, f"{name}: need a contiguous {dtype} HIP tensor")
+            if t.numel() != batch * cols:
+                raise FastMPCError(_lib.FMPC_E_DIM, f"{name}: expected {(batch, cols)}")
+            return t
+
+        batch = x0.shape[0]
+        dev = x0.device
+        chk(x0, self.n, "x0"); chk(x0_pre, self.n, "x0_pre"); chk(w, self.T * self.n, "w")
+        chk(z_init, self.nz, "z_init"); chk(nu0, self.nu_len, "nu0")
+        n_newton = 0 if n_newton is None else int(n_newton)
+        if z_out is None:
+            z_out = torch.empty((batch, self.nz), dtype=torch.float64, device=dev)
+        if status is None:
+            status = torch.empty(batch, dtype=torch.int32, device=dev)
+        if iters is None:
+            iters = torch.empty(batch, dtype=torch.int32, device=dev)
+        chk(z_out, self.nz, "z_out"); chk(nu_out, self.nu_len, "nu_out")
+        chk(status, 1, "status", torch.int32); chk(iters, 1, "iters", torch.int32)
+        if step is not None:
+            chk(step, self._lib.fmpc_step_ld(n_newton), "step")
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
+                                         n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                         p(iters), p(step), stream)
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_solve_device")
+        return z_out, status, iters
+
+    def unpack_device(self, z, U=None, X=None, u0=None):
+        import torch
+        batch = z.shape[0]
+        dev = z.device
+        if u0 is None:
+            u0 = torch.empty((batch, self.m), dtype=torch.float64, device=dev)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.fmpc_unpack_device(self._h, batch, p(z), p(U), p(X), p(u0), stream)
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_unpack_device")
+        return U, X, u0

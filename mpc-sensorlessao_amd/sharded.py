@@ -1,0 +1,64 @@
+"""Multi-GPU driver: independent problems are sharded across ranks (one process per GPU), each
+rank solves its contiguous block locally with no data-path collective, and ONE gather at the end
+collects the outputs (RCCL over xGMI when the process group is `nccl`).  SURVEY.md §8(e).
+
+The reference has no distributed code at all; this is the batch partitioning the north-star asks
+for, placed above the drop-in boundary (`mpc_fixed_log_newton`)."""
+from __future__ import annotations
+
+
+def shard_range(batch, world_size, rank):
+    """Contiguous block of ceil(batch/G) problems per rank (the last blocks may be short/empty)."""
+    per = -(-batch // world_size)
+    lo = min(rank * per, batch)
+    return lo, min(lo + per, batch)
+
+
+class ShardedFastMPC:
+    """solve_fn(x0, x0_pre, w, nu0, n_newton, k) -> z (local_batch, N_z) tensor on the rank's
+    device.  On a GPU rank this is `FastMPCHandle.solve_device`; CPU gloo tests inject a checker.
+    """
+
+    def __init__(self, solve_fn, nz, m, T, n, group=None):
+        self.solve_fn = solve_fn
+        self.nz, self.m, self.T, self.n = nz, m, T, n
+        self.group = group
+
+    def _dist(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist, dist.get_world_size(self.group), dist.get_rank(self.group)
+        return None, 1, 0
+
+    def solve_local(self, x0, x0_pre, w, nu0, n_newton, k):
+        """Solve this rank's shard of a replicated global batch.  Returns (z_local, lo, hi)."""
+        _, ws, rank = self._dist()
+        lo, hi = shard_range(x0.shape[0], ws, rank)
+        sl = lambda t: None if t is None else t[lo:hi].contiguous()
+        if hi == lo:
+            return x0.new_zeros((0, self.nz)), lo, hi
+        return self.solve_fn(sl(x0), sl(x0_pre), sl(w), sl(nu0), n_newton, k), lo, hi
+
+    def gather(self, local, batch, what="z"):
+        """One all-gather of the per-rank outputs (rows of `local`) into the global batch order.
+        what: "z" (N_z), "u0" (first move, README.md:589), "U" (T*m)."""
+        import torch
+        dist, ws, rank = self._dist()
+        if what == "u0":
+            local = local[:, :self.m].contiguous()
+        elif what == "U":
+            local = local.reshape(local.shape[0], self.T, self.n + self.m)[:, :, :self.m] \
+                         .reshape(local.shape[0], self.T * self.m).contiguous()
+        if ws == 1:
+            return local
+        per = -(-batch // ws)
+        cols = local.shape[1]
+        pad = local.new_zeros((per, cols))
+        pad[:local.shape[0]] = local
+        out = local.new_empty((ws * per, cols))
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return out[:batch]
+
+    def solve_gather(self, x0, x0_pre, w, nu0, n_newton, k, what="u0"):
+        z, lo, hi = self.solve_local(x0, x0_pre, w, nu0, n_newton, k)
+        return self.gather(z, x0.shape[0], what)

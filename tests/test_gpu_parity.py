@@ -1,0 +1,111 @@
+"""HIP path (through the C ABI) vs the structured oracle on the same seeded inputs.
+Tolerance: 1e-9 relative on z (fp64; north-star "stated fp64 tolerance"), iteration counts,
+status codes and line-search steps identical."""
+import numpy as np
+import pytest
+
+from tests.util import handle_from_model, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _run(pkg, model, data, nw, k, z_init=None):
+    h = handle_from_model(pkg, model)
+    z, info = h.solve(data["x0"], data.get("x0_pre"), data.get("w"), z_init=z_init,
+                      nu0=data.get("nu0"), n_newton=nw, k=k, return_info=True, check=False)
+    h.close()
+    return z, info
+
+
+def _compare(pkg, model, data, nw, k, z_init=None, tol=TOL):
+    z, info = _run(pkg, model, data, nw, k, z_init)
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, k, z_init)
+    assert np.array_equal(info["status"], sto), (info["status"], sto)
+    assert np.array_equal(info["iters"], ito), (info["iters"], ito)
+    for p in range(z.shape[0]):
+        assert rel_err(z[p], zo[p]) <= tol, (p, rel_err(z[p], zo[p]))
+        assert rel_err(info["nu"][p], nuo[p]) <= 1e-7
+        got = info["step"][p][:ito[p]]
+        assert np.array_equal(got, np.array(steps[p])), (p, got, steps[p])
+        assert np.all(info["step"][p][ito[p]:] == -1.0)
+    return z, info
+
+
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("var_order", [2, 1])
+@pytest.mark.parametrize("nw", [1, 5, 0])
+def test_reference_demo_config(pkg, gpu, xf, var_order, nw):
+    """test_fast_mpc.m:8-37 configuration (n=8, m=5, T=10, k=0.01)."""
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=3, xf=xf, var_order=var_order, batch=4)
+    _compare(pkg, model, data, nw, 0.01)
+
+
+@pytest.mark.parametrize("T", [1, 2, 3])
+def test_short_horizons(pkg, gpu, T):
+    model, data = pkg.synthetic.make_test_problem(4, 3, T, seed=5, xf=(T == 2), batch=3)
+    _compare(pkg, model, data, 4, 0.1)
+
+
+def test_active_barrier_and_backtracking(pkg, gpu):
+    """Tight box, strong barrier, off-centre start: t < 1 steps."""
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=7, umax=0.3, batch=6)
+    rng = np.random.default_rng(11)
+    nz = 10 * 13
+    z0 = np.zeros((6, nz)).reshape(6, 10, 13)
+    z0[:, :, :5] = rng.uniform(-0.25, 0.25, (6, 10, 5))
+    z0[:, :, 5:] = rng.uniform(-1, 1, (6, 10, 8))
+    z0 = z0.reshape(6, nz)
+    z, info = _compare(pkg, model, data, 8, 10.0, z_init=z0)
+    assert np.any((info["step"] > 0) & (info["step"] < 1)), "case must exercise backtracking"
+
+
+def test_linesearch_collapse_warning(pkg, gpu):
+    """k=100, u_max=0.2: the search collapses; reference ends at t=0 (quirk D2)."""
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=9, umax=0.2, batch=2)
+    z, info = _run(pkg, model, data, 3, 100.0)
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, 3, 100.0)
+    assert np.array_equal(info["status"], sto)
+    for p in range(2):
+        assert rel_err(z[p], zo[p]) <= TOL
+
+
+@pytest.mark.parametrize("T,nw", [(2, 1), (10, 5), (30, 1), (30, 5)])
+def test_ao_config_batch(pkg, gpu, T, nw):
+    """n=27 Zernike modes, m=144 actuators, README weights; replay batch of 64 problems."""
+    model = pkg.synthetic.make_model(27, 144, T)
+    data = pkg.synthetic.make_replay_batch(model, r=1, steps=64)
+    _compare(pkg, model, data, nw, 1e-2)
+
+
+def test_ao_config_tight_bounds(pkg, gpu):
+    """Same model with a box the optimum presses against, so several Newton steps are real."""
+    model = pkg.synthetic.make_model(27, 144, 10)
+    model["u_min"] = -0.05 * np.ones(144); model["u_max"] = 0.05 * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(model, r=2, steps=16)
+    z, info = _compare(pkg, model, data, 6, 1e-2)
+    assert info["iters"].min() >= 3
+
+
+def test_deterministic_and_position_independent(pkg, gpu):
+    model = pkg.synthetic.make_model(27, 144, 10)
+    data = pkg.synthetic.make_replay_batch(model, r=3, steps=48)
+    z1, _ = _run(pkg, model, data, 3, 1e-2)
+    z2, _ = _run(pkg, model, data, 3, 1e-2)
+    assert np.array_equal(z1, z2), "two runs must agree bitwise"
+    perm = np.random.default_rng(0).permutation(48)
+    dperm = {k: (None if v is None else v[perm]) for k, v in data.items()}
+    z3, _ = _run(pkg, model, dperm, 3, 1e-2)
+    assert np.array_equal(z3, z1[perm]), "a problem's result must not depend on its batch slot"
+
+
+def test_unpack(pkg, gpu):
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=1, batch=5)
+    h = handle_from_model(pkg, model)
+    z = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=2, k=0.01)
+    U, X, u0 = h.unpack(z)
+    Z = z.reshape(5, 10, 13)
+    assert np.array_equal(U, Z[:, :, :5].reshape(5, -1))
+    assert np.array_equal(X, Z[:, :, 5:].reshape(5, -1))
+    assert np.array_equal(u0, Z[:, 0, :5])
+    h.close()
