@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfastmpc.so")
+LIB_PATH = os.environ.get("FMPC_LIB") or os.path.join(_HERE, "lib", "libfastmpc.so")
 
 FMPC_OK = 0
 FMPC_W_LINESEARCH = 1

@@ -22,6 +22,21 @@ hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const
 hipError_t fmpc_launch_unpack(int n, int m, int T, int batch, const double* z, double* U,
                               double* X, double* u0, hipStream_t stream);
 
+// one-wave-per-problem MFMA kernel (fmpc_kernel_wave.hip)
+size_t fmpc_wave_lds_bytes(int n, int mp);
+bool fmpc_wave_supports(int n);
+int fmpc_wave_img_stride(int n);
+int fmpc_wave_mp(int m);
+int fmpc_wave_waves_per_wg();
+size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb);
+void fmpc_wave_make_images(int n, const double* blk, double* out);
+hipError_t fmpc_wave_prepare(int n, size_t lds_bytes);
+hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, int grid,
+                            const double* x0, const double* x0p, const double* w, const double* zinit,
+                            const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
+                            int* status, int* iters, double* step, int step_ld, double* ws,
+                            size_t ws_stride, size_t lds_bytes, hipStream_t stream);
+
 #define FMPC_LDS_LIMIT (160 * 1024)
 
 struct fmpc_handle_s {
@@ -32,6 +47,12 @@ struct fmpc_handle_s {
     int* pool_i;                 // and one for the index arrays
     size_t lds_bytes;
     int wg_per_cu;
+    // wave kernel (n = 27): used when available unless FMPC_FORCE_GENERIC=1
+    int use_wave;
+    FwModel wave;
+    double* wave_pool_d;
+    int* wave_pool_i;
+    size_t wave_lds;
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
@@ -120,6 +141,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->nb = T + h->has_xf; h->device = device;
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
+    h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -243,6 +265,44 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
 
     if (fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+
+    // ---- wave kernel: MFMA-layout images of the constant blocks (+ a zero block), padded B'
+    const char* force = getenv("FMPC_FORCE_GENERIC");
+    const int mp = fmpc_wave_mp(m);
+    if (fmpc_wave_supports(n) && !(force && force[0] == '1') &&
+        fmpc_wave_lds_bytes(n, mp) <= FMPC_LDS_LIMIT) {
+        const int stride = fmpc_wave_img_stride(n);
+        const int nblk = (int)blocks.size();
+        std::vector<double> wpool((size_t)(nblk + 1) * stride, 0.0);      // last = zero block
+        for (int k = 0; k < nblk; ++k) fmpc_wave_make_images(n, blocks[k].data(), wpool.data() + (size_t)k * stride);
+        const size_t oBtP = wpool.size();
+        wpool.resize(oBtP + (size_t)mp * 33, 0.0);
+        for (int c = 0; c < m; ++c)
+            for (int rr = 0; rr < n; ++rr) wpool[oBtP + (size_t)c * 33 + rr] = bt[(size_t)c * n + rr];
+        std::vector<int> wi;
+        for (int i = 0; i < h->nb; ++i) wi.push_back(idxD[i]);
+        for (int i = 0; i < h->nb; ++i) wi.push_back(idx1[i] >= 0 ? idx1[i] : nblk);
+        for (int i = 0; i < h->nb; ++i) wi.push_back(idx2[i] >= 0 ? idx2[i] : nblk);
+        if (hipMalloc((void**)&h->wave_pool_d, wpool.size() * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&h->wave_pool_i, wi.size() * sizeof(int)) != hipSuccess) {
+            fmpc_destroy(h);
+            return FMPC_E_ALLOC;
+        }
+        if (hipMemcpy(h->wave_pool_d, wpool.data(), wpool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->wave_pool_i, wi.data(), wi.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            fmpc_destroy(h);
+            return FMPC_E_HIP;
+        }
+        h->wave.mp = mp;
+        h->wave.img = h->wave_pool_d;
+        h->wave.BtP = h->wave_pool_d + oBtP;
+        h->wave.iD = h->wave_pool_i;
+        h->wave.i1 = h->wave_pool_i + h->nb;
+        h->wave.i2 = h->wave_pool_i + 2 * h->nb;
+        h->wave_lds = fmpc_wave_lds_bytes(n, mp);
+        if (fmpc_wave_prepare(n, h->wave_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+        h->use_wave = 1;
+    }
     *out = h;
     return FMPC_OK;
 }
@@ -252,6 +312,8 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     (void)hipSetDevice(h->device);
     if (h->pool_d) (void)hipFree(h->pool_d);
     if (h->pool_i) (void)hipFree(h->pool_i);
+    if (h->wave_pool_d) (void)hipFree(h->wave_pool_d);
+    if (h->wave_pool_i) (void)hipFree(h->wave_pool_i);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -297,14 +359,32 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
     std::lock_guard<std::mutex> lk(h->mu);
-    const int grid = fmpc_grid_for(h, batch);
-    size_t stride = 0;
-    int rc = fmpc_ensure_ws(h, h->num_cu * h->wg_per_cu, &stride);   // full size once: no regrowth
-    if (rc != FMPC_OK) return rc;
     const int max_iter = n_newton > 0 ? n_newton : 1000;
-    hipError_t e = fmpc_launch_generic(h->dev, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
-                                       z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
-                                       h->ws, stride, (hipStream_t)stream);
+    hipError_t e;
+    if (h->use_wave) {
+        // one wavefront per problem, 8 per workgroup, one workgroup per CU
+        const int wpw = fmpc_wave_waves_per_wg();
+        int grid = (batch + wpw - 1) / wpw;
+        if (grid > h->num_cu) grid = h->num_cu;
+        const size_t stride = fmpc_wave_ws_doubles(h->n, h->m, h->wave.mp, h->T, h->nb);
+        const size_t need = stride * (size_t)h->num_cu * wpw;
+        if (need > h->ws_doubles) {
+            if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_doubles = 0; }
+            if (hipMalloc((void**)&h->ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+            h->ws_doubles = need;
+        }
+        e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                             z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
+                             h->wave_lds, (hipStream_t)stream);
+    } else {
+        const int grid = fmpc_grid_for(h, batch);
+        size_t stride = 0;
+        int rc = fmpc_ensure_ws(h, h->num_cu * h->wg_per_cu, &stride);   // full size once: no regrowth
+        if (rc != FMPC_OK) return rc;
+        e = fmpc_launch_generic(h->dev, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                                z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
+                                h->ws, stride, (hipStream_t)stream);
+    }
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 

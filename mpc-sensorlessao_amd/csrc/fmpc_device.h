@@ -52,3 +52,13 @@ __host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int 
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
+
+// Extras of the one-wave-per-problem kernel (fmpc_kernel_wave.hip), device pointers.
+struct FwModel {
+    int mp;                 // m rounded up to a multiple of 4 (MFMA k-steps)
+    const double* BtP;      // mp x 33, zero padded:  BtP[c*33 + r] = B[r][c]
+    const double* img;      // per unique block: MFMA-layout images (see FwCfg in the kernel file)
+    const int* iD;          // per block row: block id of the constant part of Y_ii
+    const int* i1;          //                of Y_{i,i+1}   (zero block if none)
+    const int* i2;          //                of Y_{i,i+2}   (zero block if none)
+};

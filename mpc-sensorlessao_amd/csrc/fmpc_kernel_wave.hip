@@ -1,0 +1,936 @@
+// CDNA4 fastMPC Newton kernel, one WAVEFRONT per problem, for 16 < n < 28 (n = 27 Zernike modes).
+//
+// Same algorithm and reference correspondence as fmpc_kernel_generic.hip (inf_newton_solver.m:10-41);
+// what changes is the mapping to the machine:
+//   * every matrix product runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64):
+//       - the block products of the block-penta-diagonal Cholesky, kept in the transposed form
+//           U_{i,i+1} = L_ii^-1 (Y_{i,i+1} - U_{i-1,i}' U_{i-1,i+1}),  U_{i,i+2} = L_ii^-1 Y_{i,i+2},
+//           S_ii = Y_ii + B Rt_i^-1 B' - U_{i-1,i}' U_{i-1,i} - U_{i-2,i}' U_{i-2,i}
+//         so that every product is X'Z (contraction over the ROW index of both operands): an MFMA
+//         accumulator tile (row = 4*reg + lane/16, col = lane%16) is then directly the A and the B
+//         operand of the next product -- no LDS round trip between products;
+//       - the applications of C and C' to the stacked vectors (residuals r_d, r_p, the right-hand
+//         side, d_z): the T horizon stages are the N dimension of a GEMM (32 stage columns/pass).
+//   * tiles are 32 x 32 (2 x 2 subtiles of 16 x 16); column n of the U tiles carries y_i, so the
+//     forward substitution of the right-hand side rides in the padding of the MFMA tiles.
+//   * potrf(S_ii) and the triangular solves L^-1 [M1 | rhs | Y2 | rhs] are ONE fused column loop on
+//     the VALU: lane r holds row r of S (right-looking potrf) and lane c holds column c of the
+//     right-hand sides; each L[c][k] is broadcast once with v_readlane and feeds both updates.
+//   * the factor (L, U1, U2 per stage) is streamed to HBM in the forward sweep and read back once,
+//     in reverse, by the backward sweep.
+// 8 waves (= 8 problems) per workgroup share B' in LDS; each wave owns two 32 x 29 LDS tiles used
+// only to change layout between MFMA tiles and the row/column-per-lane VALU layouts.  Each phase is
+// a separate non-inlined function (own register allocation); parameters come from the kernarg
+// segment through scalar loads.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "fmpc_device.h"
+#include "../../include/fastmpc.h"
+
+#define FW_WAVES 8
+#define FW_THREADS (FW_WAVES * 64)
+#define FW_MAX_HALVINGS 64
+#define FW_LDB 33                       // leading dimension of B' in LDS (odd)
+#define FW_KCH 6                        // k-steps per prefetch chunk of the K = m products
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef __attribute__((address_space(3))) double* fw_lds_t;
+typedef const __attribute__((address_space(3))) double* fw_clds_t;
+#define FW_FN __device__ __noinline__
+
+// Diagnostic build only (-DFW_TIMING): per-phase cycle totals, never in the shipped library.
+#ifdef FW_TIMING
+__device__ unsigned long long fw_timing[16];
+#define FW_T0() unsigned long long _t0 = __builtin_readcyclecounter(), _t1, _a0 = 0, _a1 = 0, _a2 = 0, _a3 = 0
+#define FW_TICK(k) do { _t1 = __builtin_readcyclecounter(); _a##k += _t1 - _t0; _t0 = _t1; } while (0)
+#define FW_TFLUSH(base) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&fw_timing[base], _a0); atomicAdd(&fw_timing[base + 1], _a1); atomicAdd(&fw_timing[base + 2], _a2); atomicAdd(&fw_timing[base + 3], _a3); } } while (0)
+extern "C" int fmpc_debug_timing(unsigned long long* out) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fw_timing), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fw_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#else
+#define FW_T0()
+#define FW_TICK(k)
+#define FW_TFLUSH(base)
+#endif
+
+template <int N>
+struct FwCfg {
+    static_assert(N > 16 && N < 28, "wave kernel: 16 < n < 28");
+    static constexpr int RC = N;                  // tile column that carries the rhs / y_i
+    static constexpr int LD = 29;                 // LDS tile leading dimension (odd); col 28 = dump
+    static constexpr int LDG = (N + 2) & ~1;      // HBM factor tile leading dimension (even)
+    static constexpr int TILE = 32 * LD;
+    static constexpr int PER_WAVE = 2 * TILE;                 // tA, tB
+    static constexpr int IMG_D = 3 * 4 * 64;                  // subtiles (0,0),(0,1),(1,1)
+    static constexpr int IMG_1 = 4 * 4 * 64;                  // full tile
+    static constexpr int IMG_2 = N * 32;                      // [row j][col c] for column-per-lane loads
+    static constexpr int IMG_STRIDE = IMG_D + IMG_1 + IMG_2;
+};
+
+// per-wave workspace in HBM (doubles)
+struct FwWs { size_t b, nu, hess, winv, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
+__host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T, int nb, int LDG) {
+    FwWs L; size_t o = 0;
+    const size_t nbn = ((size_t)nb * N + 1) & ~(size_t)1;
+    L.b = o; o += nbn;  L.nu = o; o += nbn;
+    L.hess = o; o += (size_t)T * m;  L.winv = o; o += (size_t)T * mp;
+    L.rdu = o; o += (size_t)T * m;   L.rdx = o; o += nbn;
+    L.rp = o; o += nbn;  L.rhs = o; o += nbn;  L.y = o; o += nbn;  L.dnu = o; o += nbn;
+    L.phx = o; o += nbn;
+    L.rs = o; o += (size_t)nb * 32;
+    o = (o + 1) & ~(size_t)1;
+    L.fac = o; o += (size_t)nb * 3 * N * LDG;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+
+// The kernel's ONLY parameter: phases re-read it from the kernarg segment (scalar loads).
+struct FwParams {
+    FmpcDevModel M;
+    FwModel V;
+    int batch, max_iter, step_ld, pad_;
+    double kbar;
+    const double* x0; const double* x0p; const double* w; const double* zinit; const double* nu0;
+    double* zout; double* nuout; int* status; int* iters; double* step;
+    double* ws; size_t ws_stride;
+};
+
+typedef const FwParams __attribute__((address_space(4))) * FwKP;
+__device__ __forceinline__ FwKP fw_params() {
+    return (FwKP)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// A function argument arrives in VGPRs; make the kernarg pointer wave-uniform again so that
+// every P->field is a scalar load.
+__device__ __forceinline__ FwKP fw_uniform(FwKP P) {
+    const unsigned long long a = (unsigned long long)P;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (FwKP)(((unsigned long long)hi << 32) | lo);
+}
+// 1/x: hardware estimate + two Newton steps (<= 1 ulp; the parity tolerance is 1e-9)
+__device__ __forceinline__ double fw_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
+__device__ __forceinline__ double fw_readlane(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fw_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;                            // every lane holds the sum (fixed order: reproducible)
+}
+// 1/sqrt(d): hardware estimate + two Newton steps (full fp64 accuracy, no division)
+__device__ __forceinline__ double fw_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ void fw_wave_fence() {          // order LDS traffic inside the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void fw_mem_fence() {           // this wave's HBM writes -> its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Per-wave pointers, rebuilt in each phase from the kernarg parameters.
+template <int N>
+struct FwView {
+    int m, mp, T, nb, s, has_xf, var2;
+    double *zp, *b, *nu, *hess, *winv, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
+    __device__ __forceinline__ FwView(FwKP P, int p) {
+        m = P->M.m; mp = P->V.mp; T = P->M.T; nb = P->M.nb; s = N + m; has_xf = P->M.has_xf; var2 = P->M.var2;
+        const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG);
+        const int wave_g = blockIdx.x * FW_WAVES + (threadIdx.x >> 6);
+        double* wsp = P->ws + (size_t)wave_g * P->ws_stride;
+        zp = P->zout + (size_t)p * T * s;
+        b = wsp + L.b; nu = wsp + L.nu; hess = wsp + L.hess; winv = wsp + L.winv; rdu = wsp + L.rdu;
+        rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
+        phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// P0: start point, nu, b   (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
+template <int N>
+FW_FN void fw_phase_init(FwKP Pin, int p) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63;
+    const int Nz = W.T * W.s, nbn = W.nb * N, m = W.m;
+    const double* zinit = P->zinit;
+    for (int idx = lane; idx < Nz; idx += 64) {
+        const int e = idx % W.s;
+        W.zp[idx] = zinit ? zinit[(size_t)p * Nz + idx] : (e < m ? P->M.umid[e] : P->M.xmid[e - m]);
+    }
+    const double* x0v = P->x0 + (size_t)p * N;
+    const double* x0pv = P->x0p ? P->x0p + (size_t)p * N : nullptr;
+    const double* w = P->w;
+    const double* nu0 = P->nu0;
+    for (int idx = lane; idx < nbn; idx += 64) {
+        W.nu[idx] = nu0 ? nu0[(size_t)p * nbn + idx] : 0.0;
+        const int i = idx / N, r = idx - i * N;
+        double v = (i < W.T && w) ? w[(size_t)p * W.T * N + idx] : 0.0;
+        if (i == 0) {
+            for (int c = 0; c < N; ++c) v += P->M.A1t[c * N + r] * x0v[c];
+            if (W.var2 && x0pv)
+                for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0pv[c];
+        } else if (i == 1 && i < W.T && W.var2) {
+            for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0v[c];
+        }
+        if (i == W.T) v = P->M.xf[r];
+        W.b[idx] = v;
+    }
+    if (P->step)
+        for (int idx = lane; idx < P->step_ld; idx += 64) P->step[(size_t)p * P->step_ld + idx] = -1.0;
+    fw_mem_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// C' applied to a stacked dual vector v (nu or d_nu), all stages at once on the matrix cores.
+//   MODE 0 (P1): r_d = 2Hz + g + kP'd + C'nu, barrier pieces, Phi^-1 r_d on the x entries;
+//                out3 = { sum(r_d^2), -, "Phi not PD" flag }.
+//   MODE 1 (P5): d_z = Phi^-1(-r_d - C'd_nu) written over r_d; out3 = { <r_d,e>, ||e||^2, - }
+//                with e = k P'DP d_z (line search).
+template <int N, int MODE>
+FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const fw_clds_t sBt = (fw_clds_t)lds_g;
+    const fw_lds_t out3 = (fw_lds_t)out3_g;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int m = W.m, mp = W.mp, T = W.T, s = W.s;
+    const double* vec = MODE == 0 ? W.nu : W.dnu;
+    const double kbar = P->kbar;
+    const double* umaxp = P->M.umax; const double* uminp = P->M.umin;
+    const double* R2p = P->M.R2; const double* rlp = P->M.rl;
+    const double* A1p = P->M.A1; const double* A2p = P->M.A2;
+    const double* Q2p = P->M.Q2; const double* Qf2p = P->M.Qf2;
+    const double* qlp = P->M.ql; const double* qflp = P->M.qfl;
+    double acc0 = 0.0, acc1 = 0.0;
+    int bad = 0;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        // ---- u entries: G[c][j] = sum_r B[r][c] v_j[r]   (m x 32 stages, K = n)
+        double zn[2][7];
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int j = j0 + 16 * J + c16, k = 4 * ks + g;
+                zn[J][ks] = (k < N && j < T) ? vec[j * N + k] : 0.0;
+            }
+        for (int I = 0; I * 16 < m; ++I) {
+            d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            const fw_clds_t xr = sBt + (16 * I + c16) * FW_LDB + g;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const double a = xr[4 * ks];                  // B[k][c], zero for k >= n
+                a0 = MFMA64(a, zn[0][ks], a0);
+                a1 = MFMA64(a, zn[1][ks], a1);
+            }
+            // epilogue on the 8 (c, stage) elements this lane holds: all loads, then math, then stores
+            {
+                bool ok[8]; int ic[8], ij[8]; double in0[8], in1[8], in2[8], in3[8], in4[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * I + 4 * (e & 3) + g, j = j0 + 16 * (e >> 2) + c16;
+                    ok[e] = c < m && j < T;
+                    ic[e] = ok[e] ? c : 0; ij[e] = ok[e] ? j : 0;
+                    if (MODE == 0) {
+                        in0[e] = W.zp[ij[e] * s + ic[e]];
+                        in1[e] = umaxp[ic[e]]; in2[e] = uminp[ic[e]]; in3[e] = R2p[ic[e]]; in4[e] = rlp[ic[e]];
+                    } else {
+                        in0[e] = W.rdu[ij[e] * m + ic[e]];
+                        in1[e] = W.winv[ij[e] * mp + ic[e]];
+                        in2[e] = W.hess[ij[e] * m + ic[e]];
+                    }
+                }
+                double o0[8], o1[8], o2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double G = (e >> 2) == 0 ? a0[e & 3] : a1[e & 3];
+                    if (MODE == 0) {
+                        const double u = in0[e];
+                        const double dp = fw_rcp(in1[e] - u), dm = fw_rcp(u - in2[e]);
+                        const double hs = kbar * (dp * dp + dm * dm);
+                        const double rt = in3[e] + hs;
+                        if (ok[e] && (!(rt > 0.0) || isinf(rt))) bad = 1;
+                        const double rd = in3[e] * u + in4[e] + kbar * (dp - dm) - G;
+                        o0[e] = hs; o1[e] = fw_rcp(rt); o2[e] = rd;
+                        if (ok[e]) acc0 += rd * rd;
+                    } else {
+                        const double rd = in0[e];
+                        const double du = (G - rd) * in1[e];
+                        const double ee = in2[e] * du;             // k P'DP dz
+                        o0[e] = du;
+                        if (ok[e]) { acc0 += rd * ee; acc1 += ee * ee; }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (ok[e]) {
+                        if (MODE == 0) {
+                            W.hess[ij[e] * m + ic[e]] = o0[e];
+                            W.winv[ij[e] * mp + ic[e]] = o1[e];
+                            W.rdu[ij[e] * m + ic[e]] = o2[e];
+                        } else {
+                            W.rdu[ij[e] * m + ic[e]] = o0[e];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- x entries (x_j, j = jj+1): H[r][jj] = sum_k A1[k][r] v_j[k] + A2[k][r] v_{j+1}[k]
+        double z1[2][7], z2[2][7];
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int j = j0 + 16 * J + c16 + 1, k = 4 * ks + g;
+                z1[J][ks] = (k < N && j < T) ? vec[j * N + k] : 0.0;
+                z2[J][ks] = (k < N && j + 1 < T && W.var2) ? vec[(j + 1) * N + k] : 0.0;
+            }
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            const int rr = 16 * I + c16;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int k = 4 * ks + g;
+                const bool ok = k < N && rr < N;
+                const int off = ok ? k * N + rr : 0;
+                const double t1 = A1p[off], t2 = A2p[off];
+                const double x1 = ok ? t1 : 0.0, x2 = ok ? t2 : 0.0;
+                a0 = MFMA64(x1, z1[0][ks], a0);
+                a1 = MFMA64(x1, z1[1][ks], a1);
+                a0 = MFMA64(x2, z2[0][ks], a0);
+                a1 = MFMA64(x2, z2[1][ks], a1);
+            }
+            {
+                bool ok[8], last[8]; int ir[8], ijj[8]; double q2[8], vprev[8], vxf[8], in0[8], in1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 16 * I + 4 * (e & 3) + g, jj = j0 + 16 * (e >> 2) + c16;
+                    ok[e] = row < N && jj < T;
+                    ir[e] = ok[e] ? row : 0; ijj[e] = ok[e] ? jj : 0;
+                    last[e] = ijj[e] + 1 == T;
+                    q2[e] = last[e] ? Qf2p[ir[e]] : Q2p[ir[e]];
+                    vprev[e] = vec[ijj[e] * N + ir[e]];
+                    vxf[e] = vec[(last[e] && W.has_xf ? T : ijj[e]) * N + ir[e]];
+                    if (MODE == 0) {
+                        in0[e] = W.zp[ijj[e] * s + m + ir[e]];
+                        in1[e] = last[e] ? qflp[ir[e]] : qlp[ir[e]];
+                    } else {
+                        in0[e] = W.rdx[ijj[e] * N + ir[e]];
+                    }
+                }
+                double o0[8], o1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double H = (e >> 2) == 0 ? a0[e & 3] : a1[e & 3];
+                    const double iq = fw_rcp(q2[e]);
+                    if (MODE == 0) {
+                        double v = q2[e] * in0[e] + in1[e] + vprev[e] - H;
+                        if (last[e] && W.has_xf) v += vxf[e];
+                        o0[e] = v; o1[e] = v * iq;                  // r_d and Phi^-1 r_d on x_j
+                        if (ok[e]) acc0 += v * v;
+                    } else {
+                        double v = -in0[e] - vprev[e] + H;
+                        if (last[e] && W.has_xf) v -= vxf[e];
+                        o0[e] = v * iq;                              // d_x
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (ok[e]) {
+                        W.rdx[ijj[e] * N + ir[e]] = o0[e];
+                        if (MODE == 0) W.phx[ijj[e] * N + ir[e]] = o1[e];
+                    }
+                }
+            }
+        }
+    }
+    acc0 = fw_wave_sum(acc0);
+    acc1 = fw_wave_sum(acc1);
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0) { out3[0] = acc0; out3[1] = acc1; out3[2] = anybad ? 1.0 : 0.0; }
+    fw_mem_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// C applied to a stacked primal vector, all stages at once on the matrix cores.
+//   MODE 0 (P1): r_p = C z - b; out1 = sum(r_p^2).
+//   MODE 1 (P2): rhs = r_p - C Phi^-1 r_d   (inf_newton_solver.m:28-29)
+template <int N, int MODE>
+FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const fw_clds_t sBt = (fw_clds_t)lds_g;
+    const fw_lds_t out1 = (fw_lds_t)out1_g;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int m = W.m, mp = W.mp, T = W.T, s = W.s, nb = W.nb;
+    const double* A1tp = P->M.A1t; const double* A2tp = P->M.A2t;
+    double acc = 0.0;
+    for (int j0 = 0; j0 < nb; j0 += 32) {
+        d4 a[2][2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) a[I][J] = (d4){0, 0, 0, 0};
+        // ---- B u_i  (K = m): X = B' rows c, Z = u (or Phi^-1 r_d on u) of stage i
+        const int i0 = j0 + c16, i1 = j0 + 16 + c16;
+        const bool ok0 = i0 < T, ok1 = i1 < T;
+        const double* u0p = MODE == 0 ? W.zp + (size_t)(ok0 ? i0 : 0) * s : W.rdu + (size_t)(ok0 ? i0 : 0) * m;
+        const double* u1p = MODE == 0 ? W.zp + (size_t)(ok1 ? i1 : 0) * s : W.rdu + (size_t)(ok1 ? i1 : 0) * m;
+        const double* w0p = W.winv + (size_t)(ok0 ? i0 : 0) * mp;
+        const double* w1p = W.winv + (size_t)(ok1 ? i1 : 0) * mp;
+        for (int kc = 0; kc < mp; kc += 4 * FW_KCH) {
+            double x0[FW_KCH], x1[FW_KCH], v0[FW_KCH], v1[FW_KCH];
+#pragma unroll
+            for (int q = 0; q < FW_KCH; ++q) {
+                const int k = kc + 4 * q + g;
+                x0[q] = sBt[k * FW_LDB + c16];
+                x1[q] = sBt[k * FW_LDB + 16 + c16];
+                const int kk = k < m ? k : 0;
+                double t0 = u0p[kk], t1 = u1p[kk];
+                if (MODE == 1) { t0 *= w0p[kk]; t1 *= w1p[kk]; }
+                v0[q] = (ok0 && k < m) ? t0 : 0.0;
+                v1[q] = (ok1 && k < m) ? t1 : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < FW_KCH; ++q) {
+                a[0][0] = MFMA64(x0[q], v0[q], a[0][0]);
+                a[0][1] = MFMA64(x0[q], v1[q], a[0][1]);
+                a[1][0] = MFMA64(x1[q], v0[q], a[1][0]);
+                a[1][1] = MFMA64(x1[q], v1[q], a[1][1]);
+            }
+        }
+        // ---- A1 x_i + A2 x_{i-1}  (K = n)
+        const double* xs = MODE == 0 ? W.zp + m : W.phx;          // x_j at xs[(j-1)*xstride + k]
+        const int xstride = MODE == 0 ? s : N;
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int k = 4 * ks + g;
+            double xa[2], xb[2], za[2], zb[2];
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const int rr = 16 * I + c16;
+                const bool ok = k < N && rr < N;
+                const int off = ok ? k * N + rr : 0;
+                const double t1 = A1tp[off], t2 = A2tp[off];
+                xa[I] = ok ? t1 : 0.0;
+                xb[I] = ok ? t2 : 0.0;
+            }
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int i = j0 + 16 * J + c16;
+                const bool oka = k < N && i >= 1 && i < T;
+                const bool okb = k < N && i >= 2 && i < T && W.var2;
+                const double ta = xs[oka ? (size_t)(i - 1) * xstride + k : 0];
+                const double tb = xs[okb ? (size_t)(i - 2) * xstride + k : 0];
+                za[J] = oka ? ta : 0.0;
+                zb[J] = okb ? tb : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    a[I][J] = MFMA64(xa[I], za[J], a[I][J]);
+                    a[I][J] = MFMA64(xb[I], zb[J], a[I][J]);
+                }
+        }
+        {
+            bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
+                const int row = 16 * I + 4 * r + g, i = j0 + 16 * J + c16;
+                ok[e] = row < N && i < nb;
+                ir[e] = ok[e] ? row : 0; ii[e] = ok[e] ? i : 0;
+                const int jx = ii[e] < T ? ii[e] : T - 1;           // x_{i+1}; the xf row uses x_T
+                if (MODE == 0) {
+                    in0[e] = W.zp[jx * s + m + ir[e]];
+                    in1[e] = W.b[ii[e] * N + ir[e]];
+                } else {
+                    in0[e] = W.phx[jx * N + ir[e]];
+                    in1[e] = W.rp[ii[e] * N + ir[e]];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
+                const double cz = ii[e] < T ? a[I][J][r] : 0.0;
+                if (MODE == 0) {
+                    const double v = in0[e] - in1[e] - cz;
+                    if (ok[e]) { W.rp[ii[e] * N + ir[e]] = v; acc += v * v; }
+                } else {
+                    const double v = in1[e] - (in0[e] - cz);
+                    if (ok[e]) W.rhs[ii[e] * N + ir[e]] = v;
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        acc = fw_wave_sum(acc);
+        if (lane == 0) out1[0] = acc;
+    }
+    fw_mem_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// P3: block-penta-diagonal Cholesky of Y fused with the forward sweep (inf_newton_solver.m:27,30-31)
+template <int N>
+FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
+    using C = FwCfg<N>;
+    constexpr int LD = C::LD, LDG = C::LDG, RC = C::RC;
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int mp = W.mp, T = W.T, nb = W.nb;
+    const bool var2 = W.var2 != 0;
+    const fw_lds_t lds = (fw_lds_t)lds_g;
+    const fw_clds_t sBt = lds;
+    const fw_lds_t tA = lds + mp * FW_LDB + wv * C::PER_WAVE;
+    const fw_lds_t tB = tA + C::TILE;
+    const double* imgs = P->V.img;
+    FW_T0();
+
+    d4 Ua[2][2], Ub[2][2], Uc[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { Ua[I][J] = (d4){0, 0, 0, 0}; Ub[I][J] = Ua[I][J]; Uc[I][J] = Ua[I][J]; }
+    int notpd = 0;
+    for (int i = 0; i < nb; ++i) {
+        const double* img = imgs + (size_t)P->V.iD[i] * C::IMG_STRIDE + lane;
+        const double* img1 = imgs + (size_t)P->V.i1[i] * C::IMG_STRIDE + C::IMG_D + lane;
+        const double* img2 = imgs + (size_t)P->V.i2[i] * C::IMG_STRIDE + C::IMG_D + C::IMG_1;
+        d4 S00, S01, S11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            S00[r] = img[(0 * 4 + r) * 64];
+            S01[r] = img[(1 * 4 + r) * 64];
+            S11[r] = img[(2 * 4 + r) * 64];
+        }
+        if (c16 == RC - 16) {                    // rhs_i rides in column n of the tile
+            const double* rh = W.rhs + i * N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S01[r] = rh[4 * r + g];
+                const int row1 = 16 + 4 * r + g;
+                S11[r] = rh[row1 < N ? row1 : N - 1];
+            }
+        }
+        // ---- S += B Rt_i^-1 B'  (K = m; three subtiles by symmetry; chunks of FW_KCH k-steps).
+        //      (No software pipelining against the VALU loop below: on gfx950 the fp64 MFMA and
+        //      VALU instructions of a SIMD do not execute concurrently -- measured, see DESIGN.md.)
+        if (i < T) {
+            const double* wi = W.winv + (size_t)i * mp + g;
+            const fw_clds_t bp = sBt + g * FW_LDB + c16;
+            for (int kc = 0; kc < mp; kc += 4 * FW_KCH) {
+                double wk[FW_KCH], b0[FW_KCH], b1[FW_KCH];
+#pragma unroll
+                for (int q = 0; q < FW_KCH; ++q) {
+                    wk[q] = wi[kc + 4 * q];
+                    b0[q] = bp[(kc + 4 * q) * FW_LDB];
+                    b1[q] = bp[(kc + 4 * q) * FW_LDB + 16];
+                }
+#pragma unroll
+                for (int q = 0; q < FW_KCH; ++q) {
+                    const double a0 = b0[q] * wk[q], a1 = b1[q] * wk[q];
+                    S00 = MFMA64(a0, b0[q], S00);
+                    S01 = MFMA64(a0, b1[q], S01);
+                    S11 = MFMA64(a1, b1[q], S11);
+                }
+            }
+        }
+        // ---- S -= Ua'Ua + Uc'Uc ;  M1 = Y_{i,i+1} - Ua'Ub
+        d4 M00, M01, M10, M11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            M00[r] = img1[(0 * 4 + r) * 64];
+            M01[r] = img1[(1 * 4 + r) * 64];
+            M10[r] = img1[(2 * 4 + r) * 64];
+            M11[r] = img1[(3 * 4 + r) * 64];
+        }
+#pragma unroll
+        for (int Ix = 0; Ix < 2; ++Ix)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * Ix + 4 * r >= N) continue;          // rows >= n of the U tiles are zero
+                const double na0 = -Ua[Ix][0][r], na1 = -Ua[Ix][1][r];
+                S00 = MFMA64(na0, Ua[Ix][0][r], S00);
+                S01 = MFMA64(na0, Ua[Ix][1][r], S01);
+                S11 = MFMA64(na1, Ua[Ix][1][r], S11);
+                if (var2) {
+                    M00 = MFMA64(na0, Ub[Ix][0][r], M00);
+                    M01 = MFMA64(na0, Ub[Ix][1][r], M01);
+                    M10 = MFMA64(na1, Ub[Ix][0][r], M10);
+                    M11 = MFMA64(na1, Ub[Ix][1][r], M11);
+                    const double nc0 = -Uc[Ix][0][r], nc1 = -Uc[Ix][1][r];
+                    S00 = MFMA64(nc0, Uc[Ix][0][r], S00);
+                    S01 = MFMA64(nc0, Uc[Ix][1][r], S01);
+                    S11 = MFMA64(nc1, Uc[Ix][1][r], S11);
+                }
+            }
+        FW_TICK(0);
+        // ---- MFMA tiles -> LDS.  tA: S with its lower triangle complete; tB: M1 with the rhs in
+        //      column n.  Tiles have 32 rows and a dump column (28): no predicates needed.
+        {
+            const int cA = 16 + c16 < 28 ? 16 + c16 : 28;                // clamped column for J = 1
+            const fw_lds_t pa = tA + g * LD + c16;                        // (4r+g, c16)
+            const fw_lds_t pt = tA + (16 + c16 < N ? 16 + c16 : 31) * LD + g;   // transposed (16+c16, 4r+g); pads -> row 31
+            const fw_lds_t pa11 = tA + (16 + g) * LD + cA;
+            const fw_lds_t pb0 = tB + g * LD;
+            const bool isrhs = c16 == RC - 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[4 * r * LD] = S00[r];
+                pt[4 * r] = S01[r];
+                pa11[4 * r * LD] = S11[r];
+                pb0[4 * r * LD + c16] = M00[r];
+                pb0[4 * r * LD + cA] = isrhs ? S01[r] : M01[r];
+                pb0[(16 + 4 * r) * LD + c16] = M10[r];
+                pb0[(16 + 4 * r) * LD + cA] = isrhs ? S11[r] : M11[r];
+            }
+        }
+        fw_wave_fence();
+        // ---- row r of S on lane r; column c of [M1 | rhs | . | Y2 | rhs] on lane c
+        double row[N], x[N];
+        {
+            const int rr = lane < N ? lane : N;                      // lanes >= n read a pad row
+            const int cl = lane & 31;
+            const fw_clds_t pr = tA + rr * LD;
+#pragma unroll
+            for (int j = 0; j < N; ++j) row[j] = pr[j];
+            if (lane < 32 || cl == RC) {
+                const fw_clds_t pc = tB + (cl < 28 ? cl : 28);
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] = pc[j * LD];
+            } else {
+                const double* pc = img2 + cl;
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] = pc[j * 32];
+            }
+        }
+        fw_wave_fence();
+        FW_TICK(1);
+        // ---- fused potrf (lane = row) + forward substitution (lane = column)
+        double myrs = 1.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double d = fw_readlane(row[k], k);
+            if (!(d > 0.0) || isinf(d)) notpd = 1;
+            const double rs = fw_rsqrt(d);
+            const double lk = row[k] * rs;           // L[r][k] on lane r (r > k)
+            row[k] = lk;
+            const double xk = x[k] * rs;
+            x[k] = xk;
+            if (lane == k) myrs = rs;
+#pragma unroll
+            for (int c = k + 1; c < N; ++c) {
+                const double lck = fw_readlane(lk, c);   // L[c][k], uniform
+                row[c] = fma(-lk, lck, row[c]);
+                x[c] = fma(-lck, xk, x[c]);
+            }
+        }
+        FW_TICK(2);
+        // ---- results: U1|y -> tB, U2|y -> tA (layout change) and the factor to HBM
+        {
+            double* f = W.fac + (size_t)i * 3 * N * LDG;
+            const int cl = lane & 31;
+            const bool hi = lane >= 32;
+            const fw_lds_t tdst = (hi ? tA : tB) + (cl < 28 ? cl : 28);
+#pragma unroll
+            for (int j = 0; j < N; ++j) tdst[j * LD] = x[j];
+            if (cl < N) {
+                double* gdst = f + (hi ? 2 : 1) * N * LDG + cl;
+#pragma unroll
+                for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];       // U1 / U2 row-major for the backward sweep
+            }
+            if (lane < N) {
+                double* gl = f + lane;
+#pragma unroll
+                for (int j = 0; j < N; ++j) gl[j * LDG] = row[j];       // column j of L contiguous in r (upper part unused)
+                W.rsg[i * 32 + lane] = myrs;
+            }
+        }
+        fw_wave_fence();
+        // ---- rotate and read the new U tiles back in MFMA layout (pad rows must be exact zeros)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) Uc[I][J] = Ub[I][J];
+        {
+            const int cB = 16 + c16 < 28 ? 16 + c16 : 28;
+            const fw_clds_t pa = tB + g * LD;
+            const fw_clds_t pb = tA + g * LD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Ua[0][0][r] = pa[4 * r * LD + c16];
+                Ua[0][1][r] = pa[4 * r * LD + cB];
+                Ub[0][0][r] = pb[4 * r * LD + c16];
+                Ub[0][1][r] = pb[4 * r * LD + cB];
+                if (16 + 4 * r < N) {
+                    const bool ok = 16 + 4 * r + 3 < N || 16 + 4 * r + g < N;
+                    const double v0 = pa[(16 + 4 * r) * LD + c16], v1 = pa[(16 + 4 * r) * LD + cB];
+                    const double w0 = pb[(16 + 4 * r) * LD + c16], w1 = pb[(16 + 4 * r) * LD + cB];
+                    Ua[1][0][r] = ok ? v0 : 0.0; Ua[1][1][r] = ok ? v1 : 0.0;
+                    Ub[1][0][r] = ok ? w0 : 0.0; Ub[1][1][r] = ok ? w1 : 0.0;
+                } else {
+                    Ua[1][0][r] = 0.0; Ua[1][1][r] = 0.0; Ub[1][0][r] = 0.0; Ub[1][1][r] = 0.0;
+                }
+            }
+        }
+        if (lane < N) W.yv[i * N + lane] = tB[lane * LD + RC];
+        fw_wave_fence();
+        FW_TICK(3);
+    }
+    FW_TFLUSH(0);
+    fw_mem_fence();
+    return __ballot(notpd) != 0ull ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P4: backward sweep, d_nu_i = L^-T (y_i - U1 d_nu_{i+1} - U2 d_nu_{i+2})   (inf_newton_solver.m:32)
+// The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
+// and turned to the row-/column-per-lane layouts through this wave's LDS tiles.
+template <int N>
+FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
+    using C = FwCfg<N>;
+    constexpr int LDG = C::LDG, LD = C::LD;
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const fw_lds_t lds = (fw_lds_t)lds_g;
+    const fw_lds_t tA = lds + W.mp * FW_LDB + wv * C::PER_WAVE;
+    const fw_lds_t tB = tA + C::TILE;
+    const int lr = lane < N ? lane : N - 1;
+    const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
+    double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
+    for (int i = W.nb - 1; i >= 0; --i) {
+        const double* f = W.fac + (size_t)i * 3 * N * LDG + lc;
+        // U1 -> tA, U2 -> tB (row-major tiles), then row lr of each on lane lr
+        double g1[N], g2[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; g2[j] = f[(2 * N + j) * LDG]; }
+        double v = W.yv[i * N + lr];
+        const double rsv = W.rsg[i * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { tA[j * LD + lc] = g1[j]; tB[j * LD + lc] = g2[j]; }
+        fw_wave_fence();
+        double gl[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) gl[j] = f[j * LDG];            // column j of L across the lanes
+        {
+            const fw_clds_t r1 = tA + lr * LD;
+            const fw_clds_t r2 = tB + lr * LD;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double a = fw_readlane(x1, c), bb = fw_readlane(x2, c);
+                v = fma(-r1[c], a, v);
+                v = fma(-r2[c], bb, v);
+            }
+        }
+        fw_wave_fence();
+        // L -> tA as [column j][row r]; lane j then reads its column (row j of the LDS tile)
+#pragma unroll
+        for (int j = 0; j < N; ++j) tA[j * LD + lc] = gl[j];
+        fw_wave_fence();
+        double res = 0.0;
+        {
+            const fw_clds_t cl = tA + lr * LD;
+#pragma unroll
+            for (int r = N - 1; r >= 0; --r) {
+                const double xr = fw_readlane(v * rsv, r);
+                if (lane == r) res = xr;
+                v = fma(-cl[r], xr, v);        // meaningful on lanes < r only
+            }
+        }
+        fw_wave_fence();
+        if (lane < N) W.dnu[i * N + lane] = res;
+        x2 = x1;
+        x1 = res;
+    }
+    fw_mem_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// z += t d_z, nu += t d_nu   (backtracking_inf_newton.m:10-11)
+template <int N>
+FW_FN void fw_phase_update(FwKP Pin, int p, double t) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63;
+    const int Nz = W.T * W.s, nbn = W.nb * N, m = W.m, s = W.s;
+    for (int idx = lane; idx < Nz; idx += 64) {
+        const int j = idx / s, e = idx - j * s;
+        W.zp[idx] += t * (e < m ? W.rdu[j * m + e] : W.rdx[j * N + e - m]);
+    }
+    for (int idx = lane; idx < nbn; idx += 64) W.nu[idx] += t * W.dnu[idx];
+    fw_mem_fence();
+}
+
+template <int N>
+__global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
+    using C = FwCfg<N>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FwKP P = fw_params();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int mp = P->V.mp;
+    for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
+    {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
+        double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
+        for (int i = lane; i < C::PER_WAVE; i += 64) t[i] = 0.0;
+    }
+    __syncthreads();                       // the only workgroup barrier: waves are independent below
+    // scalars handed back by the phases: a 4-double LDS slot per wave behind the tiles
+    double* red = lds + (size_t)mp * FW_LDB + (size_t)FW_WAVES * C::PER_WAVE + wv * 4;
+
+    const int wave_g = blockIdx.x * FW_WAVES + wv, nwaves = gridDim.x * FW_WAVES;
+    {   // zero the k-step padding of winv once (columns m..mp-1 never change)
+        const FwView<N> W(P, 0);
+        for (int idx = lane; idx < W.T * mp; idx += 64) W.winv[idx] = 0.0;
+    }
+    const int batch = P->batch, max_iter = P->max_iter;
+#ifdef FW_TIMING
+    unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FW_KTICK(k) do { _k1 = __builtin_readcyclecounter(); _ka[k] += _k1 - _k0; _k0 = _k1; } while (0)
+#else
+#define FW_KTICK(k)
+#endif
+    for (int p = wave_g; p < batch; p += nwaves) {
+        FW_KTICK(7);
+        fw_phase_init<N>(P, p);
+        FW_KTICK(0);
+        int st = FMPC_OK, nsteps = 0;
+        for (int it = 0; it < max_iter; ++it) {
+            fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
+            fw_wave_fence();
+            const double rd2 = red[0];
+            const bool bad = red[2] != 0.0;
+            fw_wave_fence();
+            fw_phase_C<N, 0>(P, p, lds, red);               // r_p
+            fw_wave_fence();
+            const double rp2 = red[0];
+            fw_wave_fence();
+            FW_KTICK(1);
+            const double rho2 = rd2 + rp2;
+            if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;        // inf_newton_solver.m:19-22
+            if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
+            fw_phase_C<N, 1>(P, p, lds, red);               // rhs
+            FW_KTICK(2);
+            if (fw_phase_factor<N>(P, p, lds)) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            FW_KTICK(3);
+            fw_phase_backward<N>(P, p, lds);
+            FW_KTICK(4);
+            fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
+            fw_wave_fence();
+            const double beta_e = red[0], eps2 = red[1];
+            fw_wave_fence();
+            double t = 1.0;
+            {
+                const double al = 1e-4;
+                int halv = 0;
+                while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
+                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2
+                                      - 2.0 * (1.0 - t) * beta_e + t * eps2;
+                    if (gq <= 0.0) break;
+                    t *= 0.5;
+                    if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                }
+            }
+            fw_phase_update<N>(P, p, t);
+            if (P->step && lane == 0 && it < P->step_ld) P->step[(size_t)p * P->step_ld + it] = t;
+            ++nsteps;
+            FW_KTICK(5);
+        }
+        if (P->nuout) {
+            const FwView<N> W(P, p);
+            const int nbn = W.nb * N;
+            for (int idx = lane; idx < nbn; idx += 64) P->nuout[(size_t)p * nbn + idx] = W.nu[idx];
+        }
+        if (lane == 0) {
+            if (P->status) P->status[p] = st;
+            if (P->iters) P->iters[p] = nsteps;
+        }
+    }
+#ifdef FW_TIMING
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&fw_timing[4 + q], _ka[q]);
+#endif
+}
+
+// ---------------------------------------------------------------- host side of the wave kernel
+size_t fmpc_wave_lds_bytes(int n, int mp) {
+    if (n != 27) return 0;
+    return ((size_t)mp * FW_LDB + (size_t)FW_WAVES * FwCfg<27>::PER_WAVE + FW_WAVES * 4) * sizeof(double);
+}
+bool fmpc_wave_supports(int n) { return n == 27; }
+int fmpc_wave_mp(int m) { const int q = 4 * FW_KCH; return (m + q - 1) / q * q; }
+int fmpc_wave_img_stride(int n) { return n == 27 ? FwCfg<27>::IMG_STRIDE : 0; }
+int fmpc_wave_waves_per_wg() { return FW_WAVES; }
+size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
+    return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
+}
+
+// Fill the three images of one n x n row-major block (see FwCfg): host helper.
+void fmpc_wave_make_images(int n, const double* blk, double* out) {
+    using C = FwCfg<27>;
+    for (int i = 0; i < C::IMG_STRIDE; ++i) out[i] = 0.0;
+    auto at = [&](int r, int c) { return (r < n && c < n) ? blk[r * n + c] : 0.0; };
+    const int subs[3][2] = {{0, 0}, {0, 1}, {1, 1}};
+    for (int sidx = 0; sidx < 3; ++sidx)
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l)
+                out[(sidx * 4 + r) * 64 + l] = at(16 * subs[sidx][0] + 4 * r + (l >> 4), 16 * subs[sidx][1] + (l & 15));
+    double* o1 = out + C::IMG_D;
+    for (int I = 0; I < 2; ++I)
+        for (int J = 0; J < 2; ++J)
+            for (int r = 0; r < 4; ++r)
+                for (int l = 0; l < 64; ++l)
+                    o1[((I * 2 + J) * 4 + r) * 64 + l] = at(16 * I + 4 * r + (l >> 4), 16 * J + (l & 15));
+    double* o2 = o1 + C::IMG_1;
+    for (int j = 0; j < n; ++j)
+        for (int c = 0; c < 32; ++c) o2[j * 32 + c] = at(j, c);
+}
+
+hipError_t fmpc_wave_prepare(int n, size_t lds_bytes) {
+    if (n != 27) return hipErrorInvalidValue;
+    return hipFuncSetAttribute((const void*)fmpc_newton_wave<27>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, int grid,
+                            const double* x0, const double* x0p, const double* w, const double* zinit,
+                            const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
+                            int* status, int* iters, double* step, int step_ld, double* ws,
+                            size_t ws_stride, size_t lds_bytes, hipStream_t stream) {
+    if (M.n != 27) return hipErrorInvalidValue;
+    FwParams P;
+    P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.pad_ = 0;
+    P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
+    P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;
+    hipLaunchKernelGGL(fmpc_newton_wave<27>, dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);
+    return hipGetLastError();
+}
