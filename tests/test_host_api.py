@@ -1,0 +1,121 @@
+"""Host logic and the C-ABI library on a machine WITHOUT a GPU: the library loads, exports every
+symbol include/fastmpc.h declares, validates arguments, and refuses to solve without a HIP device
+(there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load()
+    hdr = open(os.path.join(ROOT, "include", "fastmpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fmpc_[a-z_]+)\s*\(", hdr))
+    assert declared == set(pkg._lib.SIGNATURES), (declared ^ set(pkg._lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fmpc_version() == 100
+    assert lib.fmpc_strerror(-8).decode().startswith("no HIP device")
+    assert lib.fmpc_step_ld(5) == 5 and lib.fmpc_step_ld(0) == 1000
+
+
+def test_status_codes_match_header(pkg):
+    hdr = open(os.path.join(ROOT, "include", "fastmpc.h")).read()
+    for name, val in re.findall(r"#define (FMPC_[EW]_[A-Z_]+|FMPC_OK)\s+(-?\d+)", hdr):
+        assert getattr(pkg._lib, name) == int(val), name
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback(pkg):
+    md, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=0)
+    with pytest.raises(pkg.FastMPCError) as e:
+        pkg.FastMPCHandle(md["A1"], md["A2"], md["B"], md["Q"], md["R"], md["Qf"], md["u_min"], md["u_max"],
+                          md["x_min"], md["x_max"], 10)
+    assert e.value.code in (pkg.FMPC_E_NO_DEVICE, pkg.FMPC_E_HIP)
+    with pytest.raises(pkg.FastMPCError) as e2:
+        pkg.FastMPCHandle(md["A1"], md["A2"], md["B"], md["Q"], md["R"], md["Qf"], md["u_min"], md["u_max"],
+                          md["x_min"], md["x_max"], 10, device=-1)
+    assert e2.value.code == pkg.FMPC_E_NO_DEVICE
+
+
+def test_create_argument_checks(pkg):
+    """Argument errors are reported before any device is touched."""
+    lib = pkg.load()
+    h = C.c_void_p()
+    one = (C.c_double * 4)(1, 0, 0, 1)
+    nul = None
+    assert lib.fmpc_create(None, 2, 2, 1, 2, *([one] * 14), 0) == pkg.FMPC_E_NULL
+    assert lib.fmpc_create(C.byref(h), 0, 2, 1, 2, *([one] * 14), 0) == pkg.FMPC_E_DIM
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 3, *([one] * 14), 0) == pkg.FMPC_E_DIM
+    args = [one] * 14
+    args[1] = nul                                     # A2 missing for VAR(2): fast_mpc_eq_const.m:21-22
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NULL
+    full = (C.c_double * 4)(1, 0.5, 0.5, 1)           # non-diagonal Q: not on the device yet
+    args = [one] * 14
+    args[3] = full
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_UNSUPPORTED
+    neg = (C.c_double * 4)(-1, 0, 0, 1)               # Q not PD -> chol(KKT_H) would fail
+    args = [one] * 14
+    args[3] = neg
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NOT_PD_PHI
+    assert lib.fmpc_destroy(None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_solve(None, 1, *([None] * 5), 1, 0.01, *([None] * 5)) == pkg.FMPC_E_NULL
+
+
+def test_fast_mpc2_validation_mirrors_reference_errors(pkg):
+    md, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=0)
+    mk = lambda **kw: pkg.Fast_MPC2(kw.get("Q", md["Q"]), md["R"], [], md["Qf"], kw.get("q", []), [], [], md["x_min"],
+                                    md["x_max"], kw.get("umin", md["u_min"]), md["u_max"], [], [], 10,
+                                    kw.get("x0", data["x0"][0]), data["x0_pre"][0], np.zeros(5), md["A1"],
+                                    kw.get("A2", md["A2"]), md["B"], kw.get("w", data["w"][0]), [], kw.get("x_init", []))
+    cases = [(dict(x_init=np.zeros(7)), "Initialization size mismatch"),
+             (dict(q=np.zeros(3)), "Linear state cost"),
+             (dict(umin=np.zeros(2)), "Check cotrol iequality"),
+             (dict(A2=[]), "Define the state dynamics"),
+             (dict(x0=np.zeros(3)), "equality state dynamics matrix size"),
+             (dict(w=np.zeros(8)), "Index exceeds")]
+    for kw, msg in cases:
+        with pytest.raises(pkg.FastMPCError) as e:
+            mk(**kw).mpc_fixed_log_newton(1, 0.01)
+        assert msg in str(e.value), (msg, str(e.value))
+    obj = mk()
+    z0 = obj.initialize()
+    assert z0.shape == (130,) and np.array_equal(z0, np.zeros(130))
+    with pytest.raises(NotImplementedError):
+        obj.matlab_solve()
+    v1 = pkg.Fast_MPC2_VAR1(md["Q"], md["R"], [], md["Qf"], [], [], [], md["x_min"], md["x_max"], md["u_min"], md["u_max"],
+                            -np.ones(5), np.ones(5), 10, data["x0"][0], np.zeros(5), md["A1"], md["B"], data["w"][0], [], [])
+    with pytest.raises(pkg.FastMPCError) as e:
+        v1.mpc_fixed_log_newton(1, 0.01)
+    assert e.value.code == pkg.FMPC_E_UNSUPPORTED          # ramp rows are not on the device: refuse, do not approximate
+
+
+def test_deinterleave_and_shard_range(pkg):
+    z = np.arange(3 * 5.0)
+    U, X = pkg.deinterleave(z, 3, 2, 3)
+    assert np.array_equal(U, [0, 1, 5, 6, 10, 11]) and np.array_equal(X, [2, 3, 4, 7, 8, 9, 12, 13, 14])
+    got = [pkg.shard_range(10, 4, r) for r in range(4)]
+    assert got == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [pkg.shard_range(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert pkg.shard_range(4096, 8, 7) == (3584, 4096)
+
+
+def test_synthetic_is_seeded_and_stable(pkg):
+    a = pkg.synthetic.make_model(27, 144, 30); b = pkg.synthetic.make_model(27, 144, 30)
+    assert all(np.array_equal(a[k], b[k]) for k in ("A1", "A2", "B"))
+    comp = np.block([[a["A1"], a["A2"]], [np.eye(27), np.zeros((27, 27))]])
+    assert np.max(np.abs(np.linalg.eigvals(comp))) < 0.999
+    d = pkg.synthetic.make_replay_batch(a, r=0, steps=50)
+    assert d["x0"].shape == (50, 27) and np.array_equal(d["x0"][:-1], d["x0_pre"][1:])
+    assert abs(np.mean(np.linalg.norm(pkg.synthetic.make_realisation(a, 0, 500)[1:], axis=1)) - 3.0) < 1e-9
+    assert [pkg.synthetic.radial_order(j) for j in (1, 2, 3, 4, 6, 7, 10, 11)] == [0, 1, 1, 2, 2, 3, 3, 4]

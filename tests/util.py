@@ -55,3 +55,12 @@ def oracle_batch(model, data, n_newton, k, z_init=None):
 def rel_err(a, b):
     a = np.asarray(a); b = np.asarray(b)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def canon_steps(t):
+    """Line-search steps with the collapse case canonicalised: the reference's literal loop leaves a
+    failing search at t ~ 2^-50 (where (1 - al*t) rounds to 1), the closed form at exactly 0 after 64
+    halvings (FMPC_W_LINESEARCH); both mean "no move" (SURVEY App. B-D2)."""
+    t = np.asarray(t, dtype=np.float64).copy()
+    t[(t >= 0) & (t < 1e-12)] = 0.0
+    return t
