@@ -67,13 +67,16 @@ def cpu_baseline(pkg, model, data):
 
 
 def main():
+    global N_NEWTON
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-newton", type=int, default=N_NEWTON)
     args = ap.parse_args()
+    N_NEWTON = args.n_newton
 
     import numpy as np
     import torch

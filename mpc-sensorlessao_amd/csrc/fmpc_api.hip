@@ -35,7 +35,9 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* x0, const double* x0p, const double* w, const double* zinit,
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
-                            size_t ws_stride, size_t lds_bytes, hipStream_t stream);
+                            size_t ws_stride, size_t lds_bytes, hipStream_t stream,
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok);
+size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 
 #define FMPC_LDS_LIMIT (160 * 1024)
 
@@ -53,6 +55,11 @@ struct fmpc_handle_s {
     double* wave_pool_d;
     int* wave_pool_i;
     size_t wave_lds;
+    // shared cold-start factor (SURVEY §7.2a regime (ii)): Phi, Y and its Cholesky factor are the
+    // same for every problem in the first Newton step from the mid-box start; it depends only on the
+    // model and on k, so it is computed once per (handle, k) and kept in HBM (L2-resident, 0.5 MB).
+    double* sh_fac; double* sh_rs; int* sh_ok; double* sh_scratch;
+    double sh_k; int sh_valid; int sh_enabled;
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
@@ -142,6 +149,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
+    h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -302,6 +310,21 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         h->wave_lds = fmpc_wave_lds_bytes(n, mp);
         if (fmpc_wave_prepare(n, h->wave_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
         h->use_wave = 1;
+        const char* nosh = getenv("FMPC_NO_SHARED");
+        if (!(nosh && nosh[0] == '1')) {
+            const size_t nf = fmpc_wave_shared_fac_doubles(n, h->nb);
+            const size_t nscr = (size_t)T * (n + m) + 64 + (size_t)n;      // zero state + z of the export solve
+            if (hipMalloc((void**)&h->sh_fac, nf * sizeof(double)) != hipSuccess ||
+                hipMalloc((void**)&h->sh_rs, (size_t)h->nb * 32 * sizeof(double)) != hipSuccess ||
+                hipMalloc((void**)&h->sh_ok, sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&h->sh_scratch, nscr * sizeof(double)) != hipSuccess) {
+                fmpc_destroy(h);
+                return FMPC_E_ALLOC;
+            }
+            (void)hipMemset(h->sh_ok, 0, sizeof(int));
+            (void)hipMemset(h->sh_scratch, 0, nscr * sizeof(double));
+            h->sh_enabled = 1;
+        }
     }
     *out = h;
     return FMPC_OK;
@@ -314,6 +337,10 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->pool_i) (void)hipFree(h->pool_i);
     if (h->wave_pool_d) (void)hipFree(h->wave_pool_d);
     if (h->wave_pool_i) (void)hipFree(h->wave_pool_i);
+    if (h->sh_fac) (void)hipFree(h->sh_fac);
+    if (h->sh_rs) (void)hipFree(h->sh_rs);
+    if (h->sh_ok) (void)hipFree(h->sh_ok);
+    if (h->sh_scratch) (void)hipFree(h->sh_scratch);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -373,9 +400,22 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             if (hipMalloc((void**)&h->ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
             h->ws_doubles = need;
         }
+        int mode = 0;
+        if (h->sh_enabled && z_init == nullptr) {
+            // cold start: the first Newton step of every problem shares one factor (depends on k only)
+            if (!h->sh_valid || h->sh_k != k) {
+                double* scr = h->sh_scratch;                 // a zero state: x0 = x0_pre = 0, w = nu0 = 0
+                e = fmpc_launch_wave(h->dev, h->wave, 1, 1, scr, scr, nullptr, nullptr, nullptr, 1, k,
+                                     scr + ((h->n + 15) & ~15), nullptr, nullptr, nullptr, nullptr, 1, h->ws, stride,
+                                     h->wave_lds, (hipStream_t)stream, 2, h->sh_fac, h->sh_rs, h->sh_ok);
+                if (e != hipSuccess) return FMPC_E_HIP;
+                h->sh_valid = 1; h->sh_k = k;
+            }
+            mode = 1;
+        }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
-                             h->wave_lds, (hipStream_t)stream);
+                             h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok);
     } else {
         const int grid = fmpc_grid_for(h, batch);
         size_t stride = 0;

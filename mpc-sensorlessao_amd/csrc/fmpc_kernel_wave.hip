@@ -24,6 +24,7 @@
 // segment through scalar loads.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "fmpc_device.h"
 #include "../../include/fastmpc.h"
 
@@ -32,6 +33,9 @@
 #define FW_MAX_HALVINGS 64
 #define FW_LDB 33                       // leading dimension of B' in LDS (odd)
 #define FW_KCH 6                        // k-steps per prefetch chunk of the K = m products
+#define FW_MODE_NORMAL 0                // every problem factors its own Y
+#define FW_MODE_SHARED 1                // first Newton step from a cold start uses the handle's shared factor
+#define FW_MODE_EXPORT 2                // compute that shared factor (batch 1) and publish it
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -91,11 +95,13 @@ __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T,
 struct FwParams {
     FmpcDevModel M;
     FwModel V;
-    int batch, max_iter, step_ld, pad_;
+    int batch, max_iter, step_ld;
+    int mode;                       // FW_MODE_*
     double kbar;
     const double* x0; const double* x0p; const double* w; const double* zinit; const double* nu0;
     double* zout; double* nuout; int* status; int* iters; double* step;
     double* ws; size_t ws_stride;
+    double* sh_fac; double* sh_rs; int* sh_ok;     // shared (cold-start) factor owned by the handle
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -162,6 +168,7 @@ struct FwView {
         b = wsp + L.b; nu = wsp + L.nu; hess = wsp + L.hess; winv = wsp + L.winv; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
+        if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; }   // the factor IS the product
     }
 };
 
@@ -204,10 +211,12 @@ FW_FN void fw_phase_init(FwKP Pin, int p) {
 
 // ------------------------------------------------------------------------------------------------
 // C' applied to a stacked dual vector v (nu or d_nu), all stages at once on the matrix cores.
-//   MODE 0 (P1): r_d = 2Hz + g + kP'd + C'nu, barrier pieces, Phi^-1 r_d on the x entries;
+// Output tiles are (16 stages) x (16 consecutive entries of u_j or x_j): the epilogue then reads and
+// writes along contiguous elements of a stage, and the per-column constants are loaded once per tile.
+//   MODE 0 (P1): r_d = 2Hz + g + kP'd + C'nu, Rt^-1, Phi^-1 r_d on the x entries;
 //                out3 = { sum(r_d^2), -, "Phi not PD" flag }.
 //   MODE 1 (P5): d_z = Phi^-1(-r_d - C'd_nu) written over r_d; out3 = { <r_d,e>, ||e||^2, - }
-//                with e = k P'DP d_z (line search).
+//                with e = k P'DP d_z (line search); k P'DP = Rt - 2R.
 template <int N, int MODE>
 FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
     const FwKP P = fw_uniform(Pin);
@@ -224,145 +233,138 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
     const double* A1p = P->M.A1; const double* A2p = P->M.A2;
     const double* Q2p = P->M.Q2; const double* Qf2p = P->M.Qf2;
     const double* qlp = P->M.ql; const double* qflp = P->M.qfl;
+    const bool has_xf = W.has_xf != 0, var2 = W.var2 != 0;
     double acc0 = 0.0, acc1 = 0.0;
     int bad = 0;
     for (int j0 = 0; j0 < T; j0 += 32) {
-        // ---- u entries: G[c][j] = sum_r B[r][c] v_j[r]   (m x 32 stages, K = n)
-        double zn[2][7];
+        // stage of each of the 8 accumulator elements of this lane (e = 4*I + r): j0 + 16I + 4r + g
+        bool sok[8]; int sj[8];
 #pragma unroll
-        for (int J = 0; J < 2; ++J)
+        for (int e = 0; e < 8; ++e) {
+            const int j = j0 + 16 * (e >> 2) + 4 * (e & 3) + g;
+            sok[e] = j < T; sj[e] = sok[e] ? j : 0;
+        }
+        // A fragments (stage on the row index): v_j[k], v_{j+1}[k], v_{j+2}[k] for stage j = j0+16I+c16
+        double an[2][7], a1[2][7], a2[2][7];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
-                const int j = j0 + 16 * J + c16, k = 4 * ks + g;
-                zn[J][ks] = (k < N && j < T) ? vec[j * N + k] : 0.0;
+                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
+                const bool kk = k < N;
+                const double t0 = vec[(kk && j < T ? j : 0) * N + (kk ? k : 0)];
+                const double t1 = vec[(kk && j + 1 < T ? j + 1 : 0) * N + (kk ? k : 0)];
+                const double t2 = vec[(kk && j + 2 < T ? j + 2 : 0) * N + (kk ? k : 0)];
+                an[I][ks] = (kk && j < T) ? t0 : 0.0;
+                a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
+                a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
             }
-        for (int I = 0; I * 16 < m; ++I) {
-            d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-            const fw_clds_t xr = sBt + (16 * I + c16) * FW_LDB + g;
+        // ---- u entries: G[j][c] = sum_k v_j[k] B[k][c]
+        for (int J = 0; J * 16 < m; ++J) {
+            const int c = 16 * J + c16;
+            const bool cok = c < m;
+            const int cc = cok ? c : 0;
+            d4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+            const fw_clds_t br = sBt + c * FW_LDB + g;            // rows >= m of B' are zero padding
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
-                const double a = xr[4 * ks];                  // B[k][c], zero for k >= n
-                a0 = MFMA64(a, zn[0][ks], a0);
-                a1 = MFMA64(a, zn[1][ks], a1);
+                const double bb = br[4 * ks];                        // B[k][c], zero for k >= n
+                g0 = MFMA64(an[0][ks], bb, g0);
+                g1 = MFMA64(an[1][ks], bb, g1);
             }
-            // epilogue on the 8 (c, stage) elements this lane holds: all loads, then math, then stores
-            {
-                bool ok[8]; int ic[8], ij[8]; double in0[8], in1[8], in2[8], in3[8], in4[8];
+            double in0[8], in1[8];
+            double cmax = 0.0, cmin = 0.0, cr2 = R2p[cc], crl = 0.0;
+            if (MODE == 0) { cmax = umaxp[cc]; cmin = uminp[cc]; crl = rlp[cc]; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int c = 16 * I + 4 * (e & 3) + g, j = j0 + 16 * (e >> 2) + c16;
-                    ok[e] = c < m && j < T;
-                    ic[e] = ok[e] ? c : 0; ij[e] = ok[e] ? j : 0;
-                    if (MODE == 0) {
-                        in0[e] = W.zp[ij[e] * s + ic[e]];
-                        in1[e] = umaxp[ic[e]]; in2[e] = uminp[ic[e]]; in3[e] = R2p[ic[e]]; in4[e] = rlp[ic[e]];
-                    } else {
-                        in0[e] = W.rdu[ij[e] * m + ic[e]];
-                        in1[e] = W.winv[ij[e] * mp + ic[e]];
-                        in2[e] = W.hess[ij[e] * m + ic[e]];
-                    }
+            for (int e = 0; e < 8; ++e) {
+                if (MODE == 0) {
+                    in0[e] = W.zp[sj[e] * s + cc];
+                } else {
+                    in0[e] = W.rdu[sj[e] * m + cc];
+                    in1[e] = W.winv[sj[e] * mp + cc];
                 }
-                double o0[8], o1[8], o2[8];
+            }
+            double o0[8], o1[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const double G = (e >> 2) == 0 ? a0[e & 3] : a1[e & 3];
-                    if (MODE == 0) {
-                        const double u = in0[e];
-                        const double dp = fw_rcp(in1[e] - u), dm = fw_rcp(u - in2[e]);
-                        const double hs = kbar * (dp * dp + dm * dm);
-                        const double rt = in3[e] + hs;
-                        if (ok[e] && (!(rt > 0.0) || isinf(rt))) bad = 1;
-                        const double rd = in3[e] * u + in4[e] + kbar * (dp - dm) - G;
-                        o0[e] = hs; o1[e] = fw_rcp(rt); o2[e] = rd;
-                        if (ok[e]) acc0 += rd * rd;
-                    } else {
-                        const double rd = in0[e];
-                        const double du = (G - rd) * in1[e];
-                        const double ee = in2[e] * du;             // k P'DP dz
-                        o0[e] = du;
-                        if (ok[e]) { acc0 += rd * ee; acc1 += ee * ee; }
-                    }
+            for (int e = 0; e < 8; ++e) {
+                const double G = (e >> 2) == 0 ? g0[e & 3] : g1[e & 3];
+                const bool ok = cok && sok[e];
+                if (MODE == 0) {
+                    const double u = in0[e];
+                    const double dp = fw_rcp(cmax - u), dm = fw_rcp(u - cmin);
+                    const double rt = cr2 + kbar * (dp * dp + dm * dm);
+                    if (ok && (!(rt > 0.0) || isinf(rt))) bad = 1;
+                    const double rd = cr2 * u + crl + kbar * (dp - dm) - G;
+                    o0[e] = fw_rcp(rt); o1[e] = rd;
+                    if (ok) acc0 += rd * rd;
+                } else {
+                    const double rd = in0[e];
+                    const double du = (G - rd) * in1[e];
+                    const double ee = (fw_rcp(in1[e]) - cr2) * du;       // k P'DP dz, k P'DP = Rt - 2R
+                    o0[e] = du;
+                    if (ok) { acc0 += rd * ee; acc1 += ee * ee; }
                 }
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (ok[e]) {
-                        if (MODE == 0) {
-                            W.hess[ij[e] * m + ic[e]] = o0[e];
-                            W.winv[ij[e] * mp + ic[e]] = o1[e];
-                            W.rdu[ij[e] * m + ic[e]] = o2[e];
-                        } else {
-                            W.rdu[ij[e] * m + ic[e]] = o0[e];
-                        }
-                    }
+            for (int e = 0; e < 8; ++e) {
+                if (cok && sok[e]) {
+                    if (MODE == 0) { W.winv[sj[e] * mp + c] = o0[e]; W.rdu[sj[e] * m + c] = o1[e]; }
+                    else W.rdu[sj[e] * m + c] = o0[e];
                 }
             }
         }
-        // ---- x entries (x_j, j = jj+1): H[r][jj] = sum_k A1[k][r] v_j[k] + A2[k][r] v_{j+1}[k]
-        double z1[2][7], z2[2][7];
+        // ---- x entries (x_jx, jx = j+1 for stage column j): H[j][r] = sum_k v_{j+1}[k] A1[k][r] + v_{j+2}[k] A2[k][r]
 #pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                const int j = j0 + 16 * J + c16 + 1, k = 4 * ks + g;
-                z1[J][ks] = (k < N && j < T) ? vec[j * N + k] : 0.0;
-                z2[J][ks] = (k < N && j + 1 < T && W.var2) ? vec[(j + 1) * N + k] : 0.0;
-            }
-#pragma unroll
-        for (int I = 0; I < 2; ++I) {
-            d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-            const int rr = 16 * I + c16;
+        for (int J = 0; J < 2; ++J) {
+            const int rr = 16 * J + c16;
+            const bool rok = rr < N;
+            const int rc = rok ? rr : 0;
+            d4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
                 const int k = 4 * ks + g;
-                const bool ok = k < N && rr < N;
+                const bool ok = k < N && rok;
                 const int off = ok ? k * N + rr : 0;
                 const double t1 = A1p[off], t2 = A2p[off];
-                const double x1 = ok ? t1 : 0.0, x2 = ok ? t2 : 0.0;
-                a0 = MFMA64(x1, z1[0][ks], a0);
-                a1 = MFMA64(x1, z1[1][ks], a1);
-                a0 = MFMA64(x2, z2[0][ks], a0);
-                a1 = MFMA64(x2, z2[1][ks], a1);
+                const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
+                h0 = MFMA64(a1[0][ks], b1, h0);
+                h1 = MFMA64(a1[1][ks], b1, h1);
+                h0 = MFMA64(a2[0][ks], b2, h0);
+                h1 = MFMA64(a2[1][ks], b2, h1);
             }
-            {
-                bool ok[8], last[8]; int ir[8], ijj[8]; double q2[8], vprev[8], vxf[8], in0[8], in1[8];
+            const double cq2 = Q2p[rc], cqf2 = Qf2p[rc];
+            const double cql = MODE == 0 ? qlp[rc] : 0.0, cqfl = MODE == 0 ? qflp[rc] : 0.0;
+            double vprev[8], vxf[8], in0[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int row = 16 * I + 4 * (e & 3) + g, jj = j0 + 16 * (e >> 2) + c16;
-                    ok[e] = row < N && jj < T;
-                    ir[e] = ok[e] ? row : 0; ijj[e] = ok[e] ? jj : 0;
-                    last[e] = ijj[e] + 1 == T;
-                    q2[e] = last[e] ? Qf2p[ir[e]] : Q2p[ir[e]];
-                    vprev[e] = vec[ijj[e] * N + ir[e]];
-                    vxf[e] = vec[(last[e] && W.has_xf ? T : ijj[e]) * N + ir[e]];
-                    if (MODE == 0) {
-                        in0[e] = W.zp[ijj[e] * s + m + ir[e]];
-                        in1[e] = last[e] ? qflp[ir[e]] : qlp[ir[e]];
-                    } else {
-                        in0[e] = W.rdx[ijj[e] * N + ir[e]];
-                    }
+            for (int e = 0; e < 8; ++e) {
+                const bool last = sj[e] + 1 == T;
+                vprev[e] = vec[sj[e] * N + rc];
+                vxf[e] = vec[(last && has_xf ? T : sj[e]) * N + rc];
+                in0[e] = MODE == 0 ? W.zp[sj[e] * s + m + rc] : W.rdx[sj[e] * N + rc];
+            }
+            double o0[8], o1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double H = (e >> 2) == 0 ? h0[e & 3] : h1[e & 3];
+                const bool last = sj[e] + 1 == T;
+                const double q2 = last ? cqf2 : cq2;
+                const double iq = fw_rcp(q2);
+                if (MODE == 0) {
+                    double v = q2 * in0[e] + (last ? cqfl : cql) + vprev[e] - H;
+                    if (last && has_xf) v += vxf[e];
+                    o0[e] = v; o1[e] = v * iq;                  // r_d and Phi^-1 r_d on x_j
+                    if (rok && sok[e]) acc0 += v * v;
+                } else {
+                    double v = -in0[e] - vprev[e] + H;
+                    if (last && has_xf) v -= vxf[e];
+                    o0[e] = v * iq;                              // d_x
                 }
-                double o0[8], o1[8];
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const double H = (e >> 2) == 0 ? a0[e & 3] : a1[e & 3];
-                    const double iq = fw_rcp(q2[e]);
-                    if (MODE == 0) {
-                        double v = q2[e] * in0[e] + in1[e] + vprev[e] - H;
-                        if (last[e] && W.has_xf) v += vxf[e];
-                        o0[e] = v; o1[e] = v * iq;                  // r_d and Phi^-1 r_d on x_j
-                        if (ok[e]) acc0 += v * v;
-                    } else {
-                        double v = -in0[e] - vprev[e] + H;
-                        if (last[e] && W.has_xf) v -= vxf[e];
-                        o0[e] = v * iq;                              // d_x
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (ok[e]) {
-                        W.rdx[ijj[e] * N + ir[e]] = o0[e];
-                        if (MODE == 0) W.phx[ijj[e] * N + ir[e]] = o1[e];
-                    }
+            for (int e = 0; e < 8; ++e) {
+                if (rok && sok[e]) {
+                    W.rdx[sj[e] * N + rr] = o0[e];
+                    if (MODE == 0) W.phx[sj[e] * N + rr] = o1[e];
                 }
             }
         }
@@ -375,7 +377,8 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// C applied to a stacked primal vector, all stages at once on the matrix cores.
+// C applied to a stacked primal vector, all stages at once on the matrix cores; output tiles are
+// (16 block rows i) x (16 state entries), so the epilogue runs along contiguous entries.
 //   MODE 0 (P1): r_p = C z - b; out1 = sum(r_p^2).
 //   MODE 1 (P2): rhs = r_p - C Phi^-1 r_d   (inf_newton_solver.m:28-29)
 template <int N, int MODE>
@@ -388,14 +391,15 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int m = W.m, mp = W.mp, T = W.T, s = W.s, nb = W.nb;
     const double* A1tp = P->M.A1t; const double* A2tp = P->M.A2t;
+    const bool var2 = W.var2 != 0;
     double acc = 0.0;
     for (int j0 = 0; j0 < nb; j0 += 32) {
-        d4 a[2][2];
+        d4 a[2][2];                              // a[I][J]: block rows 16I.., entries 16J..
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int J = 0; J < 2; ++J) a[I][J] = (d4){0, 0, 0, 0};
-        // ---- B u_i  (K = m): X = B' rows c, Z = u (or Phi^-1 r_d on u) of stage i
+        // ---- B u_i (K = m): A operand = u_i[c] (or Phi^-1 r_d on u) with the stage on the row index
         const int i0 = j0 + c16, i1 = j0 + 16 + c16;
         const bool ok0 = i0 < T, ok1 = i1 < T;
         const double* u0p = MODE == 0 ? W.zp + (size_t)(ok0 ? i0 : 0) * s : W.rdu + (size_t)(ok0 ? i0 : 0) * m;
@@ -407,7 +411,7 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
 #pragma unroll
             for (int q = 0; q < FW_KCH; ++q) {
                 const int k = kc + 4 * q + g;
-                x0[q] = sBt[k * FW_LDB + c16];
+                x0[q] = sBt[k * FW_LDB + c16];                    // B[r = c16][c = k]
                 x1[q] = sBt[k * FW_LDB + 16 + c16];
                 const int kk = k < m ? k : 0;
                 double t0 = u0p[kk], t1 = u1p[kk];
@@ -417,10 +421,10 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
             }
 #pragma unroll
             for (int q = 0; q < FW_KCH; ++q) {
-                a[0][0] = MFMA64(x0[q], v0[q], a[0][0]);
-                a[0][1] = MFMA64(x0[q], v1[q], a[0][1]);
-                a[1][0] = MFMA64(x1[q], v0[q], a[1][0]);
-                a[1][1] = MFMA64(x1[q], v1[q], a[1][1]);
+                a[0][0] = MFMA64(v0[q], x0[q], a[0][0]);
+                a[0][1] = MFMA64(v0[q], x1[q], a[0][1]);
+                a[1][0] = MFMA64(v1[q], x0[q], a[1][0]);
+                a[1][1] = MFMA64(v1[q], x1[q], a[1][1]);
             }
         }
         // ---- A1 x_i + A2 x_{i-1}  (K = n)
@@ -431,38 +435,38 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
             const int k = 4 * ks + g;
             double xa[2], xb[2], za[2], zb[2];
 #pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                const int rr = 16 * I + c16;
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
                 const bool ok = k < N && rr < N;
                 const int off = ok ? k * N + rr : 0;
-                const double t1 = A1tp[off], t2 = A2tp[off];
-                xa[I] = ok ? t1 : 0.0;
-                xb[I] = ok ? t2 : 0.0;
+                const double t1 = A1tp[off], t2 = A2tp[off];       // A1[rr][k], A2[rr][k]
+                xa[J] = ok ? t1 : 0.0;
+                xb[J] = ok ? t2 : 0.0;
             }
 #pragma unroll
-            for (int J = 0; J < 2; ++J) {
-                const int i = j0 + 16 * J + c16;
+            for (int I = 0; I < 2; ++I) {
+                const int i = j0 + 16 * I + c16;
                 const bool oka = k < N && i >= 1 && i < T;
-                const bool okb = k < N && i >= 2 && i < T && W.var2;
+                const bool okb = k < N && i >= 2 && i < T && var2;
                 const double ta = xs[oka ? (size_t)(i - 1) * xstride + k : 0];
                 const double tb = xs[okb ? (size_t)(i - 2) * xstride + k : 0];
-                za[J] = oka ? ta : 0.0;
-                zb[J] = okb ? tb : 0.0;
+                za[I] = oka ? ta : 0.0;
+                zb[I] = okb ? tb : 0.0;
             }
 #pragma unroll
             for (int I = 0; I < 2; ++I)
 #pragma unroll
                 for (int J = 0; J < 2; ++J) {
-                    a[I][J] = MFMA64(xa[I], za[J], a[I][J]);
-                    a[I][J] = MFMA64(xb[I], zb[J], a[I][J]);
+                    a[I][J] = MFMA64(za[I], xa[J], a[I][J]);
+                    a[I][J] = MFMA64(zb[I], xb[J], a[I][J]);
                 }
         }
-        {
+        {   // epilogue: element e = (I, J, r): block row i = j0+16I+4r+g, entry 16J+c16
             bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
-                const int row = 16 * I + 4 * r + g, i = j0 + 16 * J + c16;
+                const int i = j0 + 16 * I + 4 * r + g, row = 16 * J + c16;
                 ok[e] = row < N && i < nb;
                 ir[e] = ok[e] ? row : 0; ii[e] = ok[e] ? i : 0;
                 const int jx = ii[e] < T ? ii[e] : T - 1;           // x_{i+1}; the xf row uses x_T
@@ -715,7 +719,7 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
 // The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
 // and turned to the row-/column-per-lane layouts through this wave's LDS tiles.
 template <int N>
-FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
+FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g, int shared) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, LD = C::LD;
     const FwKP P = fw_uniform(Pin);
@@ -727,21 +731,31 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     const fw_lds_t tB = tA + C::TILE;
     const int lr = lane < N ? lane : N - 1;
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
+    shared = __builtin_amdgcn_readfirstlane(shared);
+    const double* facp = shared ? P->sh_fac : W.fac;
+    const double* rsp = shared ? P->sh_rs : W.rsg;
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
-    for (int i = W.nb - 1; i >= 0; --i) {
-        const double* f = W.fac + (size_t)i * 3 * N * LDG + lc;
-        // U1 -> tA, U2 -> tB (row-major tiles), then row lr of each on lane lr
-        double g1[N], g2[N];
+    // software pipeline: each register set is reloaded for stage i-1 as soon as stage i has consumed it
+    double g1[N], g2[N], gl[N], yv_n, rs_n;
+    {
+        const int i = W.nb - 1;
+        const double* f = facp + (size_t)i * 3 * N * LDG + lc;
 #pragma unroll
-        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; g2[j] = f[(2 * N + j) * LDG]; }
-        double v = W.yv[i * N + lr];
-        const double rsv = W.rsg[i * 32 + lr];
+        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; g2[j] = f[(2 * N + j) * LDG]; gl[j] = f[j * LDG]; }
+        yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
+    }
+    for (int i = W.nb - 1; i >= 0; --i) {
+        const int ip = i > 0 ? i - 1 : 0;                      // stage to prefetch (harmless re-read at i = 0)
+        const double* fp = facp + (size_t)ip * 3 * N * LDG + lc;
+        double v = yv_n;
+        const double rsv = rs_n;
+        // U1 -> tA, U2 -> tB (row-major tiles), then row lr of each on lane lr
 #pragma unroll
         for (int j = 0; j < N; ++j) { tA[j * LD + lc] = g1[j]; tB[j * LD + lc] = g2[j]; }
         fw_wave_fence();
-        double gl[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) gl[j] = f[j * LDG];            // column j of L across the lanes
+        for (int j = 0; j < N; ++j) { g1[j] = fp[(N + j) * LDG]; g2[j] = fp[(2 * N + j) * LDG]; }
+        yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
         {
             const fw_clds_t r1 = tA + lr * LD;
             const fw_clds_t r2 = tB + lr * LD;
@@ -757,6 +771,8 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int j = 0; j < N; ++j) tA[j * LD + lc] = gl[j];
         fw_wave_fence();
+#pragma unroll
+        for (int j = 0; j < N; ++j) gl[j] = fp[j * LDG];
         double res = 0.0;
         {
             const fw_clds_t cl = tA + lr * LD;
@@ -771,6 +787,62 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         if (lane < N) W.dnu[i * N + lane] = res;
         x2 = x1;
         x1 = res;
+    }
+    fw_mem_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward sweep against the handle's SHARED factor (first Newton step from a cold start: every
+// problem has the same Phi, Y and Cholesky factor, only the right-hand side differs; SURVEY §7.2a
+// regime (ii)).   y_i = L_ii^-1 (rhs_i - U_{i-1,i}' y_{i-1} - U_{i-2,i}' y_{i-2})
+// The tiles are read coalesced from L2 (all waves read the same 0.5 MB); lane r owns entry r.
+template <int N>
+FW_FN void fw_phase_forward_shared(FwKP Pin, int p) {
+    using C = FwCfg<N>;
+    constexpr int LDG = C::LDG;
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63;
+    const int lr = lane < N ? lane : N - 1;
+    const double* fac = P->sh_fac + lr;
+    const double* rsp = P->sh_rs + lr;
+    double y1 = 0.0, y2 = 0.0;                   // lane j: y_{i-1}[j], y_{i-2}[j]
+    for (int i = 0; i < W.nb; ++i) {
+        double sv = W.rhs[i * N + lr];
+        const double rsv = rsp[i * 32];
+        double lcol[N];
+        {
+            const double* fl = fac + (size_t)i * 3 * N * LDG;
+#pragma unroll
+            for (int j = 0; j < N; ++j) lcol[j] = fl[j * LDG];              // L[lane][j]
+        }
+        if (i >= 1) {
+            const double* f1 = fac + ((size_t)(i - 1) * 3 + 1) * N * LDG;   // U_{i-1,i}, row-major
+            double u[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) u[j] = f1[j * LDG];
+#pragma unroll
+            for (int j = 0; j < N; ++j) sv = fma(-u[j], fw_readlane(y1, j), sv);
+        }
+        if (i >= 2) {
+            const double* f2 = fac + ((size_t)(i - 2) * 3 + 2) * N * LDG;   // U_{i-2,i}
+            double u[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) u[j] = f2[j * LDG];
+#pragma unroll
+            for (int j = 0; j < N; ++j) sv = fma(-u[j], fw_readlane(y2, j), sv);
+        }
+        double res = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double xj = fw_readlane(sv * rsv, j);
+            if (lane == j) res = xj;
+            sv = fma(-lcol[j], xj, sv);            // meaningful on lanes > j only
+        }
+        if (lane < N) W.yv[i * N + lane] = res;
+        y2 = y1;
+        y1 = res;
     }
     fw_mem_fence();
 }
@@ -837,13 +909,20 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             fw_wave_fence();
             FW_KTICK(1);
             const double rho2 = rd2 + rp2;
-            if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;        // inf_newton_solver.m:19-22
+            if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
             fw_phase_C<N, 1>(P, p, lds, red);               // rhs
             FW_KTICK(2);
-            if (fw_phase_factor<N>(P, p, lds)) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            const int shared = (P->mode == FW_MODE_SHARED && it == 0 && *P->sh_ok != 0) ? 1 : 0;
+            if (shared) {
+                fw_phase_forward_shared<N>(P, p);
+            } else {
+                const int npd = fw_phase_factor<N>(P, p, lds);
+                if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
+                if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            }
             FW_KTICK(3);
-            fw_phase_backward<N>(P, p, lds);
+            fw_phase_backward<N>(P, p, lds, shared);
             FW_KTICK(4);
             fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
             fw_wave_fence();
@@ -893,6 +972,7 @@ int fmpc_wave_waves_per_wg() { return FW_WAVES; }
 size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
     return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
 }
+size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 3 * n * FwCfg<27>::LDG; }
 
 // Fill the three images of one n x n row-major block (see FwCfg): host helper.
 void fmpc_wave_make_images(int n, const double* blk, double* out) {
@@ -925,10 +1005,11 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* x0, const double* x0p, const double* w, const double* zinit,
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
-                            size_t ws_stride, size_t lds_bytes, hipStream_t stream) {
+                            size_t ws_stride, size_t lds_bytes, hipStream_t stream,
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
-    P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.pad_ = 0;
+    P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;
     hipLaunchKernelGGL(fmpc_newton_wave<27>, dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);

@@ -204,3 +204,27 @@ def test_full_size_properties_batch_2000(pkg, gpu):
     assert np.array_equal(i1["iters"][sel], ito)
     assert max(rel_err(zs[p], zo[p]) for p in range(16)) <= TOL
     h.close()
+
+
+def test_shared_cold_start_factor_equals_per_problem_factor(pkg, gpu):
+    """Cold start: the first Newton step of every problem uses ONE factor kept by the handle (it
+    depends on the model and k only).  FMPC_NO_SHARED=1 at create time forces the per-problem path;
+    both must agree to round-off, for several k on the same handle, and for later iterations."""
+    md = pkg.synthetic.make_model(27, 144, 30)
+    md["u_min"] = -0.5 * np.ones(144); md["u_max"] = 0.5 * np.ones(144)      # some problems need > 1 step
+    data = pkg.synthetic.make_replay_batch(md, r=9, steps=40)
+    hs = handle_from_model(pkg, md)
+    os.environ["FMPC_NO_SHARED"] = "1"
+    try:
+        hp = handle_from_model(pkg, md)
+    finally:
+        del os.environ["FMPC_NO_SHARED"]
+    for k, nw in [(1e-2, 1), (1e-1, 4), (1e-2, 4)]:
+        zs, i_s = hs.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=k, return_info=True)
+        zp, i_p = hp.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=k, return_info=True)
+        assert np.array_equal(i_s["iters"], i_p["iters"]) and np.array_equal(i_s["status"], i_p["status"])
+        assert np.array_equal(canon_steps(i_s["step"]), canon_steps(i_p["step"]))
+        assert max(rel_err(zs[p], zp[p]) for p in range(40)) <= 1e-11
+    zo, _, ito, _, _ = oracle_batch(md, data, 4, 1e-2)
+    assert np.array_equal(i_s["iters"], ito) and max(rel_err(zs[p], zo[p]) for p in range(40)) <= TOL
+    hs.close(); hp.close()
