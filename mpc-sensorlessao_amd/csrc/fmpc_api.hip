@@ -36,8 +36,9 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
-                            int mode, double* sh_fac, double* sh_rs, int* sh_ok);
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
+void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
 #define FMPC_LDS_LIMIT (160 * 1024)
 
@@ -60,6 +61,8 @@ struct fmpc_handle_s {
     // model and on k, so it is computed once per (handle, k) and kept in HBM (L2-resident, 0.5 MB).
     double* sh_fac; double* sh_rs; int* sh_ok; double* sh_scratch;
     double sh_k; int sh_valid; int sh_enabled;
+    double* cold_d;                      // cold-start constants on the device (FwCold layout)
+    std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
@@ -149,7 +152,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
-    h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0;
+    h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -323,6 +326,12 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             }
             (void)hipMemset(h->sh_ok, 0, sizeof(int));
             (void)hipMemset(h->sh_scratch, 0, nscr * sizeof(double));
+            int off9[9];
+            fmpc_wave_cold_layout(n, mp, off9);
+            if (hipMalloc((void**)&h->cold_d, (size_t)off9[8] * sizeof(double)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+            h->hm_R2 = R2; h->hm_rl.assign(m, 0.0); if (r) h->hm_rl.assign(r, r + m);
+            h->hm_umin.assign(u_min, u_min + m); h->hm_umax.assign(u_max, u_max + m);
+            h->hm_umid = umid; h->hm_xmid = xmid; h->hm_bt = bt; h->hm_a1 = a1; h->hm_a2 = a2;
             h->sh_enabled = 1;
         }
     }
@@ -341,6 +350,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->sh_rs) (void)hipFree(h->sh_rs);
     if (h->sh_ok) (void)hipFree(h->sh_ok);
     if (h->sh_scratch) (void)hipFree(h->sh_scratch);
+    if (h->cold_d) (void)hipFree(h->cold_d);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -355,6 +365,44 @@ extern "C" int fmpc_dims(fmpc_handle h, int* n, int* m, int* T, int* nz, int* nu
     if (nz) *nz = h->T * (h->n + h->m);
     if (nu_len) *nu_len = h->nb * h->n;
     return FMPC_OK;
+}
+
+// Cold-start constants for barrier weight k (see FwCold in fmpc_kernel_wave.hip): the first Newton
+// step from u = ubar, x = xbar only needs these k-dependent vectors and the 27 x 27 matrix G.
+static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
+    const int n = h->n, m = h->m, mp = h->wave.mp;
+    int o[9];
+    fmpc_wave_cold_layout(n, mp, o);
+    std::vector<double> c((size_t)o[8], 0.0);
+    for (int j = 0; j < m; ++j) {
+        const double sp = h->hm_umax[j] - h->hm_umid[j], sm = h->hm_umid[j] - h->hm_umin[j];
+        const double dp = 1.0 / sp, dm = 1.0 / sm;
+        const double hc = k * (dp * dp + dm * dm);
+        c[o[0] + j] = h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] + k * (dp - dm);
+        c[o[1] + j] = hc;
+        c[o[2] + j] = 1.0 / (h->hm_R2[j] + hc);
+    }
+    const double* bt = h->hm_bt.data();                         // bt[c*n + r] = B[r][c]
+    for (int a = 0; a < n; ++a) {
+        double cbu = 0.0, bu = 0.0;
+        for (int j = 0; j < m; ++j) {
+            cbu += bt[(size_t)j * n + a] * c[o[2] + j] * c[o[0] + j];
+            bu += bt[(size_t)j * n + a] * h->hm_umid[j];
+        }
+        c[o[4] + a] = cbu;
+        double a1x = 0.0, a2x = 0.0;
+        for (int q = 0; q < n; ++q) { a1x += h->hm_a1[a * n + q] * h->hm_xmid[q]; a2x += h->hm_a2[a * n + q] * h->hm_xmid[q]; }
+        c[o[5] + a] = h->hm_xmid[a] - bu;
+        c[o[6] + a] = h->hm_xmid[a] - bu - a1x;
+        c[o[7] + a] = h->hm_xmid[a] - bu - a1x - a2x;
+        for (int b = 0; b < n; ++b) {
+            double g = 0.0;
+            for (int j = 0; j < m; ++j) g += bt[(size_t)j * n + a] * c[o[2] + j] * bt[(size_t)j * n + b];
+            c[o[3] + a * n + b] = g;
+        }
+    }
+    return hipMemcpyAsync(h->cold_d, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream) == hipSuccess
+               ? FMPC_OK : FMPC_E_HIP;
 }
 
 static int fmpc_grid_for(fmpc_handle h, int batch) {
@@ -407,15 +455,16 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                 double* scr = h->sh_scratch;                 // a zero state: x0 = x0_pre = 0, w = nu0 = 0
                 e = fmpc_launch_wave(h->dev, h->wave, 1, 1, scr, scr, nullptr, nullptr, nullptr, 1, k,
                                      scr + ((h->n + 15) & ~15), nullptr, nullptr, nullptr, nullptr, 1, h->ws, stride,
-                                     h->wave_lds, (hipStream_t)stream, 2, h->sh_fac, h->sh_rs, h->sh_ok);
+                                     h->wave_lds, (hipStream_t)stream, 2, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
                 if (e != hipSuccess) return FMPC_E_HIP;
+                if (fmpc_upload_cold(h, k, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
                 h->sh_valid = 1; h->sh_k = k;
             }
             mode = 1;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
-                             h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok);
+                             h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
     } else {
         const int grid = fmpc_grid_for(h, batch);
         size_t stride = 0;

@@ -91,6 +91,22 @@ __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T,
     return L;
 }
 
+// Cold-start constants (first Newton step from the mid-box start u = ubar, x = xbar; all k-dependent
+// pieces are rebuilt by the host when k changes).  Offsets in doubles into FwParams::cold.
+//   cu = 2R ubar + r + k P'd      hc = k diag(P'DP)      wc = 1/(2R + hc)      G = B diag(wc) B'
+//   cbu = B (wc o cu)             cp_i = xbar - B ubar - [i>=1] A1 xbar - [i>=2] A2 xbar
+struct FwCold {
+    int cu, hc, wc, G, cbu, cp0, cp1, cp2, total;
+};
+__host__ __device__ static inline FwCold fw_cold_layout(int N, int mp) {
+    FwCold c; int o = 0;
+    c.cu = o; o += mp; c.hc = o; o += mp; c.wc = o; o += mp;
+    c.G = o; o += N * N + (N * N & 1);
+    c.cbu = o; o += 32; c.cp0 = o; o += 32; c.cp1 = o; o += 32; c.cp2 = o; o += 32;
+    c.total = o;
+    return c;
+}
+
 // The kernel's ONLY parameter: phases re-read it from the kernarg segment (scalar loads).
 struct FwParams {
     FmpcDevModel M;
@@ -102,6 +118,7 @@ struct FwParams {
     double* zout; double* nuout; int* status; int* iters; double* step;
     double* ws; size_t ws_stride;
     double* sh_fac; double* sh_rs; int* sh_ok;     // shared (cold-start) factor owned by the handle
+    const double* cold;                             // cold-start constants (FwCold layout), k-dependent
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -175,17 +192,19 @@ struct FwView {
 // ------------------------------------------------------------------------------------------------
 // P0: start point, nu, b   (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
 template <int N>
-FW_FN void fw_phase_init(FwKP Pin, int p) {
+FW_FN void fw_phase_init(FwKP Pin, int p, int write_z) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     const FwView<N> W(P, p);
     const int lane = threadIdx.x & 63;
     const int Nz = W.T * W.s, nbn = W.nb * N, m = W.m;
     const double* zinit = P->zinit;
-    for (int idx = lane; idx < Nz; idx += 64) {
-        const int e = idx % W.s;
-        W.zp[idx] = zinit ? zinit[(size_t)p * Nz + idx] : (e < m ? P->M.umid[e] : P->M.xmid[e - m]);
-    }
+    write_z = __builtin_amdgcn_readfirstlane(write_z);
+    if (write_z)
+        for (int idx = lane; idx < Nz; idx += 64) {
+            const int e = idx % W.s;
+            W.zp[idx] = zinit ? zinit[(size_t)p * Nz + idx] : (e < m ? P->M.umid[e] : P->M.xmid[e - m]);
+        }
     const double* x0v = P->x0 + (size_t)p * N;
     const double* x0pv = P->x0p ? P->x0p + (size_t)p * N : nullptr;
     const double* w = P->w;
@@ -204,7 +223,7 @@ FW_FN void fw_phase_init(FwKP Pin, int p) {
         if (i == W.T) v = P->M.xf[r];
         W.b[idx] = v;
     }
-    if (P->step)
+    if (write_z != 2 && P->step)
         for (int idx = lane; idx < P->step_ld; idx += 64) P->step[(size_t)p * P->step_ld + idx] = -1.0;
     fw_mem_fence();
 }
@@ -495,6 +514,323 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
     if (MODE == 0) {
         acc = fw_wave_sum(acc);
         if (lane == 0) out1[0] = acc;
+    }
+    fw_mem_fence();
+}
+
+// ================================================================================================
+// Cold-start variants of the vector phases (first Newton step from u = ubar, x = xbar; SURVEY §7.2a
+// regime (ii)).  With a constant primal start the m-wide quantities collapse:
+//     r_d[u_j] = cu - B'nu_j          B Phi^-1 r_d[u_i] = cbu - G nu_i          r_p,i = cp_i - b_i
+// so no m-wide array (z, Rt^-1, r_d) makes a round trip through HBM and z is written exactly once.
+// ================================================================================================
+
+// residual norms, r_d on the x entries (+ Phi^-1 of it) and r_p.   out3 = { sum r_d^2, sum r_p^2, - }
+template <int N>
+FW_FN void fw_cold_resid(FwKP Pin, int p, double* lds_g, double* out3_g) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const fw_clds_t sBt = (fw_clds_t)lds_g;
+    const fw_lds_t out3 = (fw_lds_t)out3_g;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int m = W.m, T = W.T, nb = W.nb;
+    const FwCold CL = fw_cold_layout(N, W.mp);
+    const double* cold = P->cold;
+    const double* vec = W.nu;
+    const double* A1p = P->M.A1; const double* A2p = P->M.A2;
+    const double* Q2p = P->M.Q2; const double* Qf2p = P->M.Qf2;
+    const double* qlp = P->M.ql; const double* qflp = P->M.qfl; const double* xmid = P->M.xmid;
+    const bool has_xf = W.has_xf != 0, var2 = W.var2 != 0;
+    double acc_d = 0.0, acc_p = 0.0;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        bool sok[8]; int sj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = j0 + 16 * (e >> 2) + 4 * (e & 3) + g;
+            sok[e] = j < T; sj[e] = sok[e] ? j : 0;
+        }
+        double an[2][7], a1[2][7], a2[2][7];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
+                const bool kk = k < N;
+                const double t0 = vec[(kk && j < T ? j : 0) * N + (kk ? k : 0)];
+                const double t1 = vec[(kk && j + 1 < T ? j + 1 : 0) * N + (kk ? k : 0)];
+                const double t2 = vec[(kk && j + 2 < T ? j + 2 : 0) * N + (kk ? k : 0)];
+                an[I][ks] = (kk && j < T) ? t0 : 0.0;
+                a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
+                a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
+            }
+        // ---- u entries: only ||cu - B'nu_j||^2 is needed
+        for (int J = 0; J * 16 < m; ++J) {
+            const int c = 16 * J + c16;
+            const bool cok = c < m;
+            d4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+            const fw_clds_t br = sBt + c * FW_LDB + g;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const double bb = br[4 * ks];
+                g0 = MFMA64(an[0][ks], bb, g0);
+                g1 = MFMA64(an[1][ks], bb, g1);
+            }
+            const double cuc = cold[CL.cu + (cok ? c : 0)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double rd = cuc - ((e >> 2) == 0 ? g0[e & 3] : g1[e & 3]);
+                if (cok && sok[e]) acc_d += rd * rd;
+            }
+        }
+        // ---- x entries: r_d[x_j] = 2Q_j xbar + q_j + nu_{j-1} - A1'nu_j - A2'nu_{j+1} (+ nu_T)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            const int rr = 16 * J + c16;
+            const bool rok = rr < N;
+            const int rc = rok ? rr : 0;
+            d4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int k = 4 * ks + g;
+                const bool ok = k < N && rok;
+                const int off = ok ? k * N + rr : 0;
+                const double t1 = A1p[off], t2 = A2p[off];
+                const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
+                h0 = MFMA64(a1[0][ks], b1, h0);
+                h1 = MFMA64(a1[1][ks], b1, h1);
+                h0 = MFMA64(a2[0][ks], b2, h0);
+                h1 = MFMA64(a2[1][ks], b2, h1);
+            }
+            const double cq2 = Q2p[rc], cqf2 = Qf2p[rc], cql = qlp[rc], cqfl = qflp[rc], xb = xmid[rc];
+            double vprev[8], vxf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool last = sj[e] + 1 == T;
+                vprev[e] = vec[sj[e] * N + rc];
+                vxf[e] = vec[(last && has_xf ? T : sj[e]) * N + rc];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double H = (e >> 2) == 0 ? h0[e & 3] : h1[e & 3];
+                const bool last = sj[e] + 1 == T;
+                const double q2 = last ? cqf2 : cq2;
+                double v = q2 * xb + (last ? cqfl : cql) + vprev[e] - H;
+                if (last && has_xf) v += vxf[e];
+                if (rok && sok[e]) {
+                    W.rdx[sj[e] * N + rr] = v;
+                    W.phx[sj[e] * N + rr] = v * fw_rcp(q2);
+                    acc_d += v * v;
+                }
+            }
+        }
+    }
+    // ---- r_p,i = cp_i - b_i  (xf row: xbar - xf)
+    for (int idx = lane; idx < nb * N; idx += 64) {
+        const int i = idx / N, r = idx - i * N;
+        const double c = i >= T ? xmid[r] : cold[(i == 0 ? CL.cp0 : i == 1 ? CL.cp1 : CL.cp2) + r];
+        const double v = c - W.b[idx];
+        W.rp[idx] = v;
+        acc_p += v * v;
+    }
+    acc_d = fw_wave_sum(acc_d);
+    acc_p = fw_wave_sum(acc_p);
+    if (lane == 0) { out3[0] = acc_d; out3[1] = acc_p; }
+    fw_mem_fence();
+}
+
+// rhs_i = r_p,i - (Phi^-1 r_d[x_{i+1}] - (cbu - G nu_i) - A1 Phi^-1 r_d[x_i] - A2 Phi^-1 r_d[x_{i-1}])
+template <int N>
+FW_FN void fw_cold_rhs(FwKP Pin, int p) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int T = W.T, nb = W.nb;
+    const FwCold CL = fw_cold_layout(N, W.mp);
+    const double* cold = P->cold;
+    const double* A1tp = P->M.A1t; const double* A2tp = P->M.A2t;
+    const bool var2 = W.var2 != 0;
+    for (int j0 = 0; j0 < nb; j0 += 32) {
+        d4 a[2][2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) a[I][J] = (d4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int k = 4 * ks + g;
+            double xg[2], xa[2], xb[2], zn[2], za[2], zb[2];
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
+                const bool ok = k < N && rr < N;
+                const int off = ok ? k * N + rr : 0;
+                const double tg = cold[CL.G + off], t1 = A1tp[off], t2 = A2tp[off];
+                xg[J] = ok ? -tg : 0.0;              // -G[k][r]  (G symmetric)
+                xa[J] = ok ? t1 : 0.0;               // A1[r][k]
+                xb[J] = ok ? t2 : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const int i = j0 + 16 * I + c16;
+                const bool okn = k < N && i < T;
+                const bool oka = k < N && i >= 1 && i < T;
+                const bool okb = k < N && i >= 2 && i < T && var2;
+                const double tn = W.nu[okn ? i * N + k : 0];
+                const double ta = W.phx[oka ? (i - 1) * N + k : 0];
+                const double tb = W.phx[okb ? (i - 2) * N + k : 0];
+                zn[I] = okn ? tn : 0.0; za[I] = oka ? ta : 0.0; zb[I] = okb ? tb : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    a[I][J] = MFMA64(zn[I], xg[J], a[I][J]);
+                    a[I][J] = MFMA64(za[I], xa[J], a[I][J]);
+                    a[I][J] = MFMA64(zb[I], xb[J], a[I][J]);
+                }
+        }
+        bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16], cb[2];
+#pragma unroll
+        for (int J = 0; J < 2; ++J) cb[J] = cold[CL.cbu + 16 * J + c16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
+            const int i = j0 + 16 * I + 4 * r + g, row = 16 * J + c16;
+            ok[e] = row < N && i < nb;
+            ir[e] = ok[e] ? row : 0; ii[e] = ok[e] ? i : 0;
+            const int jx = ii[e] < T ? ii[e] : T - 1;
+            in0[e] = W.phx[jx * N + ir[e]];
+            in1[e] = W.rp[ii[e] * N + ir[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
+            const double cz = ii[e] < T ? cb[J] + a[I][J][r] : 0.0;
+            if (ok[e]) W.rhs[ii[e] * N + ir[e]] = in1[e] - (in0[e] - cz);
+        }
+    }
+    fw_mem_fence();
+}
+
+// d_z from d_nu.  pass 0: line-search dots  out3 = { <r_d,e>, ||e||^2 };  pass 1: z = zbar + t d_z
+// written ONCE, nu += t d_nu.   d_u_j = wc o (B'(d_nu_j) - r_d[u_j]),  r_d[u_j] = cu - B'nu_j.
+template <int N>
+FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass, double t) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    pass = __builtin_amdgcn_readfirstlane(pass);
+    const FwView<N> W(P, p);
+    const fw_clds_t sBt = (fw_clds_t)lds_g;
+    const fw_lds_t out3 = (fw_lds_t)out3_g;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int m = W.m, T = W.T, s = W.s, nb = W.nb;
+    const FwCold CL = fw_cold_layout(N, W.mp);
+    const double* cold = P->cold;
+    const double* A1p = P->M.A1; const double* A2p = P->M.A2;
+    const double* Q2p = P->M.Q2; const double* Qf2p = P->M.Qf2;
+    const double* umid = P->M.umid; const double* xmid = P->M.xmid;
+    const bool has_xf = W.has_xf != 0, var2 = W.var2 != 0;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        bool sok[8]; int sj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = j0 + 16 * (e >> 2) + 4 * (e & 3) + g;
+            sok[e] = j < T; sj[e] = sok[e] ? j : 0;
+        }
+        double an[2][7], ad[2][7];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
+                const bool ok = k < N && j < T;
+                const double t0 = W.nu[ok ? j * N + k : 0], t1 = W.dnu[ok ? j * N + k : 0];
+                an[I][ks] = ok ? t0 : 0.0; ad[I][ks] = ok ? t1 : 0.0;
+            }
+        for (int J = 0; J * 16 < m; ++J) {
+            const int c = 16 * J + c16;
+            const bool cok = c < m;
+            const int cc = cok ? c : 0;
+            d4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0}, q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+            const fw_clds_t br = sBt + c * FW_LDB + g;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const double bb = br[4 * ks];
+                g0 = MFMA64(an[0][ks], bb, g0);
+                g1 = MFMA64(an[1][ks], bb, g1);
+                q0 = MFMA64(ad[0][ks], bb, q0);
+                q1 = MFMA64(ad[1][ks], bb, q1);
+            }
+            const double cuc = cold[CL.cu + cc], hcc = cold[CL.hc + cc], wcc = cold[CL.wc + cc], ub = umid[cc];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double rd = cuc - ((e >> 2) == 0 ? g0[e & 3] : g1[e & 3]);
+                const double du = wcc * (((e >> 2) == 0 ? q0[e & 3] : q1[e & 3]) - rd);
+                if (cok && sok[e]) {
+                    if (pass == 0) { const double ee = hcc * du; acc0 += rd * ee; acc1 += ee * ee; }
+                    else W.zp[sj[e] * s + c] = ub + t * du;
+                }
+            }
+        }
+        if (pass == 1) {
+            // ---- x entries: d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1'd_nu_j + A2'd_nu_{j+1} (- d_nu_T))
+            double a1[2][7], a2[2][7];
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    const int j = j0 + 16 * I + c16, k = 4 * ks + g;
+                    const bool o1 = k < N && j + 1 < T, o2 = k < N && j + 2 < T && var2;
+                    const double t1 = W.dnu[o1 ? (j + 1) * N + k : 0], t2 = W.dnu[o2 ? (j + 2) * N + k : 0];
+                    a1[I][ks] = o1 ? t1 : 0.0; a2[I][ks] = o2 ? t2 : 0.0;
+                }
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
+                const bool rok = rr < N;
+                const int rc = rok ? rr : 0;
+                d4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    const int k = 4 * ks + g;
+                    const bool ok = k < N && rok;
+                    const int off = ok ? k * N + rr : 0;
+                    const double t1 = A1p[off], t2 = A2p[off];
+                    const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
+                    h0 = MFMA64(a1[0][ks], b1, h0);
+                    h1 = MFMA64(a1[1][ks], b1, h1);
+                    h0 = MFMA64(a2[0][ks], b2, h0);
+                    h1 = MFMA64(a2[1][ks], b2, h1);
+                }
+                const double cq2 = Q2p[rc], cqf2 = Qf2p[rc], xb = xmid[rc];
+                double vprev[8], vxf[8], rdx[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool last = sj[e] + 1 == T;
+                    vprev[e] = W.dnu[sj[e] * N + rc];
+                    vxf[e] = W.dnu[(last && has_xf ? T : sj[e]) * N + rc];
+                    rdx[e] = W.rdx[sj[e] * N + rc];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double H = (e >> 2) == 0 ? h0[e & 3] : h1[e & 3];
+                    const bool last = sj[e] + 1 == T;
+                    double v = -rdx[e] - vprev[e] + H;
+                    if (last && has_xf) v -= vxf[e];
+                    if (rok && sok[e]) W.zp[sj[e] * s + m + rr] = xb + t * (v * fw_rcp(last ? cqf2 : cq2));
+                }
+            }
+        }
+    }
+    if (pass == 0) {
+        acc0 = fw_wave_sum(acc0);
+        acc1 = fw_wave_sum(acc1);
+        if (lane == 0) { out3[0] = acc0; out3[1] = acc1; }
+    } else {
+        for (int idx = lane; idx < nb * N; idx += 64) W.nu[idx] += t * W.dnu[idx];
     }
     fw_mem_fence();
 }
@@ -892,29 +1228,41 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
 #else
 #define FW_KTICK(k)
 #endif
+    // cold: first Newton step from the mid-box start with the handle's shared factor and constants
+    const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
     for (int p = wave_g; p < batch; p += nwaves) {
         FW_KTICK(7);
-        fw_phase_init<N>(P, p);
+        fw_phase_init<N>(P, p, cold_mode ? 0 : 1);
         FW_KTICK(0);
         int st = FMPC_OK, nsteps = 0;
         for (int it = 0; it < max_iter; ++it) {
-            fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
-            fw_wave_fence();
-            const double rd2 = red[0];
-            const bool bad = red[2] != 0.0;
-            fw_wave_fence();
-            fw_phase_C<N, 0>(P, p, lds, red);               // r_p
-            fw_wave_fence();
-            const double rp2 = red[0];
-            fw_wave_fence();
+            const bool cold = cold_mode && it == 0;
+            double rd2, rp2;
+            bool bad = false;
+            if (cold) {
+                fw_cold_resid<N>(P, p, lds, red);
+                fw_wave_fence();
+                rd2 = red[0]; rp2 = red[1];
+                fw_wave_fence();
+            } else {
+                fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
+                fw_wave_fence();
+                rd2 = red[0];
+                bad = red[2] != 0.0;
+                fw_wave_fence();
+                fw_phase_C<N, 0>(P, p, lds, red);               // r_p
+                fw_wave_fence();
+                rp2 = red[0];
+                fw_wave_fence();
+            }
             FW_KTICK(1);
             const double rho2 = rd2 + rp2;
             if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
-            fw_phase_C<N, 1>(P, p, lds, red);               // rhs
+            if (cold) fw_cold_rhs<N>(P, p);
+            else fw_phase_C<N, 1>(P, p, lds, red);               // rhs
             FW_KTICK(2);
-            const int shared = (P->mode == FW_MODE_SHARED && it == 0 && *P->sh_ok != 0) ? 1 : 0;
-            if (shared) {
+            if (cold) {
                 fw_phase_forward_shared<N>(P, p);
             } else {
                 const int npd = fw_phase_factor<N>(P, p, lds);
@@ -922,9 +1270,10 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                 if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             }
             FW_KTICK(3);
-            fw_phase_backward<N>(P, p, lds, shared);
+            fw_phase_backward<N>(P, p, lds, cold ? 1 : 0);
             FW_KTICK(4);
-            fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
+            if (cold) fw_cold_step<N>(P, p, lds, red, 0, 0.0);
+            else fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
             fw_wave_fence();
             const double beta_e = red[0], eps2 = red[1];
             fw_wave_fence();
@@ -940,11 +1289,14 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                     if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
             }
-            fw_phase_update<N>(P, p, t);
+            if (cold) fw_cold_step<N>(P, p, lds, red, 1, t);
+            else fw_phase_update<N>(P, p, t);
             if (P->step && lane == 0 && it < P->step_ld) P->step[(size_t)p * P->step_ld + it] = t;
             ++nsteps;
             FW_KTICK(5);
         }
+        if (cold_mode && nsteps == 0) fw_phase_init<N>(P, p, 2);       // left before stepping: z is the start point
+        FW_KTICK(6);
         if (P->nuout) {
             const FwView<N> W(P, p);
             const int nbn = W.nb * N;
@@ -973,6 +1325,11 @@ size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
     return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
 }
 size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 3 * n * FwCfg<27>::LDG; }
+void fmpc_wave_cold_layout(int n, int mp, int* off9) {
+    const FwCold c = fw_cold_layout(n, mp);
+    off9[0] = c.cu; off9[1] = c.hc; off9[2] = c.wc; off9[3] = c.G; off9[4] = c.cbu; off9[5] = c.cp0; off9[6] = c.cp1;
+    off9[7] = c.cp2; off9[8] = c.total;
+}
 
 // Fill the three images of one n x n row-major block (see FwCfg): host helper.
 void fmpc_wave_make_images(int n, const double* blk, double* out) {
@@ -1006,10 +1363,10 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
-                            int mode, double* sh_fac, double* sh_rs, int* sh_ok) {
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
-    P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok;
+    P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;
     hipLaunchKernelGGL(fmpc_newton_wave<27>, dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);
