@@ -174,7 +174,7 @@ __device__ __forceinline__ void fw_mem_fence() {           // this wave's HBM wr
 // Per-wave pointers, rebuilt in each phase from the kernarg parameters.
 template <int N>
 struct FwView {
-    int m, mp, T, nb, s, has_xf, var2;
+    int m, mp, T, nb, s, has_xf, var2, fstride;
     double *zp, *b, *nu, *hess, *winv, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
     __device__ __forceinline__ FwView(FwKP P, int p) {
         m = P->M.m; mp = P->V.mp; T = P->M.T; nb = P->M.nb; s = N + m; has_xf = P->M.has_xf; var2 = P->M.var2;
@@ -185,7 +185,8 @@ struct FwView {
         b = wsp + L.b; nu = wsp + L.nu; hess = wsp + L.hess; winv = wsp + L.winv; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
-        if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; }   // the factor IS the product
+        fstride = 3 * N * FwCfg<N>::LDG;
+        if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; fstride = 6 * N * FwCfg<N>::LDG; }   // the factor IS the product
     }
 };
 
@@ -996,7 +997,7 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
         FW_TICK(2);
         // ---- results: U1|y -> tB, U2|y -> tA (layout change) and the factor to HBM
         {
-            double* f = W.fac + (size_t)i * 3 * N * LDG;
+            double* f = W.fac + (size_t)i * W.fstride;
             const int cl = lane & 31;
             const bool hi = lane >= 32;
             const fw_lds_t tdst = (hi ? tA : tB) + (cl < 28 ? cl : 28);
@@ -1007,11 +1008,27 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];       // U1 / U2 row-major for the backward sweep
             }
+            const bool ex = P->mode == FW_MODE_EXPORT;
             if (lane < N) {
+                // column j of L contiguous in r.  Shared (exported) tiles carry exact zeros on and above
+                // the diagonal so that the shared sweeps need no per-step masking; otherwise that part is unused.
                 double* gl = f + lane;
 #pragma unroll
-                for (int j = 0; j < N; ++j) gl[j * LDG] = row[j];       // column j of L contiguous in r (upper part unused)
+                for (int j = 0; j < N; ++j) gl[j * LDG] = (ex && j >= lane) ? 0.0 : row[j];
                 W.rsg[i * 32 + lane] = myrs;
+            }
+            if (ex) {
+                // transposed copies for the shared backward sweep: tile 3 = L as [r][j], 4/5 = U1'/U2' as [c][r]
+                if (cl < N) {
+                    double* gt = f + (hi ? 5 : 4) * N * LDG + cl * LDG;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) gt[j] = x[j];
+                }
+                if (lane < N) {
+                    double* gt = f + 3 * N * LDG + lane * LDG;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) gt[j] = j < lane ? row[j] : 0.0;
+                }
             }
         }
         fw_wave_fence();
@@ -1068,21 +1085,22 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g, int shared) {
     const int lr = lane < N ? lane : N - 1;
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
     shared = __builtin_amdgcn_readfirstlane(shared);
-    const double* facp = shared ? P->sh_fac : W.fac;
-    const double* rsp = shared ? P->sh_rs : W.rsg;
+    (void)shared;
+    const double* facp = W.fac;
+    const double* rsp = W.rsg;
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
     // software pipeline: each register set is reloaded for stage i-1 as soon as stage i has consumed it
     double g1[N], g2[N], gl[N], yv_n, rs_n;
     {
         const int i = W.nb - 1;
-        const double* f = facp + (size_t)i * 3 * N * LDG + lc;
+        const double* f = facp + (size_t)i * W.fstride + lc;
 #pragma unroll
         for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; g2[j] = f[(2 * N + j) * LDG]; gl[j] = f[j * LDG]; }
         yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
     }
     for (int i = W.nb - 1; i >= 0; --i) {
         const int ip = i > 0 ? i - 1 : 0;                      // stage to prefetch (harmless re-read at i = 0)
-        const double* fp = facp + (size_t)ip * 3 * N * LDG + lc;
+        const double* fp = facp + (size_t)ip * W.fstride + lc;
         double v = yv_n;
         const double rsv = rs_n;
         // U1 -> tA, U2 -> tB (row-major tiles), then row lr of each on lane lr
@@ -1128,57 +1146,97 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g, int shared) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward sweep against the handle's SHARED factor (first Newton step from a cold start: every
-// problem has the same Phi, Y and Cholesky factor, only the right-hand side differs; SURVEY §7.2a
-// regime (ii)).   y_i = L_ii^-1 (rhs_i - U_{i-1,i}' y_{i-1} - U_{i-2,i}' y_{i-2})
-// The tiles are read coalesced from L2 (all waves read the same 0.5 MB); lane r owns entry r.
-template <int N>
-FW_FN void fw_phase_forward_shared(FwKP Pin, int p) {
+// Sweeps against the handle's SHARED factor (first Newton step from a cold start: every problem has
+// the same Phi, Y and Cholesky factor, only the right-hand side differs; SURVEY §7.2a regime (ii)).
+//     forward   y_i    = L_ii^-1 (rhs_i - U_{i-1,i}' y_{i-1} - U_{i-2,i}' y_{i-2})
+//     backward  d_nu_i = L_ii^-T (y_i  - U_{i,i+1} d_nu_{i+1} - U_{i,i+2} d_nu_{i+2})
+// Six tiles per stage in the shared buffer: [0] L with f[j][r] = L[r][j], [1] U1, [2] U2 row-major,
+// [3] L row-major, [4] U1', [5] U2'; the L tiles are exactly zero on and above the diagonal.
+// WORKGROUP-COLLECTIVE: all 8 waves walk the stages together; the three tiles of a stage (18 KB) are
+// staged ONCE per workgroup into LDS (double buffered in the per-wave tile region, idle here; one
+// barrier per stage) and every wave reads its rows from LDS.  Every wave of the workgroup must call
+// this function; `go` = 0 makes a wave take part in the staging only.
+template <int N, int BWD>
+FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
     using C = FwCfg<N>;
-    constexpr int LDG = C::LDG;
+    constexpr int LDG = C::LDG, TS = N * LDG, ST = 3 * TS, NPRE = (ST + FW_THREADS - 1) / FW_THREADS;
+    static_assert(2 * ST <= FW_WAVES * C::PER_WAVE, "stage buffers must fit the tile region");
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
-    const FwView<N> W(P, p);
-    const int lane = threadIdx.x & 63;
+    go = __builtin_amdgcn_readfirstlane(go);
+    const FwView<N> W(P, go ? p : 0);
+    const int tid = threadIdx.x, lane = tid & 63;
     const int lr = lane < N ? lane : N - 1;
-    const double* fac = P->sh_fac + lr;
+    const int nb = W.nb;
+    const fw_lds_t buf = (fw_lds_t)lds_g + W.mp * FW_LDB;
+    const double* fac = P->sh_fac;
     const double* rsp = P->sh_rs + lr;
-    double y1 = 0.0, y2 = 0.0;                   // lane j: y_{i-1}[j], y_{i-2}[j]
-    for (int i = 0; i < W.nb; ++i) {
-        double sv = W.rhs[i * N + lr];
-        const double rsv = rsp[i * 32];
-        double lcol[N];
-        {
-            const double* fl = fac + (size_t)i * 3 * N * LDG;
+    const double* src = BWD ? W.yv : W.rhs;
+    double* dst = BWD ? W.dnu : W.yv;
+    // tiles used by stage i:  forward: (i,0), (i-1,1), (i-2,2);  backward: (i,3), (i,4), (i,5)
+    auto tile = [&](int i, int which) -> const double* {
+        if (BWD) return fac + ((size_t)i * 6 + 3 + which) * TS;
+        const int st = i - which;
+        return fac + ((size_t)(st < 0 ? 0 : st) * 6 + which) * TS;
+    };
+    const int first = BWD ? nb - 1 : 0, step = BWD ? -1 : 1;
 #pragma unroll
-            for (int j = 0; j < N; ++j) lcol[j] = fl[j * LDG];              // L[lane][j]
+    for (int r = 0; r < NPRE; ++r) {
+        const int idx = tid + FW_THREADS * r;
+        if (idx < ST) buf[idx] = tile(first, idx / TS)[idx % TS];
+    }
+    __syncthreads();
+    double ya = 0.0, yb = 0.0;                   // lane j: the two previously computed block entries
+    for (int q = 0, i = first; q < nb; ++q, i += step) {
+        const fw_clds_t cur = buf + (q & 1) * ST;
+        const fw_lds_t nxt = buf + ((q + 1) & 1) * ST;
+        const bool more = q + 1 < nb;
+        double pre[NPRE];
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < NPRE; ++r) {
+                const int idx = tid + FW_THREADS * r;
+                pre[r] = idx < ST ? tile(i + step, idx / TS)[idx % TS] : 0.0;
+            }
         }
-        if (i >= 1) {
-            const double* f1 = fac + ((size_t)(i - 1) * 3 + 1) * N * LDG;   // U_{i-1,i}, row-major
-            double u[N];
+        if (go) {
+            double sv = src[i * N + lr];
+            const double rsv = rsp[i * 32];
+            const bool has1 = BWD ? (i + 1 < nb) : (i >= 1);
+            const bool has2 = BWD ? (i + 2 < nb) : (i >= 2);
+            if (has1) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) u[j] = f1[j * LDG];
+                for (int j = 0; j < N; ++j) sv = fma(-cur[TS + j * LDG + lr], fw_readlane(ya, j), sv);
+            }
+            if (has2) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) sv = fma(-u[j], fw_readlane(y1, j), sv);
+                for (int j = 0; j < N; ++j) sv = fma(-cur[2 * TS + j * LDG + lr], fw_readlane(yb, j), sv);
+            }
+            // substitution: L is exactly zero on/above the diagonal, so lane j's sv is final after
+            // step j-1 (forward) / j+1 (backward) and x_j = sv * rs for every lane at the end
+            double lcol[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) lcol[j] = cur[j * LDG + lr];
+            if (BWD) {
+#pragma unroll
+                for (int j = N - 1; j >= 1; --j) sv = fma(-lcol[j], fw_readlane(sv * rsv, j), sv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N - 1; ++j) sv = fma(-lcol[j], fw_readlane(sv * rsv, j), sv);
+            }
+            const double res = sv * rsv;
+            if (lane < N) dst[i * N + lane] = res;
+            yb = ya;
+            ya = res;
         }
-        if (i >= 2) {
-            const double* f2 = fac + ((size_t)(i - 2) * 3 + 2) * N * LDG;   // U_{i-2,i}
-            double u[N];
+        if (more) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) u[j] = f2[j * LDG];
-#pragma unroll
-            for (int j = 0; j < N; ++j) sv = fma(-u[j], fw_readlane(y2, j), sv);
+            for (int r = 0; r < NPRE; ++r) {
+                const int idx = tid + FW_THREADS * r;
+                if (idx < ST) nxt[idx] = pre[r];
+            }
         }
-        double res = 0.0;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double xj = fw_readlane(sv * rsv, j);
-            if (lane == j) res = xj;
-            sv = fma(-lcol[j], xj, sv);            // meaningful on lanes > j only
-        }
-        if (lane < N) W.yv[i * N + lane] = res;
-        y2 = y1;
-        y1 = res;
+        __syncthreads();
     }
     fw_mem_fence();
 }
@@ -1228,52 +1286,84 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
 #else
 #define FW_KTICK(k)
 #endif
-    // cold: first Newton step from the mid-box start with the handle's shared factor and constants
+    // cold: first Newton step from the mid-box start with the handle's shared factor and constants.
+    // All waves of a workgroup run the same number of rounds (the shared sweeps are collective).
     const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
-    for (int p = wave_g; p < batch; p += nwaves) {
+    const int rounds = (batch + nwaves - 1) / nwaves;
+    for (int rnd = 0; rnd < rounds; ++rnd) {
+        const int p = wave_g + rnd * nwaves;
+        const bool active = p < batch;
         FW_KTICK(7);
-        fw_phase_init<N>(P, p, cold_mode ? 0 : 1);
-        FW_KTICK(0);
-        int st = FMPC_OK, nsteps = 0;
-        for (int it = 0; it < max_iter; ++it) {
-            const bool cold = cold_mode && it == 0;
-            double rd2, rp2;
-            bool bad = false;
-            if (cold) {
+        int st = FMPC_OK, nsteps = 0, it0 = 0;
+        bool done = !active;
+        if (cold_mode) {
+            double rho2 = 0.0;
+            int go = 0;
+            if (active) {
+                fw_phase_init<N>(P, p, 0);
+                FW_KTICK(0);
                 fw_cold_resid<N>(P, p, lds, red);
                 fw_wave_fence();
-                rd2 = red[0]; rp2 = red[1];
+                const double rd2 = red[0], rp2 = red[1];
                 fw_wave_fence();
-            } else {
-                fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
-                fw_wave_fence();
-                rd2 = red[0];
-                bad = red[2] != 0.0;
-                fw_wave_fence();
-                fw_phase_C<N, 0>(P, p, lds, red);               // r_p
-                fw_wave_fence();
-                rp2 = red[0];
-                fw_wave_fence();
+                rho2 = rd2 + rp2;
+                FW_KTICK(1);
+                if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) done = true;     // inf_newton_solver.m:19-22
+                else { go = 1; fw_cold_rhs<N>(P, p); }
+                FW_KTICK(2);
             }
+            fw_phase_sweep_shared<N, 0>(P, p, go, lds);
+            FW_KTICK(3);
+            fw_phase_sweep_shared<N, 1>(P, p, go, lds);
+            FW_KTICK(4);
+            if (go) {
+                fw_cold_step<N>(P, p, lds, red, 0, 0.0);
+                fw_wave_fence();
+                const double beta_e = red[0], eps2 = red[1];
+                fw_wave_fence();
+                double t = 1.0;
+                const double al = 1e-4;
+                int halv = 0;
+                while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
+                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2
+                                      - 2.0 * (1.0 - t) * beta_e + t * eps2;
+                    if (gq <= 0.0) break;
+                    t *= 0.5;
+                    if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                }
+                fw_cold_step<N>(P, p, lds, red, 1, t);
+                if (P->step && lane == 0 && P->step_ld > 0) P->step[(size_t)p * P->step_ld] = t;
+                nsteps = 1;
+                FW_KTICK(5);
+            }
+            it0 = 1;
+        } else if (active) {
+            fw_phase_init<N>(P, p, 1);
+            FW_KTICK(0);
+        }
+        for (int it = it0; it < max_iter && !done; ++it) {
+            fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
+            fw_wave_fence();
+            const double rd2 = red[0];
+            const bool bad = red[2] != 0.0;
+            fw_wave_fence();
+            fw_phase_C<N, 0>(P, p, lds, red);               // r_p
+            fw_wave_fence();
+            const double rp2 = red[0];
+            fw_wave_fence();
             FW_KTICK(1);
             const double rho2 = rd2 + rp2;
             if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
-            if (cold) fw_cold_rhs<N>(P, p);
-            else fw_phase_C<N, 1>(P, p, lds, red);               // rhs
+            fw_phase_C<N, 1>(P, p, lds, red);               // rhs
             FW_KTICK(2);
-            if (cold) {
-                fw_phase_forward_shared<N>(P, p);
-            } else {
-                const int npd = fw_phase_factor<N>(P, p, lds);
-                if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
-                if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
-            }
+            const int npd = fw_phase_factor<N>(P, p, lds);
+            if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
+            if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FW_KTICK(3);
-            fw_phase_backward<N>(P, p, lds, cold ? 1 : 0);
+            fw_phase_backward<N>(P, p, lds, 0);
             FW_KTICK(4);
-            if (cold) fw_cold_step<N>(P, p, lds, red, 0, 0.0);
-            else fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
+            fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
             fw_wave_fence();
             const double beta_e = red[0], eps2 = red[1];
             fw_wave_fence();
@@ -1289,12 +1379,12 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                     if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
             }
-            if (cold) fw_cold_step<N>(P, p, lds, red, 1, t);
-            else fw_phase_update<N>(P, p, t);
+            fw_phase_update<N>(P, p, t);
             if (P->step && lane == 0 && it < P->step_ld) P->step[(size_t)p * P->step_ld + it] = t;
             ++nsteps;
             FW_KTICK(5);
         }
+        if (!active) continue;
         if (cold_mode && nsteps == 0) fw_phase_init<N>(P, p, 2);       // left before stepping: z is the start point
         FW_KTICK(6);
         if (P->nuout) {
@@ -1324,7 +1414,7 @@ int fmpc_wave_waves_per_wg() { return FW_WAVES; }
 size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
     return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
 }
-size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 3 * n * FwCfg<27>::LDG; }
+size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 6 * n * FwCfg<27>::LDG; }
 void fmpc_wave_cold_layout(int n, int mp, int* off9) {
     const FwCold c = fw_cold_layout(n, mp);
     off9[0] = c.cu; off9[1] = c.hc; off9[2] = c.wc; off9[3] = c.G; off9[4] = c.cbu; off9[5] = c.cp0; off9[6] = c.cp1;
