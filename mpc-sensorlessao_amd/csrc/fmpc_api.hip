@@ -314,7 +314,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         if (fmpc_wave_prepare(n, h->wave_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
         h->use_wave = 1;
         const char* nosh = getenv("FMPC_NO_SHARED");
-        if (!(nosh && nosh[0] == '1')) {
+        if (!(nosh && nosh[0] == '1') && h->nb * n <= 840) {     // the cold path keeps rhs/y/d_nu in an 840-double LDS vector
             const size_t nf = fmpc_wave_shared_fac_doubles(n, h->nb);
             const size_t nscr = (size_t)T * (n + m) + 64 + (size_t)n;      // zero state + z of the export solve
             if (hipMalloc((void**)&h->sh_fac, nf * sizeof(double)) != hipSuccess ||

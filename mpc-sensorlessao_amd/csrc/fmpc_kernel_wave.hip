@@ -33,6 +33,8 @@
 #define FW_MAX_HALVINGS 64
 #define FW_LDB 33                       // leading dimension of B' in LDS (odd)
 #define FW_KCH 6                        // k-steps per prefetch chunk of the K = m products
+// cold path: LDS region behind B' = [2 stage buffers of the shared sweeps][8 per-wave vectors rhs->y->d_nu]
+#define FW_VEC_STRIDE 840               // doubles per wave (nb*n <= 840 checked on the host)
 #define FW_MODE_NORMAL 0                // every problem factors its own Y
 #define FW_MODE_SHARED 1                // first Newton step from a cold start uses the handle's shared factor
 #define FW_MODE_EXPORT 2                // compute that shared factor (batch 1) and publish it
@@ -519,6 +521,12 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
     fw_mem_fence();
 }
 
+
+template <int N>
+__device__ __forceinline__ fw_lds_t fw_cold_vec(double* lds_g, int mp) {      // this wave's rhs/y/d_nu vector
+    return (fw_lds_t)lds_g + mp * FW_LDB + 2 * 3 * N * FwCfg<N>::LDG + (threadIdx.x >> 6) * FW_VEC_STRIDE;
+}
+
 // ================================================================================================
 // Cold-start variants of the vector phases (first Newton step from u = ubar, x = xbar; SURVEY §7.2a
 // regime (ii)).  With a constant primal start the m-wide quantities collapse:
@@ -642,10 +650,11 @@ FW_FN void fw_cold_resid(FwKP Pin, int p, double* lds_g, double* out3_g) {
 
 // rhs_i = r_p,i - (Phi^-1 r_d[x_{i+1}] - (cbu - G nu_i) - A1 Phi^-1 r_d[x_i] - A2 Phi^-1 r_d[x_{i-1}])
 template <int N>
-FW_FN void fw_cold_rhs(FwKP Pin, int p) {
+FW_FN void fw_cold_rhs(FwKP Pin, int p, double* lds_g) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     const FwView<N> W(P, p);
+    const fw_lds_t vl = fw_cold_vec<N>(lds_g, W.mp);
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int T = W.T, nb = W.nb;
     const FwCold CL = fw_cold_layout(N, W.mp);
@@ -709,14 +718,16 @@ FW_FN void fw_cold_rhs(FwKP Pin, int p) {
         for (int e = 0; e < 16; ++e) {
             const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
             const double cz = ii[e] < T ? cb[J] + a[I][J][r] : 0.0;
-            if (ok[e]) W.rhs[ii[e] * N + ir[e]] = in1[e] - (in0[e] - cz);
+            if (ok[e]) vl[ii[e] * N + ir[e]] = in1[e] - (in0[e] - cz);
         }
     }
+    fw_wave_fence();
     fw_mem_fence();
 }
 
-// d_z from d_nu.  pass 0: line-search dots  out3 = { <r_d,e>, ||e||^2 };  pass 1: z = zbar + t d_z
-// written ONCE, nu += t d_nu.   d_u_j = wc o (B'(d_nu_j) - r_d[u_j]),  r_d[u_j] = cu - B'nu_j.
+// d_z from d_nu (read from this wave's LDS vector).  pass 0: line-search dots out3 = { <r_d,e>, ||e||^2 }
+// AND z = zbar + d_z written speculatively for t = 1 (the usual outcome); pass 1 (only if t != 1):
+// z = zbar + t d_z rewritten.  nu += t d_nu is done by the caller's last pass.   d_u_j = wc o (B'(d_nu_j) - r_d[u_j]),  r_d[u_j] = cu - B'nu_j.
 template <int N>
 FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass, double t) {
     const FwKP P = fw_uniform(Pin);
@@ -725,8 +736,10 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
     const FwView<N> W(P, p);
     const fw_clds_t sBt = (fw_clds_t)lds_g;
     const fw_lds_t out3 = (fw_lds_t)out3_g;
+    const fw_clds_t dn = fw_cold_vec<N>(lds_g, W.mp);
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    const int m = W.m, T = W.T, s = W.s, nb = W.nb;
+    const int m = W.m, T = W.T, s = W.s;
+    if (pass == 0) t = 1.0;
     const FwCold CL = fw_cold_layout(N, W.mp);
     const double* cold = P->cold;
     const double* A1p = P->M.A1; const double* A2p = P->M.A2;
@@ -748,7 +761,7 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
             for (int ks = 0; ks < 7; ++ks) {
                 const int j = j0 + 16 * I + c16, k = 4 * ks + g;
                 const bool ok = k < N && j < T;
-                const double t0 = W.nu[ok ? j * N + k : 0], t1 = W.dnu[ok ? j * N + k : 0];
+                const double t0 = W.nu[ok ? j * N + k : 0], t1 = dn[ok ? j * N + k : 0];
                 an[I][ks] = ok ? t0 : 0.0; ad[I][ks] = ok ? t1 : 0.0;
             }
         for (int J = 0; J * 16 < m; ++J) {
@@ -772,11 +785,11 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
                 const double du = wcc * (((e >> 2) == 0 ? q0[e & 3] : q1[e & 3]) - rd);
                 if (cok && sok[e]) {
                     if (pass == 0) { const double ee = hcc * du; acc0 += rd * ee; acc1 += ee * ee; }
-                    else W.zp[sj[e] * s + c] = ub + t * du;
+                    W.zp[sj[e] * s + c] = ub + t * du;
                 }
             }
         }
-        if (pass == 1) {
+        {
             // ---- x entries: d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1'd_nu_j + A2'd_nu_{j+1} (- d_nu_T))
             double a1[2][7], a2[2][7];
 #pragma unroll
@@ -785,7 +798,7 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
                 for (int ks = 0; ks < 7; ++ks) {
                     const int j = j0 + 16 * I + c16, k = 4 * ks + g;
                     const bool o1 = k < N && j + 1 < T, o2 = k < N && j + 2 < T && var2;
-                    const double t1 = W.dnu[o1 ? (j + 1) * N + k : 0], t2 = W.dnu[o2 ? (j + 2) * N + k : 0];
+                    const double t1 = dn[o1 ? (j + 1) * N + k : 0], t2 = dn[o2 ? (j + 2) * N + k : 0];
                     a1[I][ks] = o1 ? t1 : 0.0; a2[I][ks] = o2 ? t2 : 0.0;
                 }
 #pragma unroll
@@ -811,8 +824,8 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool last = sj[e] + 1 == T;
-                    vprev[e] = W.dnu[sj[e] * N + rc];
-                    vxf[e] = W.dnu[(last && has_xf ? T : sj[e]) * N + rc];
+                    vprev[e] = dn[sj[e] * N + rc];
+                    vxf[e] = dn[(last && has_xf ? T : sj[e]) * N + rc];
                     rdx[e] = W.rdx[sj[e] * N + rc];
                 }
 #pragma unroll
@@ -830,9 +843,19 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
         acc0 = fw_wave_sum(acc0);
         acc1 = fw_wave_sum(acc1);
         if (lane == 0) { out3[0] = acc0; out3[1] = acc1; }
-    } else {
-        for (int idx = lane; idx < nb * N; idx += 64) W.nu[idx] += t * W.dnu[idx];
     }
+    fw_mem_fence();
+}
+
+// nu += t d_nu (d_nu in this wave's LDS vector)
+template <int N>
+FW_FN void fw_cold_nu_update(FwKP Pin, int p, double* lds_g, double t) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const fw_clds_t dn = fw_cold_vec<N>(lds_g, W.mp);
+    const int lane = threadIdx.x & 63;
+    for (int idx = lane; idx < W.nb * N; idx += 64) W.nu[idx] += t * dn[idx];
     fw_mem_fence();
 }
 
@@ -1160,7 +1183,7 @@ template <int N, int BWD>
 FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, TS = N * LDG, ST = 3 * TS, NPRE = (ST + FW_THREADS - 1) / FW_THREADS;
-    static_assert(2 * ST <= FW_WAVES * C::PER_WAVE, "stage buffers must fit the tile region");
+    static_assert(2 * ST + FW_WAVES * FW_VEC_STRIDE <= FW_WAVES * C::PER_WAVE, "stage buffers + vectors must fit the tile region");
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     go = __builtin_amdgcn_readfirstlane(go);
@@ -1171,8 +1194,7 @@ FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
     const fw_lds_t buf = (fw_lds_t)lds_g + W.mp * FW_LDB;
     const double* fac = P->sh_fac;
     const double* rsp = P->sh_rs + lr;
-    const double* src = BWD ? W.yv : W.rhs;
-    double* dst = BWD ? W.dnu : W.yv;
+    const fw_lds_t vl = fw_cold_vec<N>(lds_g, W.mp);          // rhs -> y (forward), y -> d_nu (backward), in place
     // tiles used by stage i:  forward: (i,0), (i-1,1), (i-2,2);  backward: (i,3), (i,4), (i,5)
     auto tile = [&](int i, int which) -> const double* {
         if (BWD) return fac + ((size_t)i * 6 + 3 + which) * TS;
@@ -1200,7 +1222,7 @@ FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
             }
         }
         if (go) {
-            double sv = src[i * N + lr];
+            double sv = vl[i * N + lr];
             const double rsv = rsp[i * 32];
             const bool has1 = BWD ? (i + 1 < nb) : (i >= 1);
             const bool has2 = BWD ? (i + 2 < nb) : (i >= 2);
@@ -1225,7 +1247,7 @@ FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
                 for (int j = 0; j < N - 1; ++j) sv = fma(-lcol[j], fw_readlane(sv * rsv, j), sv);
             }
             const double res = sv * rsv;
-            if (lane < N) dst[i * N + lane] = res;
+            if (lane < N) vl[i * N + lane] = res;
             yb = ya;
             ya = res;
         }
@@ -1309,7 +1331,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                 rho2 = rd2 + rp2;
                 FW_KTICK(1);
                 if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) done = true;     // inf_newton_solver.m:19-22
-                else { go = 1; fw_cold_rhs<N>(P, p); }
+                else { go = 1; fw_cold_rhs<N>(P, p, lds); }
                 FW_KTICK(2);
             }
             fw_phase_sweep_shared<N, 0>(P, p, go, lds);
@@ -1331,7 +1353,8 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                     t *= 0.5;
                     if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
-                fw_cold_step<N>(P, p, lds, red, 1, t);
+                if (t != 1.0) fw_cold_step<N>(P, p, lds, red, 1, t);      // z was written for t = 1 by pass 0
+                fw_cold_nu_update<N>(P, p, lds, t);
                 if (P->step && lane == 0 && P->step_ld > 0) P->step[(size_t)p * P->step_ld] = t;
                 nsteps = 1;
                 FW_KTICK(5);

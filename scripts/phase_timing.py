@@ -25,5 +25,5 @@ for nm, i in [("P0 init", 4), ("P1 residuals (C'nu, Cz)", 5), ("P2 rhs", 6), ("P
 print("  total %.0f cycles/wave" % (tot / nw_))
 ft = sum(out[i] for i in range(4))
 ft = sum(out[i] for i in range(4))
-for nm, i in [("[factor: mfma | sweep: loop top]", 0), ("[factor: toLDS | sweep: matvecs+prefetch issue]", 1), ("[factor: fused | sweep: substitution]", 2), ("[factor: store | sweep: L prefetch + store]", 3)]:
+for nm, i in [("[cold_step: fragment loads]", 0), ("[cold_step: u-part GEMM+epilogue+z stores]", 1), ("[cold_step: x-part]", 2), ("[cold_step: reduction + fence]", 3)]:
     print("    %-30s %12.0f  %5.1f%% of P3" % (nm, out[i] / nw_, 100.0 * out[i] / max(ft, 1)))
