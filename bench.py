@@ -97,11 +97,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU path"
+    # Rehearsal on a one-GPU box: FMPC_BENCH_REHEARSE=1 puts every rank on device 0 and gathers over gloo
+    # (NCCL refuses two ranks on one device).  The real multi-GPU run uses RCCL ("nccl") below.
+    rehearse = os.environ.get("FMPC_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("mpc-sensorlessao_amd")
     n, m, T, B = N_MODES, N_ACT, HORIZON, args.batch
@@ -140,7 +148,11 @@ def main():
                 ev[1].record()
             handle.unpack_device(z, None, None, u0)              # first move u0 (README.md:589)
             if world > 1:
-                dist.all_gather_into_tensor(u0_all, u0)          # the one collective: final gather
+                if rehearse:
+                    parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, u0.cpu())
+                else:
+                    dist.all_gather_into_tensor(u0_all, u0)      # the one collective: final gather (RCCL)
         for _ in range(warmup):
             step()
         sync()
@@ -151,7 +163,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
