@@ -77,12 +77,12 @@ struct FwCfg {
 };
 
 // per-wave workspace in HBM (doubles)
-struct FwWs { size_t b, nu, hess, winv, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
+struct FwWs { size_t b, nu, winv, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
 __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T, int nb, int LDG) {
     FwWs L; size_t o = 0;
     const size_t nbn = ((size_t)nb * N + 1) & ~(size_t)1;
     L.b = o; o += nbn;  L.nu = o; o += nbn;
-    L.hess = o; o += (size_t)T * m;  L.winv = o; o += (size_t)T * mp;
+    L.winv = o; o += (size_t)T * mp;
     L.rdu = o; o += (size_t)T * m;   L.rdx = o; o += nbn;
     L.rp = o; o += nbn;  L.rhs = o; o += nbn;  L.y = o; o += nbn;  L.dnu = o; o += nbn;
     L.phx = o; o += nbn;
@@ -177,14 +177,14 @@ __device__ __forceinline__ void fw_mem_fence() {           // this wave's HBM wr
 template <int N>
 struct FwView {
     int m, mp, T, nb, s, has_xf, var2, fstride;
-    double *zp, *b, *nu, *hess, *winv, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
+    double *zp, *b, *nu, *winv, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
     __device__ __forceinline__ FwView(FwKP P, int p) {
         m = P->M.m; mp = P->V.mp; T = P->M.T; nb = P->M.nb; s = N + m; has_xf = P->M.has_xf; var2 = P->M.var2;
         const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG);
         const int wave_g = blockIdx.x * FW_WAVES + (threadIdx.x >> 6);
         double* wsp = P->ws + (size_t)wave_g * P->ws_stride;
         zp = P->zout + (size_t)p * T * s;
-        b = wsp + L.b; nu = wsp + L.nu; hess = wsp + L.hess; winv = wsp + L.winv; rdu = wsp + L.rdu;
+        b = wsp + L.b; nu = wsp + L.nu; winv = wsp + L.winv; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
         fstride = 3 * N * FwCfg<N>::LDG;
@@ -1095,7 +1095,7 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
 // The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
 // and turned to the row-/column-per-lane layouts through this wave's LDS tiles.
 template <int N>
-FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g, int shared) {
+FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, LD = C::LD;
     const FwKP P = fw_uniform(Pin);
@@ -1107,8 +1107,6 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g, int shared) {
     const fw_lds_t tB = tA + C::TILE;
     const int lr = lane < N ? lane : N - 1;
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
-    shared = __builtin_amdgcn_readfirstlane(shared);
-    (void)shared;
     const double* facp = W.fac;
     const double* rsp = W.rsg;
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
@@ -1384,7 +1382,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
             if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FW_KTICK(3);
-            fw_phase_backward<N>(P, p, lds, 0);
+            fw_phase_backward<N>(P, p, lds);
             FW_KTICK(4);
             fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
             fw_wave_fence();

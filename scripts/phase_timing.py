@@ -20,10 +20,10 @@ for rep in range(3):
 tot = sum(out[i] for i in range(4, 12))
 nw_ = min(B, 2048)
 print("per-wave-average cycles (batch %d, n_newton %d):" % (B, nw))
-for nm, i in [("P0 init", 4), ("P1 residuals (C'nu, Cz)", 5), ("P2 rhs", 6), ("P3 factor+fwd", 7), ("P4 backward", 8), ("P5 dz+update", 9), ("between problems", 11)]:
+for nm, i in [("P0 init", 4), ("P1 residuals (C'nu, Cz)", 5), ("P2 rhs", 6), ("P3 factor+fwd | shared fwd sweep", 7), ("P4 backward | shared bwd sweep", 8), ("P5 dz+update", 9), ("between problems", 11)]:
     print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nw_, 100.0 * out[i] / tot))
 print("  total %.0f cycles/wave" % (tot / nw_))
 ft = sum(out[i] for i in range(4))
-ft = sum(out[i] for i in range(4))
-for nm, i in [("[cold_step: fragment loads]", 0), ("[cold_step: u-part GEMM+epilogue+z stores]", 1), ("[cold_step: x-part]", 2), ("[cold_step: reduction + fence]", 3)]:
-    print("    %-30s %12.0f  %5.1f%% of P3" % (nm, out[i] / nw_, 100.0 * out[i] / max(ft, 1)))
+if ft:       # per-stage sections of the per-problem factor phase (general path only)
+    for nm, i in [("P3.images + B Rt^-1 B' + U'U (MFMA)", 0), ("P3.tiles -> LDS, row/col loads", 1), ("P3.fused potrf+trsm (VALU)", 2), ("P3.store + readback", 3)]:
+        print("    %-38s %12.0f  %5.1f%% of P3" % (nm, out[i] / nw_, 100.0 * out[i] / ft))
