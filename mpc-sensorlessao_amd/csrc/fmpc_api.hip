@@ -326,7 +326,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             }
             (void)hipMemset(h->sh_ok, 0, sizeof(int));
             (void)hipMemset(h->sh_scratch, 0, nscr * sizeof(double));
-            int off9[9];
+            int off9[14];
             fmpc_wave_cold_layout(n, mp, off9);
             if (hipMalloc((void**)&h->cold_d, (size_t)off9[8] * sizeof(double)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
             h->hm_R2 = R2; h->hm_rl.assign(m, 0.0); if (r) h->hm_rl.assign(r, r + m);
@@ -371,7 +371,7 @@ extern "C" int fmpc_dims(fmpc_handle h, int* n, int* m, int* T, int* nz, int* nu
 // step from u = ubar, x = xbar only needs these k-dependent vectors and the 27 x 27 matrix G.
 static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
     const int n = h->n, m = h->m, mp = h->wave.mp;
-    int o[9];
+    int o[14];
     fmpc_wave_cold_layout(n, mp, o);
     std::vector<double> c((size_t)o[8], 0.0);
     for (int j = 0; j < m; ++j) {
@@ -395,11 +395,26 @@ static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
         c[o[5] + a] = h->hm_xmid[a] - bu;
         c[o[6] + a] = h->hm_xmid[a] - bu - a1x;
         c[o[7] + a] = h->hm_xmid[a] - bu - a1x - a2x;
-        for (int b = 0; b < n; ++b) {
-            double g = 0.0;
-            for (int j = 0; j < m; ++j) g += bt[(size_t)j * n + a] * c[o[2] + j] * bt[(size_t)j * n + b];
-            c[o[3] + a * n + b] = g;
+        double va = 0.0, va2 = 0.0;
+        for (int j = 0; j < m; ++j) {
+            const double aj = c[o[1] + j] * c[o[2] + j];
+            va += bt[(size_t)j * n + a] * aj * c[o[0] + j];
+            va2 += bt[(size_t)j * n + a] * aj * aj * c[o[0] + j];
         }
+        c[o[11] + a] = va; c[o[12] + a] = va2;
+        for (int b = 0; b < n; ++b) {
+            double g = 0.0, ma = 0.0, ma2 = 0.0;
+            for (int j = 0; j < m; ++j) {
+                const double bb = bt[(size_t)j * n + a] * bt[(size_t)j * n + b];
+                const double aj = c[o[1] + j] * c[o[2] + j];
+                g += bb * c[o[2] + j]; ma += bb * aj; ma2 += bb * aj * aj;
+            }
+            c[o[3] + a * n + b] = g; c[o[9] + a * n + b] = ma; c[o[10] + a * n + b] = ma2;
+        }
+    }
+    for (int j = 0; j < m; ++j) {
+        const double aj = c[o[1] + j] * c[o[2] + j], cu = c[o[0] + j];
+        c[o[13]] += aj * cu * cu; c[o[13] + 1] += aj * aj * cu * cu;
     }
     return hipMemcpyAsync(h->cold_d, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, stream) == hipSuccess
                ? FMPC_OK : FMPC_E_HIP;

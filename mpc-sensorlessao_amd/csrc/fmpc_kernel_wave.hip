@@ -35,6 +35,8 @@
 #define FW_KCH 6                        // k-steps per prefetch chunk of the K = m products
 // cold path: LDS region behind B' = [2 stage buffers of the shared sweeps][8 per-wave vectors rhs->y->d_nu]
 #define FW_VEC_STRIDE 840               // doubles per wave (nb*n <= 840 checked on the host)
+// ... followed by [cu | hc | wc | ubar] (4*mp doubles) for the cold step's epilogue: LDS reads do not queue behind
+// the global stores of the previous column block (vmcnt counts stores too)
 #define FW_MODE_NORMAL 0                // every problem factors its own Y
 #define FW_MODE_SHARED 1                // first Newton step from a cold start uses the handle's shared factor
 #define FW_MODE_EXPORT 2                // compute that shared factor (batch 1) and publish it
@@ -97,14 +99,18 @@ __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T,
 // pieces are rebuilt by the host when k changes).  Offsets in doubles into FwParams::cold.
 //   cu = 2R ubar + r + k P'd      hc = k diag(P'DP)      wc = 1/(2R + hc)      G = B diag(wc) B'
 //   cbu = B (wc o cu)             cp_i = xbar - B ubar - [i>=1] A1 xbar - [i>=2] A2 xbar
+//   a = hc o wc:  Ma = B diag(a) B', Ma2 = B diag(a^2) B', va = B (a o cu), va2 = B (a^2 o cu),
+//   sa = sum a cu^2, sa2 = sum a^2 cu^2      (line-search dots as 27-dimensional quadratic forms)
 struct FwCold {
-    int cu, hc, wc, G, cbu, cp0, cp1, cp2, total;
+    int cu, hc, wc, G, cbu, cp0, cp1, cp2, Ma, Ma2, va, va2, sa, total;
 };
 __host__ __device__ static inline FwCold fw_cold_layout(int N, int mp) {
     FwCold c; int o = 0;
     c.cu = o; o += mp; c.hc = o; o += mp; c.wc = o; o += mp;
     c.G = o; o += N * N + (N * N & 1);
     c.cbu = o; o += 32; c.cp0 = o; o += 32; c.cp1 = o; o += 32; c.cp2 = o; o += 32;
+    c.Ma = o; o += N * N + (N * N & 1); c.Ma2 = o; o += N * N + (N * N & 1);
+    c.va = o; o += 32; c.va2 = o; o += 32; c.sa = o; o += 2;      // sa, sa2
     c.total = o;
     return c;
 }
@@ -212,19 +218,32 @@ FW_FN void fw_phase_init(FwKP Pin, int p, int write_z) {
     const double* x0pv = P->x0p ? P->x0p + (size_t)p * N : nullptr;
     const double* w = P->w;
     const double* nu0 = P->nu0;
-    for (int idx = lane; idx < nbn; idx += 64) {
-        W.nu[idx] = nu0 ? nu0[(size_t)p * nbn + idx] : 0.0;
-        const int i = idx / N, r = idx - i * N;
-        double v = (i < W.T && w) ? w[(size_t)p * W.T * N + idx] : 0.0;
-        if (i == 0) {
-            for (int c = 0; c < N; ++c) v += P->M.A1t[c * N + r] * x0v[c];
-            if (W.var2 && x0pv)
-                for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0pv[c];
-        } else if (i == 1 && i < W.T && W.var2) {
-            for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0v[c];
+    // every load before the first store: a load issued behind a global store waits for it (vmcnt is in order)
+    for (int base = 0; base < nbn; base += 64 * 14) {
+        double nv[14], bv[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const int idx = base + lane + 64 * q;
+            const bool ok = idx < nbn;
+            const int ic = ok ? idx : 0;
+            nv[q] = nu0 ? nu0[(size_t)p * nbn + ic] : 0.0;
+            const int i = ic / N, r = ic - i * N;
+            double v = (i < W.T && w) ? w[(size_t)p * W.T * N + ic] : 0.0;
+            if (ok && i == 0) {
+                for (int c = 0; c < N; ++c) v += P->M.A1t[c * N + r] * x0v[c];
+                if (W.var2 && x0pv)
+                    for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0pv[c];
+            } else if (ok && i == 1 && i < W.T && W.var2) {
+                for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0v[c];
+            }
+            if (i == W.T) v = P->M.xf[r];
+            bv[q] = v;
         }
-        if (i == W.T) v = P->M.xf[r];
-        W.b[idx] = v;
+#pragma unroll
+        for (int q = 0; q < 14; ++q) {
+            const int idx = base + lane + 64 * q;
+            if (idx < nbn) { W.nu[idx] = nv[q]; W.b[idx] = bv[q]; }
+        }
     }
     if (write_z != 2 && P->step)
         for (int idx = lane; idx < P->step_ld; idx += 64) P->step[(size_t)p * P->step_ld + idx] = -1.0;
@@ -527,6 +546,11 @@ __device__ __forceinline__ fw_lds_t fw_cold_vec(double* lds_g, int mp) {      //
     return (fw_lds_t)lds_g + mp * FW_LDB + 2 * 3 * N * FwCfg<N>::LDG + (threadIdx.x >> 6) * FW_VEC_STRIDE;
 }
 
+template <int N>
+__device__ __forceinline__ fw_lds_t fw_cold_consts(double* lds_g, int mp) {   // [cu | hc | wc | ubar], 4*mp doubles
+    return (fw_lds_t)lds_g + mp * FW_LDB + 2 * 3 * N * FwCfg<N>::LDG + FW_WAVES * FW_VEC_STRIDE;
+}
+
 // ================================================================================================
 // Cold-start variants of the vector phases (first Newton step from u = ubar, x = xbar; SURVEY §7.2a
 // regime (ii)).  With a constant primal start the m-wide quantities collapse:
@@ -725,6 +749,77 @@ FW_FN void fw_cold_rhs(FwKP Pin, int p, double* lds_g) {
     fw_mem_fence();
 }
 
+// Line-search dots of the cold step as 27-dimensional quadratic forms (mu_j = nu_j + d_nu_j):
+//   <r_d,e> = sum_j [ va'(mu_j + nu_j) - sa - nu_j' Ma mu_j ],   ||e||^2 = sum_j [ mu_j' Ma2 mu_j - 2 va2' mu_j + sa2 ]
+// out3 = { <r_d,e>, ||e||^2 }.  Exact algebra, different rounding: the caller uses it only when the step
+// length decision has a wide margin and falls back to the element-wise evaluation otherwise.
+template <int N>
+FW_FN void fw_cold_dots(FwKP Pin, int p, double* lds_g, double* out3_g) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const fw_lds_t out3 = (fw_lds_t)out3_g;
+    const fw_clds_t dn = fw_cold_vec<N>(lds_g, W.mp);
+    const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int T = W.T;
+    const FwCold CL = fw_cold_layout(N, W.mp);
+    const double* cold = P->cold;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int j0 = 0; j0 < T; j0 += 32) {
+        d4 a[2][2], b[2][2];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) { a[I][J] = (d4){0, 0, 0, 0}; b[I][J] = a[I][J]; }
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int k = 4 * ks + g;
+            double x1[2], x2[2], zm[2];
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
+                const bool ok = k < N && rr < N;
+                const int off = ok ? k * N + rr : 0;
+                const double t1 = cold[CL.Ma + off], t2 = cold[CL.Ma2 + off];
+                x1[J] = ok ? t1 : 0.0; x2[J] = ok ? t2 : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const int j = j0 + 16 * I + c16;
+                const bool ok = k < N && j < T;
+                const double t0 = W.nu[ok ? j * N + k : 0], t1 = dn[ok ? j * N + k : 0];
+                zm[I] = ok ? t0 + t1 : 0.0;
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    a[I][J] = MFMA64(zm[I], x1[J], a[I][J]);      // (Ma mu_j)[r]
+                    b[I][J] = MFMA64(zm[I], x2[J], b[I][J]);      // (Ma2 mu_j)[r]
+                }
+        }
+        double va[2], va2[2];
+#pragma unroll
+        for (int J = 0; J < 2; ++J) { va[J] = cold[CL.va + 16 * J + c16]; va2[J] = cold[CL.va2 + 16 * J + c16]; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
+            const int j = j0 + 16 * I + 4 * r + g, row = 16 * J + c16;
+            const bool ok = row < N && j < T;
+            const double nuv = W.nu[ok ? j * N + row : 0];
+            const double mu = nuv + dn[ok ? j * N + row : 0];
+            if (ok) {
+                acc0 += va[J] * (mu + nuv) - nuv * a[I][J][r];
+                acc1 += mu * b[I][J][r] - 2.0 * va2[J] * mu;
+            }
+        }
+    }
+    acc0 = fw_wave_sum(acc0) - T * cold[CL.sa];
+    acc1 = fw_wave_sum(acc1) + T * cold[CL.sa + 1];
+    if (lane == 0) { out3[0] = acc0; out3[1] = acc1; }
+    fw_mem_fence();
+}
+
 // d_z from d_nu (read from this wave's LDS vector).  pass 0: line-search dots out3 = { <r_d,e>, ||e||^2 }
 // AND z = zbar + d_z written speculatively for t = 1 (the usual outcome); pass 1 (only if t != 1):
 // z = zbar + t d_z rewritten.  nu += t d_nu is done by the caller's last pass.   d_u_j = wc o (B'(d_nu_j) - r_d[u_j]),  r_d[u_j] = cu - B'nu_j.
@@ -737,14 +832,13 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
     const fw_clds_t sBt = (fw_clds_t)lds_g;
     const fw_lds_t out3 = (fw_lds_t)out3_g;
     const fw_clds_t dn = fw_cold_vec<N>(lds_g, W.mp);
+    const fw_clds_t sC = fw_cold_consts<N>(lds_g, W.mp);
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    const int m = W.m, T = W.T, s = W.s;
+    const int m = W.m, mp = W.mp, T = W.T, s = W.s;
     if (pass == 0) t = 1.0;
-    const FwCold CL = fw_cold_layout(N, W.mp);
-    const double* cold = P->cold;
     const double* A1p = P->M.A1; const double* A2p = P->M.A2;
     const double* Q2p = P->M.Q2; const double* Qf2p = P->M.Qf2;
-    const double* umid = P->M.umid; const double* xmid = P->M.xmid;
+    const double* xmid = P->M.xmid;
     const bool has_xf = W.has_xf != 0, var2 = W.var2 != 0;
     double acc0 = 0.0, acc1 = 0.0;
     for (int j0 = 0; j0 < T; j0 += 32) {
@@ -762,7 +856,7 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
                 const int j = j0 + 16 * I + c16, k = 4 * ks + g;
                 const bool ok = k < N && j < T;
                 const double t0 = W.nu[ok ? j * N + k : 0], t1 = dn[ok ? j * N + k : 0];
-                an[I][ks] = ok ? t0 : 0.0; ad[I][ks] = ok ? t1 : 0.0;
+                an[I][ks] = ok ? t0 : 0.0; ad[I][ks] = ok ? (pass == 2 ? t0 + t1 : t1) : 0.0;     // pass 2: mu = nu + d_nu
             }
         for (int J = 0; J * 16 < m; ++J) {
             const int c = 16 * J + c16;
@@ -773,15 +867,18 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
                 const double bb = br[4 * ks];
-                g0 = MFMA64(an[0][ks], bb, g0);
-                g1 = MFMA64(an[1][ks], bb, g1);
+                if (pass != 2) {
+                    g0 = MFMA64(an[0][ks], bb, g0);
+                    g1 = MFMA64(an[1][ks], bb, g1);
+                }
                 q0 = MFMA64(ad[0][ks], bb, q0);
                 q1 = MFMA64(ad[1][ks], bb, q1);
             }
-            const double cuc = cold[CL.cu + cc], hcc = cold[CL.hc + cc], wcc = cold[CL.wc + cc], ub = umid[cc];
+            const double cuc = sC[cc], hcc = sC[mp + cc], wcc = sC[2 * mp + cc], ub = sC[3 * mp + cc];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const double rd = cuc - ((e >> 2) == 0 ? g0[e & 3] : g1[e & 3]);
+                // pass 0/1: q = B'd_nu, rd = cu - B'nu;  pass 2: q = B'(nu + d_nu), so q - cu = B'd_nu - rd
+                const double rd = pass == 2 ? cuc : cuc - ((e >> 2) == 0 ? g0[e & 3] : g1[e & 3]);
                 const double du = wcc * (((e >> 2) == 0 ? q0[e & 3] : q1[e & 3]) - rd);
                 if (cok && sok[e]) {
                     if (pass == 0) { const double ee = hcc * du; acc0 += rd * ee; acc1 += ee * ee; }
@@ -801,12 +898,14 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
                     const double t1 = dn[o1 ? (j + 1) * N + k : 0], t2 = dn[o2 ? (j + 2) * N + k : 0];
                     a1[I][ks] = o1 ? t1 : 0.0; a2[I][ks] = o2 ? t2 : 0.0;
                 }
+            d4 h[2][2];
+            double cq2[2], cqf2[2], xbv[2], vprev[2][8], vxf[2][8], rdx[2][8];
 #pragma unroll
             for (int J = 0; J < 2; ++J) {
                 const int rr = 16 * J + c16;
                 const bool rok = rr < N;
                 const int rc = rok ? rr : 0;
-                d4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
+                h[J][0] = (d4){0, 0, 0, 0}; h[J][1] = (d4){0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < 7; ++ks) {
                     const int k = 4 * ks + g;
@@ -814,27 +913,32 @@ FW_FN void fw_cold_step(FwKP Pin, int p, double* lds_g, double* out3_g, int pass
                     const int off = ok ? k * N + rr : 0;
                     const double t1 = A1p[off], t2 = A2p[off];
                     const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
-                    h0 = MFMA64(a1[0][ks], b1, h0);
-                    h1 = MFMA64(a1[1][ks], b1, h1);
-                    h0 = MFMA64(a2[0][ks], b2, h0);
-                    h1 = MFMA64(a2[1][ks], b2, h1);
+                    h[J][0] = MFMA64(a1[0][ks], b1, h[J][0]);
+                    h[J][1] = MFMA64(a1[1][ks], b1, h[J][1]);
+                    h[J][0] = MFMA64(a2[0][ks], b2, h[J][0]);
+                    h[J][1] = MFMA64(a2[1][ks], b2, h[J][1]);
                 }
-                const double cq2 = Q2p[rc], cqf2 = Qf2p[rc], xb = xmid[rc];
-                double vprev[8], vxf[8], rdx[8];
+                cq2[J] = Q2p[rc]; cqf2[J] = Qf2p[rc]; xbv[J] = xmid[rc];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool last = sj[e] + 1 == T;
-                    vprev[e] = dn[sj[e] * N + rc];
-                    vxf[e] = dn[(last && has_xf ? T : sj[e]) * N + rc];
-                    rdx[e] = W.rdx[sj[e] * N + rc];
+                    vprev[J][e] = dn[sj[e] * N + rc];
+                    vxf[J][e] = dn[(last && has_xf ? T : sj[e]) * N + rc];
+                    rdx[J][e] = W.rdx[sj[e] * N + rc];
                 }
+            }
+            // all loads are issued: only now the stores (a later load would queue behind them)
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
+                const bool rok = rr < N;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const double H = (e >> 2) == 0 ? h0[e & 3] : h1[e & 3];
+                    const double H = (e >> 2) == 0 ? h[J][0][e & 3] : h[J][1][e & 3];
                     const bool last = sj[e] + 1 == T;
-                    double v = -rdx[e] - vprev[e] + H;
-                    if (last && has_xf) v -= vxf[e];
-                    if (rok && sok[e]) W.zp[sj[e] * s + m + rr] = xb + t * (v * fw_rcp(last ? cqf2 : cq2));
+                    double v = -rdx[J][e] - vprev[J][e] + H;
+                    if (last && has_xf) v -= vxf[J][e];
+                    if (rok && sok[e]) W.zp[sj[e] * s + m + rr] = xbv[J] + t * (v * fw_rcp(last ? cqf2[J] : cq2[J]));
                 }
             }
         }
@@ -855,7 +959,12 @@ FW_FN void fw_cold_nu_update(FwKP Pin, int p, double* lds_g, double t) {
     const FwView<N> W(P, p);
     const fw_clds_t dn = fw_cold_vec<N>(lds_g, W.mp);
     const int lane = threadIdx.x & 63;
-    for (int idx = lane; idx < W.nb * N; idx += 64) W.nu[idx] += t * dn[idx];
+    const int nbn = W.nb * N;
+    double v[14];                                  // nb*n <= 840 < 14*64: every load before the first store
+#pragma unroll
+    for (int q = 0; q < 14; ++q) { const int idx = lane + 64 * q; v[q] = W.nu[idx < nbn ? idx : 0]; }
+#pragma unroll
+    for (int q = 0; q < 14; ++q) { const int idx = lane + 64 * q; if (idx < nbn) W.nu[idx] = v[q] + t * dn[idx]; }
     fw_mem_fence();
 }
 
@@ -1181,7 +1290,7 @@ template <int N, int BWD>
 FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, TS = N * LDG, ST = 3 * TS, NPRE = (ST + FW_THREADS - 1) / FW_THREADS;
-    static_assert(2 * ST + FW_WAVES * FW_VEC_STRIDE <= FW_WAVES * C::PER_WAVE, "stage buffers + vectors must fit the tile region");
+    static_assert(2 * ST + FW_WAVES * FW_VEC_STRIDE + 4 * 192 <= FW_WAVES * C::PER_WAVE, "stage buffers + vectors must fit the tile region");
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     go = __builtin_amdgcn_readfirstlane(go);
@@ -1313,6 +1422,15 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     for (int rnd = 0; rnd < rounds; ++rnd) {
         const int p = wave_g + rnd * nwaves;
         const bool active = p < batch;
+        if (cold_mode) {
+            // [cu | hc | wc | ubar] into LDS for the cold step's epilogue.  The region overlaps the per-wave
+            // tiles of the general path, so wait until every wave has left the previous round.
+            __syncthreads();
+            const fw_lds_t sC = fw_cold_consts<N>(lds, mp);
+            for (int i = threadIdx.x; i < 4 * mp; i += FW_THREADS)
+                sC[i] = i < 3 * mp ? P->cold[i] : (i - 3 * mp < P->M.m ? P->M.umid[i - 3 * mp] : 0.0);
+            __syncthreads();
+        }
         FW_KTICK(7);
         int st = FMPC_OK, nsteps = 0, it0 = 0;
         bool done = !active;
@@ -1337,21 +1455,31 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             fw_phase_sweep_shared<N, 1>(P, p, go, lds);
             FW_KTICK(4);
             if (go) {
-                fw_cold_step<N>(P, p, lds, red, 0, 0.0);
-                fw_wave_fence();
-                const double beta_e = red[0], eps2 = red[1];
-                fw_wave_fence();
-                double t = 1.0;
                 const double al = 1e-4;
-                int halv = 0;
-                while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
-                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2
-                                      - 2.0 * (1.0 - t) * beta_e + t * eps2;
-                    if (gq <= 0.0) break;
-                    t *= 0.5;
-                    if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                double t = 1.0;
+                // cheap dots (27-dimensional quadratic forms); accept t = 1 only with a wide margin
+                fw_cold_dots<N>(P, p, lds, red);
+                fw_wave_fence();
+                const double eps2q = red[1];
+                fw_wave_fence();
+                const bool clear = eps2q >= 0.0 && (-1.0 + 2.0 * al - al * al) * rho2 + eps2q <= -0.5 * rho2;
+                if (clear) {
+                    fw_cold_step<N>(P, p, lds, red, 2, 1.0);           // one product B'(nu + d_nu), z written once
+                } else {
+                    fw_cold_step<N>(P, p, lds, red, 0, 0.0);           // element-wise dots, z written for t = 1
+                    fw_wave_fence();
+                    const double beta_e = red[0], eps2 = red[1];
+                    fw_wave_fence();
+                    int halv = 0;
+                    while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
+                        const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2
+                                          - 2.0 * (1.0 - t) * beta_e + t * eps2;
+                        if (gq <= 0.0) break;
+                        t *= 0.5;
+                        if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                    }
+                    if (t != 1.0) fw_cold_step<N>(P, p, lds, red, 1, t);
                 }
-                if (t != 1.0) fw_cold_step<N>(P, p, lds, red, 1, t);      // z was written for t = 1 by pass 0
                 fw_cold_nu_update<N>(P, p, lds, t);
                 if (P->step && lane == 0 && P->step_ld > 0) P->step[(size_t)p * P->step_ld] = t;
                 nsteps = 1;
@@ -1436,10 +1564,10 @@ size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
     return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
 }
 size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 6 * n * FwCfg<27>::LDG; }
-void fmpc_wave_cold_layout(int n, int mp, int* off9) {
+void fmpc_wave_cold_layout(int n, int mp, int* off9) {      // 14 entries
     const FwCold c = fw_cold_layout(n, mp);
     off9[0] = c.cu; off9[1] = c.hc; off9[2] = c.wc; off9[3] = c.G; off9[4] = c.cbu; off9[5] = c.cp0; off9[6] = c.cp1;
-    off9[7] = c.cp2; off9[8] = c.total;
+    off9[7] = c.cp2; off9[8] = c.total; off9[9] = c.Ma; off9[10] = c.Ma2; off9[11] = c.va; off9[12] = c.va2; off9[13] = c.sa;
 }
 
 // Fill the three images of one n x n row-major block (see FwCfg): host helper.
