@@ -10,6 +10,7 @@
 
 #include "../../include/fastmpc.h"
 #include "fmpc_device.h"
+#include "fmpc_panel.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
 size_t fmpc_generic_lds_bytes(int n, int m);
@@ -36,7 +37,8 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
-                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold);
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
+                            const int* sel = nullptr, const int* sel_count = nullptr, int* sel_reset = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -62,6 +64,15 @@ struct fmpc_handle_s {
     double* sh_fac; double* sh_rs; int* sh_ok; double* sh_scratch;
     double sh_k; int sh_valid; int sh_enabled;
     double* cold_d;                      // cold-start constants on the device (FwCold layout)
+    // panel kernel (fmpc_kernel_panel.hip): the cold-start step on 16-problem panels, n_newton = 1
+    int pn_enabled, pn_valid, pn_mp, pn_parity;
+    size_t pn_lds;
+    double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
+    size_t pn_o_simg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_doubles;
+    int* pn_cnt;                         // two alternating selection counters
+    int* pn_sel; size_t pn_sel_cap;
+    double pn_rd2_0, pn_sa_cu;
+    std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
@@ -153,6 +164,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
+    h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_parity = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->pn_cnt = nullptr; h->pn_sel = nullptr; h->pn_sel_cap = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -333,6 +346,29 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             h->hm_umin.assign(u_min, u_min + m); h->hm_umax.assign(u_max, u_max + m);
             h->hm_umid = umid; h->hm_xmid = xmid; h->hm_bt = bt; h->hm_a1 = a1; h->hm_a2 = a2;
             h->sh_enabled = 1;
+            // panel kernel: needs the panel + images in LDS
+            const char* nopn = getenv("FMPC_NO_PANEL");
+            const int pmp = (m + 15) & ~15;
+            const size_t plds = fmpc_panel_lds_bytes(h->nb, pmp);
+            if (n == FP_N && !(nopn && nopn[0] == '1') && plds <= FMPC_LDS_LIMIT) {
+                const FpVec V = fp_vec_layout(h->nb, T);
+                size_t o = 0;
+                h->pn_o_simg = o; o += (size_t)h->nb * 6 * FP_IMG;
+                h->pn_o_bt = o;   o += (size_t)(pmp / 16) * FP_KS * 64;
+                h->pn_o_aimg = o; o += 5 * FP_IMG;
+                h->pn_o_vec = o;  o += V.total;
+                h->pn_o_ucon = o; o += 4 * (size_t)pmp;
+                h->pn_doubles = o;
+                if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));
+                if (fmpc_panel_prepare(plds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+                h->hm_Q2 = Q2; h->hm_Qf2 = Qf2;
+                h->hm_ql.assign(n, 0.0); if (q) h->hm_ql.assign(q, q + n);
+                h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
+                if (xf) h->hm_xf.assign(xf, xf + n);
+                h->pn_mp = pmp; h->pn_lds = plds; h->pn_enabled = 1;
+            }
         }
     }
     *out = h;
@@ -351,6 +387,9 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->sh_ok) (void)hipFree(h->sh_ok);
     if (h->sh_scratch) (void)hipFree(h->sh_scratch);
     if (h->cold_d) (void)hipFree(h->cold_d);
+    if (h->pn_pool) (void)hipFree(h->pn_pool);
+    if (h->pn_cnt) (void)hipFree(h->pn_cnt);
+    if (h->pn_sel) (void)hipFree(h->pn_sel);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -420,6 +459,167 @@ static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
                ? FMPC_OK : FMPC_E_HIP;
 }
 
+// Constants of the panel kernel for barrier weight k (fmpc_panel.h).  Reads back the shared factor the
+// export launch just produced, inverts the diagonal blocks and forms the products W = Linv U', V = Linv' U
+// in extended precision on the host (30 stages x 27^3: microseconds), and packs every matrix as an MFMA
+// A-operand image.  Called once per (handle, k); synchronises the stream.
+static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
+    typedef long double ld;
+    const int n = h->n, m = h->m, T = h->T, nb = h->nb, mp = h->pn_mp, LDG = 28, TS = n * LDG;
+    h->pn_valid = 0;
+    if (hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
+    int ok = 0;
+    if (hipMemcpy(&ok, h->sh_ok, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    if (!ok) return FMPC_OK;                                     // Y not PD at the start point: exact path reports it
+    std::vector<double> fac((size_t)nb * 6 * TS), rs((size_t)nb * 32);
+    if (hipMemcpy(fac.data(), h->sh_fac, fac.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(rs.data(), h->sh_rs, rs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    std::vector<double> pool(h->pn_doubles, 0.0);
+    auto image = [&](const std::vector<ld>& M, double sign, double* out) {      // M: n x n row-major
+        for (int I = 0; I < 2; ++I)
+            for (int ks = 0; ks < FP_KS; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
+                    out[(I * FP_KS + ks) * 64 + l] = (r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
+                }
+    };
+    const int nn = n * n;
+    std::vector<std::vector<ld>> Linv(nb, std::vector<ld>(nn, 0.0L));
+    auto U = [&](int i, int which, int r, int c) -> ld {          // which: 1 = U_{i,i+1}, 2 = U_{i,i+2}
+        return (ld)fac[((size_t)i * 6 + which) * TS + r * LDG + c];
+    };
+    for (int i = 0; i < nb; ++i) {
+        std::vector<ld> Lm(nn, 0.0L);
+        for (int r = 0; r < n; ++r) {
+            for (int j = 0; j < r; ++j) Lm[r * n + j] = (ld)fac[((size_t)i * 6 + 0) * TS + j * LDG + r];
+            Lm[r * n + r] = 1.0L / (ld)rs[(size_t)i * 32 + r];
+        }
+        std::vector<ld>& X = Linv[i];
+        for (int c = 0; c < n; ++c) {
+            X[c * n + c] = 1.0L / Lm[c * n + c];
+            for (int r = c + 1; r < n; ++r) {
+                ld sacc = 0.0L;
+                for (int q = c; q < r; ++q) sacc += Lm[r * n + q] * X[q * n + c];
+                X[r * n + c] = -sacc / Lm[r * n + r];
+            }
+        }
+    }
+    std::vector<ld> M(nn);
+    for (int i = 0; i < nb; ++i) {
+        double* dst = pool.data() + h->pn_o_simg + (size_t)i * 6 * FP_IMG;
+        const std::vector<ld>& X = Linv[i];
+        image(X, 1.0, dst + FP_SIMG_LINV * FP_IMG);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = X[c * n + r];
+        image(M, 1.0, dst + FP_SIMG_LINVT * FP_IMG);
+        for (int lag = 1; lag <= 2; ++lag) {
+            // W_lag,i = Linv_i U_{i-lag,i}'
+            std::fill(M.begin(), M.end(), 0.0L);
+            if (i - lag >= 0)
+                for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                    ld a = 0.0L;
+                    for (int q = 0; q <= r; ++q) a += X[r * n + q] * U(i - lag, lag, c, q);
+                    M[r * n + c] = a;
+                }
+            image(M, -1.0, dst + (lag == 1 ? FP_SIMG_W1 : FP_SIMG_W2) * FP_IMG);
+            // V_lag,i = Linv_i' U_{i,i+lag}
+            std::fill(M.begin(), M.end(), 0.0L);
+            if (i + lag < nb)
+                for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                    ld a = 0.0L;
+                    for (int q = r; q < n; ++q) a += X[q * n + r] * U(i, lag, q, c);
+                    M[r * n + c] = a;
+                }
+            image(M, -1.0, dst + (lag == 1 ? FP_SIMG_V1 : FP_SIMG_V2) * FP_IMG);
+        }
+    }
+    // ---- model images
+    const double* bt = h->hm_bt.data();                           // bt[c*n + r] = B[r][c]
+    {
+        double* dst = pool.data() + h->pn_o_bt;
+        for (int J = 0; J < mp / 16; ++J)
+            for (int ks = 0; ks < FP_KS; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int c = 16 * J + (l & 15), q = 4 * ks + (l >> 4);
+                    dst[(J * FP_KS + ks) * 64 + l] = (c < m && q < n) ? bt[(size_t)c * n + q] : 0.0;
+                }
+        double* a = pool.data() + h->pn_o_aimg;
+        std::vector<ld> A(nn);
+        for (int i = 0; i < nn; ++i) A[i] = h->hm_a1[i];
+        image(A, 1.0, a + FP_AIMG_A1 * FP_IMG);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = A[c * n + r];
+        image(M, 1.0, a + FP_AIMG_A1T * FP_IMG);
+        for (int i = 0; i < nn; ++i) A[i] = h->hm_a2[i];
+        image(A, 1.0, a + FP_AIMG_A2 * FP_IMG);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = A[c * n + r];
+        image(M, 1.0, a + FP_AIMG_A2T * FP_IMG);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+            ld t = 0.0L;
+            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + r] * (ld)bt[(size_t)j * n + c];
+            M[r * n + c] = t;
+        }
+        image(M, 1.0, a + FP_AIMG_BBT * FP_IMG);
+    }
+    // ---- vectors
+    const FpVec V = fp_vec_layout(nb, T);
+    double* vec = pool.data() + h->pn_o_vec;
+    double* uc = pool.data() + h->pn_o_ucon;
+    double sa_cu = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double sp = h->hm_umax[j] - h->hm_umid[j], sm = h->hm_umid[j] - h->hm_umin[j];
+        const double dp = 1.0 / sp, dm = 1.0 / sm;
+        const double hc = k * (dp * dp + dm * dm);
+        const double cu = h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] + k * (dp - dm);
+        uc[j] = cu; uc[mp + j] = 1.0 / (h->hm_R2[j] + hc); uc[2 * mp + j] = hc; uc[3 * mp + j] = h->hm_umid[j];
+        sa_cu += cu * cu;
+    }
+    std::vector<double> cbu(n), bu(n), a1x(n), a2x(n);
+    for (int a = 0; a < n; ++a) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < m; ++j) {
+            t0 += bt[(size_t)j * n + a] * uc[mp + j] * uc[j];
+            t1 += bt[(size_t)j * n + a] * h->hm_umid[j];
+            t2 += bt[(size_t)j * n + a] * uc[j];
+        }
+        cbu[a] = t0; bu[a] = t1; vec[V.bcu + a] = t2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < n; ++q) { s1 += h->hm_a1[a * n + q] * h->hm_xmid[q]; s2 += h->hm_a2[a * n + q] * h->hm_xmid[q]; }
+        a1x[a] = s1; a2x[a] = s2;
+    }
+    std::vector<double> phx((size_t)T * n);
+    double rd2_0 = T * sa_cu;
+    for (int j = 0; j < T; ++j)
+        for (int r = 0; r < n; ++r) {
+            const bool last = j + 1 == T;
+            const double q2 = last ? h->hm_Qf2[r] : h->hm_Q2[r];
+            const double d0 = q2 * h->hm_xmid[r] + (last ? h->hm_qfl[r] : h->hm_ql[r]);
+            vec[V.dx0 + j * 32 + r] = d0;
+            vec[V.iq + j * 32 + r] = 1.0 / q2;
+            phx[(size_t)j * n + r] = d0 / q2;
+            vec[V.xc + j * 32 + r] = h->hm_xmid[r] - d0 / q2;
+            rd2_0 += d0 * d0;
+        }
+    const bool var2 = h->var_order == 2;
+    for (int i = 0; i < nb; ++i)
+        for (int r = 0; r < n; ++r) {
+            double cp, c0;
+            if (i < T) {
+                cp = h->hm_xmid[r] - bu[r] - (i >= 1 ? a1x[r] : 0.0) - (i >= 2 ? a2x[r] : 0.0);
+                c0 = phx[(size_t)i * n + r] - cbu[r];
+                if (i >= 1) for (int q = 0; q < n; ++q) c0 -= h->hm_a1[r * n + q] * phx[(size_t)(i - 1) * n + q];
+                if (i >= 2 && var2) for (int q = 0; q < n; ++q) c0 -= h->hm_a2[r * n + q] * phx[(size_t)(i - 2) * n + q];
+            } else {
+                cp = h->hm_xmid[r] - h->hm_xf[r];
+                c0 = phx[(size_t)(T - 1) * n + r];
+            }
+            vec[V.cp + i * 32 + r] = cp;
+            vec[V.ct + i * 32 + r] = cp - c0;
+        }
+    h->pn_rd2_0 = rd2_0; h->pn_sa_cu = sa_cu;
+    if (hipMemcpy(h->pn_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    h->pn_valid = 1;
+    return FMPC_OK;
+}
+
 static int fmpc_grid_for(fmpc_handle h, int batch) {
     int cap = h->num_cu * h->wg_per_cu;
     return batch < cap ? batch : cap;
@@ -473,9 +673,38 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                                      h->wave_lds, (hipStream_t)stream, 2, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
                 if (e != hipSuccess) return FMPC_E_HIP;
                 if (fmpc_upload_cold(h, k, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
+                if (h->pn_enabled && fmpc_upload_panel(h, k, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
                 h->sh_valid = 1; h->sh_k = k;
             }
             mode = 1;
+        }
+        if (mode == 1 && h->pn_enabled && h->pn_valid && max_iter == 1) {
+            // the reference's own call (one Newton step from the cold start): 16-problem panels on the matrix
+            // cores; problems whose step-length / exit decision is not clear-cut go to the exact path below
+            if ((size_t)batch > h->pn_sel_cap) {
+                if (h->pn_sel) { (void)hipDeviceSynchronize(); (void)hipFree(h->pn_sel); h->pn_sel = nullptr; h->pn_sel_cap = 0; }
+                if (hipMalloc((void**)&h->pn_sel, (size_t)batch * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+                h->pn_sel_cap = batch;
+            }
+            FpParams Q;
+            Q.m = h->m; Q.mp = h->pn_mp; Q.T = h->T; Q.nb = h->nb; Q.has_xf = h->has_xf; Q.var2 = h->var_order == 2 ? 1 : 0;
+            Q.batch = batch; Q.npanels = (batch + FP_NP - 1) / FP_NP; Q.step_ld = fmpc_step_ld(n_newton);
+            Q.x0 = x0; Q.x0p = x0_pre; Q.w = w; Q.nu0 = nu0;
+            Q.zout = z_out; Q.nuout = nu_out; Q.status = status; Q.iters = iters; Q.step = step;
+            Q.simg = h->pn_pool + h->pn_o_simg; Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
+            Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
+            Q.rd2_0 = h->pn_rd2_0; Q.sa_cu = h->pn_sa_cu;
+            const int c = h->pn_parity;
+            Q.sel = h->pn_sel; Q.sel_count = h->pn_cnt + c;
+            const int pgrid = Q.npanels < h->num_cu ? Q.npanels : h->num_cu;
+            e = fmpc_launch_panel(Q, pgrid, h->pn_lds, (hipStream_t)stream);
+            if (e != hipSuccess) return FMPC_E_HIP;
+            e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                                 z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
+                                 h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                                 h->pn_sel, h->pn_cnt + c, h->pn_cnt + (1 - c));
+            h->pn_parity = 1 - c;
+            return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,

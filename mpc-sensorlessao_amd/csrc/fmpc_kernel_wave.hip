@@ -127,6 +127,9 @@ struct FwParams {
     double* ws; size_t ws_stride;
     double* sh_fac; double* sh_rs; int* sh_ok;     // shared (cold-start) factor owned by the handle
     const double* cold;                             // cold-start constants (FwCold layout), k-dependent
+    // optional selection: solve only problems sel[0 .. *sel_count-1] (those the panel kernel handed over);
+    // *sel_reset is zeroed for the next call (the two counters of the handle alternate)
+    const int* sel; const int* sel_count; int* sel_reset;
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -1394,6 +1397,10 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const FwKP P = fw_params();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int mp = P->V.mp;
+    const int* sel = P->sel;
+    const int batch = sel ? *P->sel_count : P->batch;
+    if (sel && blockIdx.x == 0 && threadIdx.x == 0 && P->sel_reset) *P->sel_reset = 0;
+    if (blockIdx.x * FW_WAVES >= batch) return;            // nothing selected for this workgroup
     for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
     {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
         double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
@@ -1408,7 +1415,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         const FwView<N> W(P, 0);
         for (int idx = lane; idx < W.T * mp; idx += 64) W.winv[idx] = 0.0;
     }
-    const int batch = P->batch, max_iter = P->max_iter;
+    const int max_iter = P->max_iter;
 #ifdef FW_TIMING
     unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define FW_KTICK(k) do { _k1 = __builtin_readcyclecounter(); _ka[k] += _k1 - _k0; _k0 = _k1; } while (0)
@@ -1420,8 +1427,9 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
     const int rounds = (batch + nwaves - 1) / nwaves;
     for (int rnd = 0; rnd < rounds; ++rnd) {
-        const int p = wave_g + rnd * nwaves;
-        const bool active = p < batch;
+        const int q = wave_g + rnd * nwaves;
+        const bool active = q < batch;
+        const int p = active && sel ? sel[q] : q;
         if (cold_mode) {
             // [cu | hc | wc | ubar] into LDS for the cold step's epilogue.  The region overlaps the per-wave
             // tiles of the general path, so wait until every wave has left the previous round.
@@ -1602,9 +1610,11 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* nu0, int max_iter, double kbar, double* zout, double* nuout,
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
-                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold) {
+                            int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
+                            const int* sel, const int* sel_count, int* sel_reset) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
+    P.sel = sel; P.sel_count = sel_count; P.sel_reset = sel_reset;
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;
