@@ -149,6 +149,19 @@ int fmpc_solve_once(int n, int m, int T, int var_order,
                     const double* nu0, int nw, double k, int device,
                     double* x_opt, int* iters);
 
+/*
+ * Diagnostic (no counterpart in the reference): which device path the last fmpc_solve[_device] call of
+ * this handle took, and how many problems the panel kernel handed to the exact per-problem path because
+ * their step-length / exit decision was not clear-cut.  Synchronises the device.
+ *   path  0 generic kernel, 1 wave kernel (per-problem factor), 2 wave kernel (shared cold-start factor),
+ *         3 panel kernel (+ exact path for `handed_over` problems).
+ */
+#define FMPC_PATH_GENERIC 0
+#define FMPC_PATH_WAVE    1
+#define FMPC_PATH_SHARED  2
+#define FMPC_PATH_PANEL   3
+int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ SIGNATURES = {
     "fmpc_unpack": (C.c_int, [_vp, C.c_int] + [_vp] * 4),
     "fmpc_unpack_device": (C.c_int, [_vp, C.c_int] + [_vp] * 4 + [_vp]),
     "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
+    "fmpc_last_dispatch": (C.c_int, [_vp, _ip, _ip]),
 }
 
 _lib = None

@@ -66,9 +66,10 @@ struct fmpc_handle_s {
     double* cold_d;                      // cold-start constants on the device (FwCold layout)
     // panel kernel (fmpc_kernel_panel.hip): the cold-start step on 16-problem panels, n_newton = 1
     int pn_enabled, pn_valid, pn_mp, pn_parity;
+    int last_path;
     size_t pn_lds;
     double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
-    size_t pn_o_simg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_doubles;
+    size_t pn_o_simg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
     int* pn_cnt;                         // two alternating selection counters
     int* pn_sel; size_t pn_sel_cap;
     double pn_rd2_0, pn_sa_cu;
@@ -164,7 +165,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
-    h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_parity = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->last_path = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_parity = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->pn_cnt = nullptr; h->pn_sel = nullptr; h->pn_sel_cap = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -353,12 +354,13 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             if (n == FP_N && !(nopn && nopn[0] == '1') && plds <= FMPC_LDS_LIMIT) {
                 const FpVec V = fp_vec_layout(h->nb, T);
                 size_t o = 0;
-                h->pn_o_simg = o; o += (size_t)h->nb * 6 * FP_IMG;
+                h->pn_o_simg = o; o += (size_t)(h->nb + 1) * 6 * FP_IMG;
                 h->pn_o_bt = o;   o += (size_t)(pmp / 16) * FP_KS * 64;
                 h->pn_o_aimg = o; o += 5 * FP_IMG;
                 h->pn_o_vec = o;  o += V.total;
                 h->pn_o_ucon = o; o += 4 * (size_t)pmp;
                 h->pn_doubles = o;
+                h->pn_o_dump = o; o += (size_t)T * (n + m) + (size_t)h->nb * n;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));
@@ -475,11 +477,12 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
     if (hipMemcpy(fac.data(), h->sh_fac, fac.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(rs.data(), h->sh_rs, rs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
     std::vector<double> pool(h->pn_doubles, 0.0);
-    auto image = [&](const std::vector<ld>& M, double sign, double* out) {      // M: n x n row-major
+    auto image = [&](const std::vector<ld>& M, double sign, double* out, bool perm = false) {      // M: n x n row-major
         for (int I = 0; I < 2; ++I)
             for (int ks = 0; ks < FP_KS; ++ks)
                 for (int l = 0; l < 64; ++l) {
-                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
+                    const int i = l & 15;
+                    const int r = 16 * I + (perm ? 4 * (i & 3) + (i >> 2) : i), c = 4 * ks + (l >> 4);
                     out[(I * FP_KS + ks) * 64 + l] = (r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
                 }
     };
@@ -693,7 +696,7 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             Q.zout = z_out; Q.nuout = nu_out; Q.status = status; Q.iters = iters; Q.step = step;
             Q.simg = h->pn_pool + h->pn_o_simg; Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
             Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
-            Q.rd2_0 = h->pn_rd2_0; Q.sa_cu = h->pn_sa_cu;
+            Q.rd2_0 = h->pn_rd2_0; Q.sa_cu = h->pn_sa_cu; Q.dump = h->pn_pool + h->pn_o_dump; { const char* d = getenv("FMPC_PANEL_DBG"); Q.dbg = d ? atoi(d) : 0; }
             const int c = h->pn_parity;
             Q.sel = h->pn_sel; Q.sel_count = h->pn_cnt + c;
             const int pgrid = Q.npanels < h->num_cu ? Q.npanels : h->num_cu;
@@ -704,12 +707,15 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                                  h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
                                  h->pn_sel, h->pn_cnt + c, h->pn_cnt + (1 - c));
             h->pn_parity = 1 - c;
+            h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                              h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
+        h->last_path = mode == 1 ? FMPC_PATH_SHARED : FMPC_PATH_WAVE;
     } else {
+        h->last_path = FMPC_PATH_GENERIC;
         const int grid = fmpc_grid_for(h, batch);
         size_t stride = 0;
         int rc = fmpc_ensure_ws(h, h->num_cu * h->wg_per_cu, &stride);   // full size once: no regrowth
@@ -719,6 +725,22 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                                 h->ws, stride, (hipStream_t)stream);
     }
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {
+    if (!h) return FMPC_E_NULL;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (path) *path = h->last_path;
+    if (handed_over) {
+        *handed_over = 0;
+        if (h->last_path == FMPC_PATH_PANEL) {
+            if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
+            // the counter of the last call is the one the NEXT call's exact-path launch will reset
+            if (hipMemcpy(handed_over, h->pn_cnt + (1 - h->pn_parity), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        }
+    }
+    return FMPC_OK;
 }
 
 extern "C" int fmpc_solve(fmpc_handle h, int batch,

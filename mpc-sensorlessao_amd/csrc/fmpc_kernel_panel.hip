@@ -35,7 +35,7 @@
 
 #define FP_WAVES 8
 #define FP_THREADS (FP_WAVES * 64)
-#define FP_FN __device__ __noinline__
+#define FP_FN __device__ __forceinline__
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -61,15 +61,17 @@ __device__ __forceinline__ FpKP fp_uniform(FpKP P) {          // see fw_uniform 
 
 // LDS map (doubles)
 struct FpLds {
-    int Y, BT, A1T, A2T, UC, RED, FLAG, total;
+    int Y, BT, A1T, A2T, UC, XQ, RED, FLAG, total;
 };
 __host__ __device__ static inline FpLds fp_lds_layout(int nb, int mp) {
     FpLds L; int o = 0;
-    L.Y = o;   o += (nb * FP_N + 1) * FP_NP;  o = (o + 63) & ~63;
+    L.Y = o;   o += (nb * FP_N + 1) * FP_NP;
     L.BT = o;  o += (mp / 16) * FP_KS * 64;
     L.A1T = o; o += FP_IMG;
     L.A2T = o; o += FP_IMG;
+    o = (o + 1) & ~1;
     L.UC = o;  o += 4 * mp;
+    L.XQ = o;  o += 4 * 32;                         // [xc | xc(last stage) | iq | iq(last stage)]
     L.RED = o; o += 3 * FP_WAVES * FP_NP;          // per wave and problem: ||r_p||^2, ||e||^2, ||r_d||^2 (+ guard)
     o += FP_WAVES * FP_NP;
     L.FLAG = o; o += 2;
@@ -123,41 +125,64 @@ __device__ __forceinline__ double fp_sum_g(double v) {         // sum over the 4
 }
 
 // ------------------------------------------------------------------------------------------------
-// S1: rhs_i = ct_i - b_i, r~_i = Linv_i rhs_i -> panel;  ||r_p||^2 per problem
+// S1: rhs_i = ct_i - b_i, r~_i = Linv_i rhs_i -> panel;  ||r_p||^2 per problem.
+// The global operands of the next stage are loaded (unconditionally, index clamped) before the current
+// one is processed: the waits in front of the MFMAs then leave those loads in flight.
+struct FpS1 { double w[8], ct[8], cp[8], img[2][FP_KS]; };
 FP_FN void fp_s1(FpKP Pin, double* lds_g, int panel) {
     const FpKP P = fp_uniform(Pin);
     panel = __builtin_amdgcn_readfirstlane(panel);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int T = P->T, nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_lds_t Y = (fp_lds_t)lds_g + L.Y;
     const fp_lds_t red = (fp_lds_t)lds_g + L.RED;
     const int p = panel * FP_NP + c16;
     const size_t pc = p < batch ? p : batch - 1;
-    const double* w = P->w;
+    const double* w = P->w ? P->w + pc * (size_t)T * FP_N : nullptr;
     const double* x0 = P->x0 + pc * FP_N;
     const double* x0p = P->x0p ? P->x0p + pc * FP_N : nullptr;
     const FpVec V = fp_vec_layout(nb, T);
     const double* ct = P->vec + V.ct;
     const double* cp = P->vec + V.cp;
+    const double* simg = P->simg + FP_SIMG_LINV * FP_IMG + lane;
     const bool var2 = P->var2 != 0;
+    int rowc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int row = 16 * (e >> 2) + 4 * (e & 3) + g; rowc[e] = row < FP_N ? row : 0; }
+    auto ld = [&](int i, FpS1& d) {
+        const int ic = i < nb ? i : nb - 1;
+        const int iw = ic < T ? ic : T - 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            d.w[e] = w ? w[iw * FP_N + rowc[e]] : 0.0;
+            d.ct[e] = ct[ic * 32 + rowc[e]];
+            d.cp[e] = cp[ic * 32 + rowc[e]];
+        }
+        const double* im = simg + (size_t)ic * 6 * FP_IMG;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) d.img[I][ks] = im[(I * FP_KS + ks) * 64];
+    };
+    double xv[FP_KS], xp[FP_KS];               // x0, x0_pre in B-operand layout (used by stages 0 and 1)
+#pragma unroll
+    for (int ks = 0; ks < FP_KS; ++ks) {
+        const int k = 4 * ks + g;
+        const double t0 = x0[k < FP_N ? k : 0];
+        const double t1 = x0p ? x0p[k < FP_N ? k : 0] : 0.0;
+        xv[ks] = k < FP_N ? t0 : 0.0; xp[ks] = k < FP_N ? t1 : 0.0;
+    }
     double rp2 = 0.0;
-    for (int i = wv; i < nb; i += FP_WAVES) {
+    auto comp = [&](int i, const FpS1& d) {
+        if (i >= nb) return;
         d4 bx[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if (i == 0 || (i == 1 && var2)) {                 // the prediction A1 x0 + A2 x0_pre enters b_0, b_1
-            double xv[FP_KS], xp[FP_KS];
-#pragma unroll
-            for (int ks = 0; ks < FP_KS; ++ks) {
-                const int k = 4 * ks + g;
-                const double t0 = x0[k < FP_N ? k : 0];
-                const double t1 = x0p ? x0p[k < FP_N ? k : 0] : 0.0;
-                xv[ks] = k < FP_N ? t0 : 0.0; xp[ks] = k < FP_N ? t1 : 0.0;
-            }
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 if (i == 0) {
                     bx[I] = fp_mm_g(P->aimg + FP_AIMG_A1 * FP_IMG, I, lane, xv, bx[I]);
-                    if (var2 && x0p) bx[I] = fp_mm_g(P->aimg + FP_AIMG_A2 * FP_IMG, I, lane, xp, bx[I]);
+                    if (var2) bx[I] = fp_mm_g(P->aimg + FP_AIMG_A2 * FP_IMG, I, lane, xp, bx[I]);
                 } else {
                     bx[I] = fp_mm_g(P->aimg + FP_AIMG_A2 * FP_IMG, I, lane, xv, bx[I]);
                 }
@@ -165,24 +190,28 @@ FP_FN void fp_s1(FpKP Pin, double* lds_g, int panel) {
         }
         double v[8];
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + 4 * r + g;
-                const bool rok = row < FP_N;
-                const int rc = rok ? row : 0;
-                const double wi = (i < T && w) ? w[pc * T * FP_N + i * FP_N + rc] : 0.0;
-                const double b = wi + bx[I][r];
-                const double rp = cp[i * 32 + rc] - b;
-                if (rok) rp2 += rp * rp;
-                v[4 * I + r] = rok ? ct[i * 32 + rc] - b : 0.0;
-            }
-        const double* img = P->simg + ((size_t)i * 6 + FP_SIMG_LINV) * FP_IMG;
+        for (int e = 0; e < 8; ++e) {
+            const bool rok = 16 * (e >> 2) + 4 * (e & 3) + g < FP_N;
+            const double b = (i < T ? d.w[e] : 0.0) + bx[e >> 2][e & 3];
+            const double rp = d.cp[e] - b;
+            if (rok) rp2 += rp * rp;
+            v[e] = rok ? d.ct[e] - b : 0.0;
+        }
 #pragma unroll
         for (int I = 0; I < 2; ++I) {
-            const d4 o = fp_mm_g(img, I, lane, v, (d4){0, 0, 0, 0});
+            d4 o = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) o = MFMA64(d.img[I][ks], v[ks], o);
             fp_store_d(Y, i, I, g, c16, o);
         }
+    };
+    FpS1 A, B;
+    ld(wv, A);
+    for (int i = wv; i < nb; i += 2 * FP_WAVES) {
+        ld(i + FP_WAVES, B);
+        comp(i, A);
+        ld(i + 2 * FP_WAVES, A);
+        comp(i + FP_WAVES, B);
     }
     rp2 = fp_sum_g(rp2);
     if (g == 0) red[wv * FP_NP + c16] = rp2;
@@ -192,165 +221,236 @@ FP_FN void fp_s1(FpKP Pin, double* lds_g, int panel) {
 // S2 / S4: the serial sweeps.  Wave q < 4: row block I = q & 1, term = q >> 1.
 //   forward  (BWD = 0): step s = 1..nb-1:  term 0: Y[s]   += -W1_s   Y[s-1] ;  term 1: Y[s+1] += -W2_{s+1} Y[s-1]
 //   backward (BWD = 1): step s = nb-2..0:  term 0: Y[s]   += -V1_s   Y[s+1] ;  term 1: Y[s-1] += -V2_{s-1} Y[s+1]
-// Every wave of the workgroup calls this (barriers).  Images are prefetched two steps ahead.
+// One barrier per step; every wave of the workgroup calls this.  The worker loop is branch-free (the
+// compiler's s_waitcnt placement gives up on conditional loads): the images are prefetched two steps ahead
+// into three rotating register sets, and steps without a target (the ends of the lag-2 chains, padding of the
+// step count to a multiple of 3) add a ZERO image (stage slot nb) into a stage nobody else updates.
 template <int BWD>
 FP_FN void fp_sweep(FpKP Pin, double* lds_g) {
     const FpKP P = fp_uniform(Pin);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb;
+    const int nsteps = nb - 1, nsteps3 = (nsteps + 2) / 3 * 3;
+    if (wv >= 4) {
+        for (int q = 0; q < nsteps3; ++q) __syncthreads();
+        return;
+    }
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_lds_t Y = (fp_lds_t)lds_g + L.Y;
-    const bool worker = wv < 4;
-    const int I = wv & 1, term = (wv >> 1) & 1;
+    const int I = wv & 1, term = wv >> 1;
     const double* simg = P->simg + (size_t)((BWD ? FP_SIMG_V1 : FP_SIMG_W1) + term) * FP_IMG + (size_t)I * FP_KS * 64 + lane;
-    const int nsteps = nb - 1;
-    // step q = 0..nsteps-1 -> s;  target stage and source stage of this wave
-    auto target = [&](int q) { const int s = BWD ? nb - 2 - q : 1 + q; return BWD ? s - term : s + term; };
-    auto source = [&](int q) { const int s = BWD ? nb - 2 - q : 1 + q; return BWD ? s + 1 : s - 1; };
+    const int dummy = BWD ? nb - 1 : 0;
+    auto target = [&](int q) {
+        const int s = BWD ? nb - 2 - q : 1 + q;
+        const int t = BWD ? s - term : s + term;
+        return (q < nsteps && t >= 0 && t < nb) ? t : -1;
+    };
     auto load_img = [&](int q, double a[FP_KS]) {
-        int t = q < nsteps ? target(q) : 0;
-        if (t < 0 || t >= nb) t = 0;
-        const double* s = simg + (size_t)t * 6 * FP_IMG;
+        const int t = target(q);
+        const double* s = simg + (size_t)(t < 0 ? nb : t) * 6 * FP_IMG;
 #pragma unroll
         for (int ks = 0; ks < FP_KS; ++ks) a[ks] = s[ks * 64];
     };
     auto step = [&](int q, const double a[FP_KS]) {
-        if (q < nsteps) {
-            const int t = target(q);
-            if (worker && t >= 0 && t < nb) {
-                double v[FP_KS];
-                fp_load_b(Y, source(q), g, c16, v);
-                d4 acc = fp_load_d(Y, t, I, g, c16);
+        const int t0 = target(q);
+        const int t = t0 < 0 ? dummy : t0;
+        const int s = BWD ? nb - 2 - q : 1 + q;
+        const int src = t0 < 0 ? dummy : (BWD ? s + 1 : s - 1);
+        double v[FP_KS];
+        fp_load_b(Y, src, g, c16, v);
+        d4 acc = fp_load_d(Y, t, I, g, c16);
 #pragma unroll
-                for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(a[ks], v[ks], acc);
-                fp_store_d(Y, t, I, g, c16, acc);
-            }
-            __syncthreads();
-        }
+        for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(a[ks], v[ks], acc);
+        fp_store_d(Y, t, I, g, c16, acc);
+        __syncthreads();
     };
     double a0[FP_KS], a1[FP_KS], a2[FP_KS];
-    if (worker) { load_img(0, a0); load_img(1, a1); }
-    for (int q = 0; q < nsteps; q += 3) {
-        if (worker) load_img(q + 2, a2);
+    load_img(0, a0); load_img(1, a1);
+    for (int q = 0; q < nsteps3; q += 3) {
+        load_img(q + 2, a2);
         step(q, a0);
-        if (worker) load_img(q + 3, a0);
+        load_img(q + 3, a0);
         step(q + 1, a1);
-        if (worker) load_img(q + 4, a1);
+        load_img(q + 4, a1);
         step(q + 2, a2);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3: y~_i = Linv_i' y_i   (stage-parallel, in place)
+// S3: y~_i = Linv_i' y_i   (stage-parallel, in place; next stage's image prefetched)
 FP_FN void fp_s3(FpKP Pin, double* lds_g) {
     const FpKP P = fp_uniform(Pin);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb;
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_lds_t Y = (fp_lds_t)lds_g + L.Y;
-    for (int i = wv; i < nb; i += FP_WAVES) {
+    const double* simg = P->simg + FP_SIMG_LINVT * FP_IMG + lane;
+    auto ld = [&](int i, double a[2][FP_KS]) {
+        const double* im = simg + (size_t)(i < nb ? i : nb - 1) * 6 * FP_IMG;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) a[I][ks] = im[(I * FP_KS + ks) * 64];
+    };
+    auto comp = [&](int i, const double a[2][FP_KS]) {
+        if (i >= nb) return;
         double v[FP_KS];
         fp_load_b(Y, i, g, c16, v);
-        const double* img = P->simg + ((size_t)i * 6 + FP_SIMG_LINVT) * FP_IMG;
-        const d4 o0 = fp_mm_g(img, 0, lane, v, (d4){0, 0, 0, 0});
-        const d4 o1 = fp_mm_g(img, 1, lane, v, (d4){0, 0, 0, 0});
+        d4 o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < FP_KS; ++ks) { o0 = MFMA64(a[0][ks], v[ks], o0); o1 = MFMA64(a[1][ks], v[ks], o1); }
         fp_store_d(Y, i, 0, g, c16, o0);
         fp_store_d(Y, i, 1, g, c16, o1);
+    };
+    double A[2][FP_KS], B[2][FP_KS];
+    ld(wv, A);
+    for (int i = wv; i < nb; i += 2 * FP_WAVES) {
+        ld(i + FP_WAVES, B);
+        comp(i, A);
+        ld(i + 2 * FP_WAVES, A);
+        comp(i + FP_WAVES, B);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// S5: d_z from nu+ (panel), z = zbar + d_z and nu = nu+ written out, ||e||^2 per problem
+// S5: d_z from nu+ (panel), z = zbar + d_z and nu = nu+ written out, ||e||^2 per problem.
+// The products of this phase are only consumed element-wise, so they are computed TRANSPOSED: the nu+ panel
+// registers (B-operand layout) are also a valid A operand with the problems as rows, and the unpermuted
+// images of B', A1', A2' serve as B operands with the entries as columns.  Result register r of lane
+// (g, c) is then (problem 4 r + g, entry 16 J + c): each store instruction writes, for 4 problems, 16
+// consecutive entries (128 contiguous bytes) and the per-entry constants are one LDS read per lane.
+// No global LOAD in this phase (a load behind a store waits for the store: vmcnt is in order); lanes of
+// problems beyond the batch write to the dump area instead of being predicated.
+template <int HAS_NU>
 FP_FN void fp_s5(FpKP Pin, double* lds_g, int panel) {
     const FpKP P = fp_uniform(Pin);
     panel = __builtin_amdgcn_readfirstlane(panel);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int T = P->T, nb = P->nb, batch = P->batch, m = P->m, mp = P->mp, s = FP_N + m;
     const FpLds L = fp_lds_layout(nb, mp);
     const fp_clds_t Y = (fp_clds_t)lds_g + L.Y;
-    const fp_clds_t BT = (fp_clds_t)lds_g + L.BT;
-    const fp_clds_t A1T = (fp_clds_t)lds_g + L.A1T;
-    const fp_clds_t A2T = (fp_clds_t)lds_g + L.A2T;
-    const fp_clds_t UC = (fp_clds_t)lds_g + L.UC;           // [cu | wc | hc | ubar]
+    const fp_clds_t BT = (fp_clds_t)lds_g + L.BT + lane;
+    const fp_clds_t A1T = (fp_clds_t)lds_g + L.A1T + lane;
+    const fp_clds_t A2T = (fp_clds_t)lds_g + L.A2T + lane;
+    const fp_clds_t UC = (fp_clds_t)lds_g + L.UC + c16;     // [c1 | wc | hc | ubar], c1 = -wc cu
+    const fp_clds_t XQ = (fp_clds_t)lds_g + L.XQ;
     const fp_lds_t red = (fp_lds_t)lds_g + L.RED + FP_WAVES * FP_NP;
-    const int p = panel * FP_NP + c16;
-    const bool valid = p < batch;
-    const size_t pc = valid ? p : batch - 1;
-    double* zp = P->zout + pc * (size_t)T * s;
-    double* nup = P->nuout ? P->nuout + pc * (size_t)nb * FP_N : nullptr;
-    const FpVec V = fp_vec_layout(nb, T);
-    const double* xc = P->vec + V.xc;
-    const double* iq = P->vec + V.iq;
+    double* zq[4]; double* nq[4];                           // problem 4 r + g of the panel
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = panel * FP_NP + 4 * r + g;
+        zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + c16;
+        nq[r] = HAS_NU ? (p < batch ? P->nuout + (size_t)p * nb * FP_N : P->dump + (size_t)T * s) + c16 : nullptr;
+    }
     const bool has_xf = P->has_xf != 0, var2 = P->var2 != 0;
-    const int NJ = mp / 16;
-    double eps2 = 0.0;
+    const int NJ = mp / 16, NJF = m / 16;                   // column blocks, full column blocks
+    double eps2[4] = {0.0, 0.0, 0.0, 0.0};
     for (int j = wv; j < T; j += FP_WAVES) {
         double v0[FP_KS], v1[FP_KS], v2[FP_KS];
         fp_load_b(Y, j, g, c16, v0);
         const bool h1 = j + 1 < T, h2 = j + 2 < T && var2;
         fp_load_b(Y, h1 ? j + 1 : j, g, c16, v1);
         fp_load_b(Y, h2 ? j + 2 : j, g, c16, v2);
-        if (!h1) {
 #pragma unroll
-            for (int ks = 0; ks < FP_KS; ++ks) v1[ks] = 0.0;
-        }
-        if (!h2) {
-#pragma unroll
-            for (int ks = 0; ks < FP_KS; ++ks) v2[ks] = 0.0;
-        }
+        for (int ks = 0; ks < FP_KS; ++ks) { v1[ks] = h1 ? v1[ks] : 0.0; v2[ks] = h2 ? v2[ks] : 0.0; }
         const bool last = j + 1 == T;
-        // ---- u entries
-        double* zu = zp + (size_t)j * s;
-        for (int J = 0; J < NJ; ++J) {
-            const d4 acc = fp_mm_l(BT + J * FP_KS * 64, 0, lane, v0, (d4){0, 0, 0, 0});
+        const size_t zoff = (size_t)j * s;
+        // ---- u entries: d_u = wc o (B' nu+_j - cu)
+        auto mm = [&](int J) {
+            d4 acc = {0, 0, 0, 0};
+            const fp_clds_t im = BT + J * FP_KS * 64;
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(v0[ks], im[ks * 64], acc);
+            return acc;
+        };
+        auto epi = [&](int J, d4 acc) {
+            const fp_clds_t uc = UC + 16 * J;
+            const double c1 = uc[0], wc = uc[mp], hc = uc[2 * mp], ub = uc[3 * mp];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = 16 * J + 4 * r + g;
-                const double du = UC[mp + c] * (acc[r] - UC[c]);
-                const double e = UC[2 * mp + c] * du;
-                if (c < m) {
-                    eps2 += e * e;
-                    if (valid) zu[c] = UC[3 * mp + c] + du;
-                }
+                const double du = fma(wc, acc[r], c1);
+                const double e = hc * du;
+                eps2[r] = fma(e, e, eps2[r]);
+                zq[r][zoff + 16 * J] = ub + du;
+            }
+        };
+        if (NJF > 0) {
+            d4 a0 = mm(0);
+            int J = 0;
+            for (; J + 2 < NJF; J += 2) {
+                const d4 a1 = mm(J + 1);
+                epi(J, a0);
+                a0 = mm(J + 2);
+                epi(J + 1, a1);
+            }
+            if (J + 1 < NJF) {
+                const d4 a1 = mm(J + 1);
+                epi(J, a0);
+                epi(J + 1, a1);
+            } else {
+                epi(J, a0);
             }
         }
-        // ---- x entries
-        d4 xf4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        if (last && has_xf) { xf4[0] = fp_load_d(Y, T, 0, g, c16); xf4[1] = fp_load_d(Y, T, 1, g, c16); }
-#pragma unroll
-        for (int I = 0; I < 2; ++I) {
-            d4 h = fp_mm_l(A1T, I, lane, v1, (d4){0, 0, 0, 0});
-            h = fp_mm_l(A2T, I, lane, v2, h);
+        if (NJF < NJ) {                                   // partial last column block (m not a multiple of 16)
+            const d4 acc = mm(NJF);
+            const fp_clds_t uc = UC + 16 * NJF;
+            const bool cok = 16 * NJF + c16 < m;
+            const double c1 = uc[0], wc = uc[mp], hc = uc[2 * mp], ub = uc[3 * mp];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * I + 4 * r + g;
-                const bool rok = row < FP_N;
-                const int rc = rok ? row : 0;
-                const double nuj = v0[4 * I + r];
-                const double val = h[r] - nuj - xf4[I][r];
-                if (rok && valid) {
-                    zu[m + row] = xc[j * 32 + rc] + iq[j * 32 + rc] * val;
-                    if (nup) {
-                        nup[j * FP_N + row] = nuj;
-                        if (last && has_xf) nup[T * FP_N + row] = xf4[I][r];
+                const double du = fma(wc, acc[r], c1);
+                const double e = hc * du;
+                if (cok) { eps2[r] = fma(e, e, eps2[r]); zq[r][zoff + 16 * NJF] = ub + du; }
+            }
+        }
+        // ---- x entries: d_x = (2Q)^-1 (-dx0 - nu+_j + A1' nu+_{j+1} + A2' nu+_{j+2} [- nu+_T])
+        const fp_clds_t xcv = XQ + (last ? 32 : 0), iqv = XQ + 64 + (last ? 32 : 0);
+        const bool xfl = last && has_xf;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            d4 h = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) h = MFMA64(v1[ks], A1T[(I * FP_KS + ks) * 64], h);
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) h = MFMA64(v2[ks], A2T[(I * FP_KS + ks) * 64], h);
+            const int row = 16 * I + c16;
+            const bool rok = row < FP_N;
+            const int rc = rok ? row : 0;
+            const double xc = xcv[rc], iq = iqv[rc];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double nj = Y[(j * FP_N + rc) * FP_NP + 4 * r + g];
+                const double t = Y[((xfl ? T : j) * FP_N + rc) * FP_NP + 4 * r + g];
+                const double nx = xfl ? t : 0.0;
+                const double zx = xc + iq * (h[r] - nj - nx);
+                if (rok) {                                 // rows 27..31 of the second row block do not exist
+                    zq[r][zoff + m + 16 * I] = zx;
+                    if (HAS_NU) {
+                        nq[r][j * FP_N + 16 * I] = nj;
+                        if (xfl) nq[r][T * FP_N + 16 * I] = nx;
                     }
                 }
             }
         }
     }
-    eps2 = fp_sum_g(eps2);
-    if (g == 0) red[wv * FP_NP + c16] = eps2;
+    // per problem: sum over the 16 entry lanes; lane (g, 0) then holds problems 4 r + g
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = eps2[r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (c16 == 0) red[wv * FP_NP + 4 * r + g] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // S6 (only when the cheap acceptance test fails somewhere in the panel and nu0 is given):
 // ||r_d(nu0)||^2 per problem.  x entries element-wise; u entries as a 27-dimensional quadratic form
 //   sum_j |cu - B' nu_j|^2 = T |cu|^2 - 2 (B cu)' sum_j nu_j + sum_j nu_j' (B B') nu_j
-// red3 = ||r_d||^2, red4 = its positive part (cancellation guard of the quadratic form).
+// red3 = ||r_d||^2 - T |cu|^2, red4 = the positive part of the quadratic form (cancellation guard).
 FP_FN void fp_s6(FpKP Pin, double* lds_g, int panel) {
     const FpKP P = fp_uniform(Pin);
     panel = __builtin_amdgcn_readfirstlane(panel);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int T = P->T, nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_clds_t A1T = (fp_clds_t)lds_g + L.A1T;
@@ -393,10 +493,9 @@ FP_FN void fp_s6(FpKP Pin, double* lds_g, int panel) {
                 const double nuj = v0[4 * I + r];
                 const double x = dx0[j * 32 + rc] + nuj - h[r] + vx[4 * I + r];
                 if (rok) {
-                    rd2 += x * x;
                     const double qf = nuj * qd[r];
                     pos += qf;
-                    rd2 += qf - 2.0 * bcu[rc] * nuj;
+                    rd2 += x * x + (qf - 2.0 * bcu[rc] * nuj);
                 }
             }
         }
@@ -420,7 +519,13 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
         lds[L.A1T + i] = P->aimg[FP_AIMG_A1T * FP_IMG + i];
         lds[L.A2T + i] = P->aimg[FP_AIMG_A2T * FP_IMG + i];
     }
-    for (int i = tid; i < 4 * mp; i += FP_THREADS) lds[L.UC + i] = P->ucon[i];
+    for (int i = tid; i < 4 * mp; i += FP_THREADS)               // [c1 | wc | hc | ubar], c1 = -wc cu
+        lds[L.UC + i] = i < mp ? -P->ucon[mp + i] * P->ucon[i] : P->ucon[i];
+    if (tid < 128) {
+        const FpVec V = fp_vec_layout(nb, P->T);
+        const int a = tid >> 5, r = tid & 31;                       // xc, xc(last), iq, iq(last)
+        lds[L.XQ + tid] = P->vec[(a < 2 ? V.xc : V.iq) + ((a & 1) ? P->T - 1 : 0) * 32 + r];
+    }
     __syncthreads();
 #ifdef FW_TIMING
     unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -441,7 +546,7 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
         FP_TICK(2);
         fp_sweep<1>(P, lds);
         FP_TICK(3);
-        fp_s5(P, lds, panel);
+        if (P->nuout) fp_s5<1>(P, lds, panel); else fp_s5<0>(P, lds, panel);
         __syncthreads();
         FP_TICK(4);
         // ---- acceptance: threads 0..15, one problem each

@@ -9,7 +9,10 @@
 #define FP_KS 7                         // k-steps of 4 covering 27 (28) entries
 #define FP_IMG (2 * FP_KS * 64)         // doubles per A-operand image of a 27 x 27 matrix
 // A-operand image of a matrix M (rows x 27): element [(I*7 + ks)*64 + l] = M[16 I + (l & 15)][4 ks + (l >> 4)],
-// zero outside the matrix: one coalesced 512-byte load per MFMA operand.
+// zero outside the matrix: one coalesced 512-byte load per MFMA operand.  The result register r of lane group
+// g = l >> 4 then holds row 16 I + 4 r + g, which is the B-operand layout of the next product.
+// The same image is a valid B operand of the TRANSPOSED product (panel registers as A operand, problems as
+// rows): lane (g, c) then holds M'[4 ks + g][16 I + c].
 
 // per-stage sweep images, [stage][6][FP_IMG]
 #define FP_SIMG_LINV 0                  //  Linv_i
@@ -44,7 +47,7 @@ struct FpParams {
     int batch, npanels, step_ld;
     const double* x0; const double* x0p; const double* w; const double* nu0;
     double* zout; double* nuout; int* status; int* iters; double* step;
-    const double* simg;                 // sweep images (k-dependent)
+    const double* simg;                 // sweep images (k-dependent), nb + 1 stage slots, the last all zero
     const double* btimg;                // B' images, [mp/16][7][64]
     const double* aimg;                 // model images
     const double* vec;                  // FpVec
@@ -52,6 +55,8 @@ struct FpParams {
     double rd2_0;                       // ||r_d||^2 at nu = 0
     double sa_cu;                       // |cu|^2
     int* sel; int* sel_count;           // problems handed to the exact path
+    int dbg;
+    double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
 };
 
 size_t fmpc_panel_lds_bytes(int nb, int mp);

@@ -129,6 +129,14 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_unpack")
         return (U[0], X[0], u0[0]) if single else (U, X, u0)
 
+    def last_dispatch(self):
+        """(path, handed_over) of the last solve: see fmpc_last_dispatch in include/fastmpc.h."""
+        path = C.c_int(); cnt = C.c_int()
+        rc = self._lib.fmpc_last_dispatch(self._h, C.byref(path), C.byref(cnt))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_last_dispatch")
+        return path.value, cnt.value
+
     # ------------------------------------------------------------------ device tensors
     def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
                      z_out=None, nu_out=None, status=None, iters=None, step=None):

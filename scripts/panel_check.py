@@ -29,6 +29,7 @@ def run(xf, use_w, use_nu, batch, k, T=30, tight=False, seed=5):
     finally:
         del os.environ["FMPC_NO_PANEL"]
     zp, ip = hp.solve(data["x0"], data["x0_pre"], data.get("w"), nu0=data["nu0"], n_newton=1, k=k, return_info=True, check=False)
+    disp = hp.last_dispatch()
     zw, iw = hw.solve(data["x0"], data["x0_pre"], data.get("w"), nu0=data["nu0"], n_newton=1, k=k, return_info=True, check=False)
     nb = min(batch, 12)
     sub = {kk: (None if v is None else v[:nb]) for kk, v in data.items() if kk in ("x0", "x0_pre", "w", "nu0")}
@@ -42,7 +43,7 @@ def run(xf, use_w, use_nu, batch, k, T=30, tight=False, seed=5):
             and np.array_equal(ip["step"], iw["step"]))
     print(f"xf={xf} w={use_w} nu={use_nu} B={batch} k={k} T={T} tight={tight}: panel-vs-wave z {ez:.2e} nu {en:.2e} | "
           f"panel-vs-oracle z {eo:.2e} nu {eno:.2e} (wave-vs-oracle {ewo:.2e}) | info equal {same} "
-          f"iters {np.bincount(ip['iters'])} steps {np.unique(ip['step'])}", flush=True)
+          f"dispatch {disp} iters {np.bincount(ip['iters'])} steps {np.unique(ip['step'])}", flush=True)
     hp.close(); hw.close()
 
 

@@ -17,7 +17,9 @@ out = (C.c_ulonglong * 16)()
 for rep in range(3):
     h.solve_device(x0, x0p, None, None, nu0, nw, 1e-2); torch.cuda.synchronize()
     lib.fmpc_debug_timing(out)
-tot = sum(out[i] for i in range(4, 12))
+    if rep < 2 and hasattr(lib, "fmpc_debug_panel_timing"):
+        lib.fmpc_debug_panel_timing((C.c_ulonglong * 16)())
+tot = sum(out[i] for i in range(4, 12)) or 1
 nw_ = min(B, 2048)
 print("per-wave-average cycles (batch %d, n_newton %d):" % (B, nw))
 for nm, i in [("P0 init", 4), ("P1 residuals (C'nu, Cz)", 5), ("P2 rhs", 6), ("P3 factor+fwd | shared fwd sweep", 7), ("P4 backward | shared bwd sweep", 8), ("P5 dz+update", 9), ("between problems", 11)]:
@@ -27,3 +29,13 @@ ft = sum(out[i] for i in range(4))
 if ft:       # per-stage sections of the per-problem factor phase (general path only)
     for nm, i in [("P3.images + B Rt^-1 B' + U'U (MFMA)", 0), ("P3.tiles -> LDS, row/col loads", 1), ("P3.fused potrf+trsm (VALU)", 2), ("P3.store + readback", 3)]:
         print("    %-38s %12.0f  %5.1f%% of P3" % (nm, out[i] / nw_, 100.0 * out[i] / ft))
+if nw == 1 and hasattr(lib, "fmpc_debug_panel_timing"):
+    lib.fmpc_debug_panel_timing(out)
+    npan = (B + 15) // 16
+    nwav = min(npan, 256) * 8
+    tot = sum(out[i] for i in range(6))
+    if tot:
+        print("panel kernel, per-wave-average cycles (%d panels):" % npan)
+        for nm, i in [("S1 rhs + Linv rhs", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep", 3), ("S5 d_z, write-out", 4), ("acceptance", 5)]:
+            print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwav, 100.0 * out[i] / tot))
+        print("  total %.0f cycles/wave" % (tot / nwav))
