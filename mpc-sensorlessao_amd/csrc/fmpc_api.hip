@@ -38,7 +38,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const int* sel = nullptr, const int* sel_count = nullptr, int* sel_reset = nullptr);
+                            const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -65,14 +65,17 @@ struct fmpc_handle_s {
     double sh_k; int sh_valid; int sh_enabled;
     double* cold_d;                      // cold-start constants on the device (FwCold layout)
     // panel kernel (fmpc_kernel_panel.hip): the cold-start step on 16-problem panels, n_newton = 1
-    int pn_enabled, pn_valid, pn_mp, pn_parity;
+    int pn_enabled, pn_valid, pn_mp;
     int last_path;
     size_t pn_lds;
     double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
     size_t pn_o_simg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
-    int* pn_cnt;                         // two alternating selection counters
-    int* pn_sel; size_t pn_sel_cap;
-    double pn_rd2_0, pn_sa_cu;
+    int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
+    size_t pn_cap;                       // per-batch buffers of the panel path, grown together
+    double* pn_gate; double* pn_epsp; double* pn_nuws;
+    size_t pn_o_dz; int pn_dz_len;
+    size_t pn_dz_lds;
+    double pn_rd2_0, pn_sa_cu, pn_rp2c;
     std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // workspace, grown on demand; guarded because a handle may be shared between threads
@@ -165,8 +168,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
-    h->last_path = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_parity = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->pn_cnt = nullptr; h->pn_sel = nullptr; h->pn_sel_cap = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
+    h->last_path = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -354,17 +357,20 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             if (n == FP_N && !(nopn && nopn[0] == '1') && plds <= FMPC_LDS_LIMIT) {
                 const FpVec V = fp_vec_layout(h->nb, T);
                 size_t o = 0;
-                h->pn_o_simg = o; o += (size_t)(h->nb + 1) * 6 * FP_IMG;
+                h->pn_o_simg = o; o += (size_t)(h->nb + 1) * 6 * FP_IMG + 3 * FP_IMG;
                 h->pn_o_bt = o;   o += (size_t)(pmp / 16) * FP_KS * 64;
                 h->pn_o_aimg = o; o += 5 * FP_IMG;
                 h->pn_o_vec = o;  o += V.total;
                 h->pn_o_ucon = o; o += 4 * (size_t)pmp;
+                h->pn_dz_len = fd_lds_layout(pmp).total;
+                h->pn_o_dz = o;   o += (size_t)h->pn_dz_len;
                 h->pn_doubles = o;
                 h->pn_o_dump = o; o += (size_t)T * (n + m) + (size_t)h->nb * n;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
-                (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));
-                if (fmpc_panel_prepare(plds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+                    hipMalloc((void**)&h->pn_cnt, sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                (void)hipMemset(h->pn_cnt, 0, sizeof(int));
+                h->pn_dz_lds = fmpc_dz_lds_bytes(pmp);
+                if (fmpc_panel_prepare(plds) != hipSuccess || fmpc_dz_prepare(h->pn_dz_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
                 h->hm_Q2 = Q2; h->hm_Qf2 = Qf2;
                 h->hm_ql.assign(n, 0.0); if (q) h->hm_ql.assign(q, q + n);
                 h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
@@ -391,7 +397,9 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->cold_d) (void)hipFree(h->cold_d);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
-    if (h->pn_sel) (void)hipFree(h->pn_sel);
+    if (h->pn_gate) (void)hipFree(h->pn_gate);
+    if (h->pn_epsp) (void)hipFree(h->pn_epsp);
+    if (h->pn_nuws) (void)hipFree(h->pn_nuws);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -535,6 +543,20 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
             image(M, -1.0, dst + (lag == 1 ? FP_SIMG_V1 : FP_SIMG_V2) * FP_IMG);
         }
     }
+    // ---- the prediction terms of stages 0 and 1 folded into product images: -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
+    {
+        double* dst = pool.data() + h->pn_o_simg + (size_t)(nb + 1) * 6 * FP_IMG;
+        auto prod = [&](const std::vector<ld>& X, const std::vector<double>& A) {
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                ld a = 0.0L;
+                for (int q = 0; q <= r; ++q) a += X[r * n + q] * (ld)A[q * n + c];
+                M[r * n + c] = a;
+            }
+        };
+        prod(Linv[0], h->hm_a1); image(M, -1.0, dst);
+        prod(Linv[0], h->hm_a2); image(M, -1.0, dst + FP_IMG);
+        if (nb > 1) { prod(Linv[1], h->hm_a2); image(M, -1.0, dst + 2 * FP_IMG); }
+    }
     // ---- model images
     const double* bt = h->hm_bt.data();                           // bt[c*n + r] = B[r][c]
     {
@@ -617,7 +639,32 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
             vec[V.cp + i * 32 + r] = cp;
             vec[V.ct + i * 32 + r] = cp - c0;
         }
+    // rt_i = Linv_i ct_i and the w-free part of ||r_p||^2
+    double rp2c = 0.0;
+    for (int i = 0; i < nb; ++i)
+        for (int r = 0; r < n; ++r) {
+            ld a = 0.0L;
+            for (int q = 0; q <= r; ++q) a += Linv[i][r * n + q] * (ld)vec[V.ct + i * 32 + q];
+            vec[V.rt + i * 32 + r] = (double)a;
+            if (i >= 2) rp2c += vec[V.cp + i * 32 + r] * vec[V.cp + i * 32 + r];
+        }
+    h->pn_rp2c = rp2c;
     h->pn_rd2_0 = rd2_0; h->pn_sa_cu = sa_cu;
+    {   // LDS image of the d_z kernel, in LDS order
+        const FdLds D = fd_lds_layout(mp);
+        double* dz = pool.data() + h->pn_o_dz;
+        memcpy(dz + D.BT, pool.data() + h->pn_o_bt, (size_t)(mp / 16) * FP_KS * 64 * sizeof(double));
+        memcpy(dz + D.A1T, pool.data() + h->pn_o_aimg + FP_AIMG_A1T * FP_IMG, FP_IMG * sizeof(double));
+        memcpy(dz + D.A2T, pool.data() + h->pn_o_aimg + FP_AIMG_A2T * FP_IMG, FP_IMG * sizeof(double));
+        for (int j = 0; j < mp; ++j) {
+            dz[D.UC + j] = -uc[mp + j] * uc[j];
+            dz[D.UC + mp + j] = uc[mp + j]; dz[D.UC + 2 * mp + j] = uc[2 * mp + j]; dz[D.UC + 3 * mp + j] = uc[3 * mp + j];
+        }
+        for (int r = 0; r < 32; ++r) {
+            dz[D.XQ + r] = vec[V.xc + r]; dz[D.XQ + 32 + r] = vec[V.xc + (T - 1) * 32 + r];
+            dz[D.XQ + 64 + r] = vec[V.iq + r]; dz[D.XQ + 96 + r] = vec[V.iq + (T - 1) * 32 + r];
+        }
+    }
     if (hipMemcpy(h->pn_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     h->pn_valid = 1;
     return FMPC_OK;
@@ -684,29 +731,45 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
         if (mode == 1 && h->pn_enabled && h->pn_valid && max_iter == 1) {
             // the reference's own call (one Newton step from the cold start): 16-problem panels on the matrix
             // cores; problems whose step-length / exit decision is not clear-cut go to the exact path below
-            if ((size_t)batch > h->pn_sel_cap) {
-                if (h->pn_sel) { (void)hipDeviceSynchronize(); (void)hipFree(h->pn_sel); h->pn_sel = nullptr; h->pn_sel_cap = 0; }
-                if (hipMalloc((void**)&h->pn_sel, (size_t)batch * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
-                h->pn_sel_cap = batch;
+            const int npanels = (batch + FP_NP - 1) / FP_NP;
+            if ((size_t)batch > h->pn_cap) {
+                (void)hipDeviceSynchronize();
+                if (h->pn_gate) (void)hipFree(h->pn_gate);
+                if (h->pn_epsp) (void)hipFree(h->pn_epsp);
+                if (h->pn_nuws) (void)hipFree(h->pn_nuws);
+                h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_cap = 0;
+                if (hipMalloc((void**)&h->pn_gate, (size_t)batch * 2 * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_epsp, (size_t)npanels * h->T * FP_NP * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_nuws, (size_t)batch * h->nb * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                h->pn_cap = batch;
             }
             FpParams Q;
             Q.m = h->m; Q.mp = h->pn_mp; Q.T = h->T; Q.nb = h->nb; Q.has_xf = h->has_xf; Q.var2 = h->var_order == 2 ? 1 : 0;
-            Q.batch = batch; Q.npanels = (batch + FP_NP - 1) / FP_NP; Q.step_ld = fmpc_step_ld(n_newton);
+            Q.batch = batch; Q.npanels = npanels; Q.step_ld = fmpc_step_ld(n_newton);
             Q.x0 = x0; Q.x0p = x0_pre; Q.w = w; Q.nu0 = nu0;
-            Q.zout = z_out; Q.nuout = nu_out; Q.status = status; Q.iters = iters; Q.step = step;
+            Q.zout = z_out; Q.status = status; Q.iters = iters; Q.step = step;
+            Q.nuws = nu_out ? nu_out : h->pn_nuws;
             Q.simg = h->pn_pool + h->pn_o_simg; Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
             Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
-            Q.rd2_0 = h->pn_rd2_0; Q.sa_cu = h->pn_sa_cu; Q.dump = h->pn_pool + h->pn_o_dump; { const char* d = getenv("FMPC_PANEL_DBG"); Q.dbg = d ? atoi(d) : 0; }
-            const int c = h->pn_parity;
-            Q.sel = h->pn_sel; Q.sel_count = h->pn_cnt + c;
-            const int pgrid = Q.npanels < h->num_cu ? Q.npanels : h->num_cu;
+            Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
+            Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;
+            Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
+            { const char* d = getenv("FMPC_PANEL_DBG"); Q.dbg = d ? atoi(d) : 0; }
+            const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             e = fmpc_launch_panel(Q, pgrid, h->pn_lds, (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;
+            const int ntasks = npanels * h->T;
+            // one task per wave, 8 per workgroup; workgroups b, b + 8, ... take the panels b % 8, b % 8 + 8, ...
+            const int ppx = (npanels + 7) / 8;                       // panels of the fullest XCD share
+            const int dgrid = 8 * ((ppx * h->T + 7) / 8);
+            (void)ntasks;
+            e = fmpc_launch_dz(Q, dgrid, h->pn_dz_lds, (hipStream_t)stream);
+            if (e != hipSuccess) return FMPC_E_HIP;
+            // decides the step length of every problem; solves exactly those whose decision is not clear-cut
             e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                  z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                                  h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
-                                 h->pn_sel, h->pn_cnt + c, h->pn_cnt + (1 - c));
-            h->pn_parity = 1 - c;
+                                 h->pn_gate, h->pn_epsp, h->pn_cnt);
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }
@@ -736,8 +799,7 @@ extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {
         *handed_over = 0;
         if (h->last_path == FMPC_PATH_PANEL) {
             if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
-            // the counter of the last call is the one the NEXT call's exact-path launch will reset
-            if (hipMemcpy(handed_over, h->pn_cnt + (1 - h->pn_parity), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+            if (hipMemcpy(handed_over, h->pn_cnt, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
         }
     }
     return FMPC_OK;

@@ -1,0 +1,209 @@
+// CDNA4 fastMPC, cold-start Newton step on panels of 16 problems (n = 27): the primal step from nu+.
+//
+// Second kernel of the panel path (the first, fmpc_kernel_panel.hip, produced nu+ = nu + d_nu of the full
+// step; same reference correspondence: inf_newton_solver.m:33-36, backtracking_inf_newton.m:2-11):
+//     d_u_j  = wc o (B' nu+_j - cu) ,  d_x_j = (2Q_j)^-1 (-dx0_j - nu+_j + A1' nu+_{j+1} + A2' nu+_{j+2} [- nu+_T])
+//     z = zbar + d_z ,  ||e||^2 = sum (k P'DP d_u)^2
+// One independent TASK per (panel of 16 problems, stage j), one wavefront per task, no barrier: the whole
+// chip works on it whatever the batch size.  The products are only consumed element-wise, so they are computed
+// TRANSPOSED: the nu+ panel in B-operand layout (lane (g, c) holds nu+[4 ks + g] of problem c) is also a valid
+// A operand with the problems as rows, and the images of B', A1', A2' (LDS) serve as B operands with the
+// entries as columns.  Result register r of lane (g, c) is then (problem 4 r + g, entry 16 J + c): each store
+// instruction writes, for 4 problems, 16 consecutive entries (128 contiguous bytes), and the per-entry
+// constants are one LDS read per lane.  A wave does ONE task: all its loads precede all its stores (a load behind a
+// store waits for the store: vmcnt is in order), and the hardware dispatcher balances the workgroups.
+//
+// Per task it also leaves the partial ||e||^2 of its 16 problems; the exact-path launch that follows
+// (fmpc_newton_wave in panel mode) sums them and decides the step length of every problem.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "fmpc_device.h"
+#include "fmpc_panel.h"
+#include "../../include/fastmpc.h"
+
+#define FD_WAVES 8
+#define FD_THREADS (FD_WAVES * 64)
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+typedef __attribute__((address_space(3))) double* fd_lds_t;
+typedef const __attribute__((address_space(3))) double* fd_clds_t;
+typedef const FpParams __attribute__((address_space(4))) * FdKP;
+
+#ifdef FW_TIMING
+__device__ unsigned long long fd_timing[8];
+extern "C" int fmpc_debug_dz_timing(unsigned long long* out) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_timing), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fd_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#define FD_TICK(k) do { _k1 = __builtin_readcyclecounter(); _ka[k] += _k1 - _k0; _k0 = _k1; } while (0)
+#else
+#define FD_TICK(k)
+#endif
+
+__global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FdKP P = (FdKP)__builtin_amdgcn_kernarg_segment_ptr();
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
+    const int nb = P->nb, T = P->T, m = P->m, mp = P->mp, batch = P->batch, s = FP_N + m;
+    const FdLds L = fd_lds_layout(mp);
+#ifdef FW_TIMING
+    unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    {   // the LDS image is packed by the host in LDS order: all loads first, then the stores
+        const double* src = P->dzimg;
+        const int len = P->dzimg_len;
+        constexpr int NB = 14;                          // 14 x 512 doubles = 56 KB >= the image for m <= 160
+        double t[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int i = k * FD_THREADS + tid; t[k] = src[i < len ? i : 0]; }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { const int i = k * FD_THREADS + tid; if (i < len) lds[i] = t[k]; }
+        for (int i = NB * FD_THREADS + tid; i < len; i += FD_THREADS) lds[i] = src[i];
+    }
+    __syncthreads();                                 // the only barrier: the waves are independent below
+    FD_TICK(0);
+    const fd_clds_t BT = (fd_clds_t)lds + L.BT + lane;
+    const fd_clds_t A1T = (fd_clds_t)lds + L.A1T + lane;
+    const fd_clds_t A2T = (fd_clds_t)lds + L.A2T + lane;
+    const fd_clds_t UC = (fd_clds_t)lds + L.UC + c16;
+    const fd_clds_t XQ = (fd_clds_t)lds + L.XQ;
+    const bool has_xf = P->has_xf != 0, var2 = P->var2 != 0;
+    const int NJ = mp / 16, NJF = m / 16;            // column blocks, full column blocks
+    // Task order: workgroups b and b + 8 share an XCD (round-robin dispatch; for speed only), so the tasks of a
+    // panel all go to the workgroups of ONE XCD: the cache lines shared by consecutive stages of a problem are
+    // then merged in that XCD's L2 instead of being written back half-filled from two.
+    const int xcd = blockIdx.x & 7;
+    const int npx = (P->npanels - xcd + 7) >> 3;       // panels xcd, xcd + 8, ...
+    const int ntasks = npx * T;
+    const int t = (blockIdx.x >> 3) * FD_WAVES + wv;   // this wave's task among those of its XCD
+    if (t >= ntasks) return;
+    const int pl = t / T, j = t - pl * T;
+    const int panel = xcd + 8 * pl;
+    const double* nuws = P->nuws;
+    const size_t nus = (size_t)nb * FP_N;
+
+    // ---- everything this task reads from HBM / L2
+    double v0[FP_KS], v1[FP_KS], v2[FP_KS];        // nu+_j, nu+_{j+1}, nu+_{j+2} in B-operand layout (problem = lane % 16)
+    double nj[2][4], nx[2][4];                      // nu+_j, nu+_T at (problem 4 r + g, row 16 I + lane % 16)
+    {
+        const int pb = panel * FP_NP + c16;
+        const double* nb_ = nuws + (size_t)(pb < batch ? pb : batch - 1) * nus + g;
+        const bool h1 = j + 1 < T, h2 = j + 2 < T && var2, xfl = j + 1 == T && has_xf;
+#pragma unroll
+        for (int ks = 0; ks < FP_KS; ++ks) {
+            const bool kok = 4 * ks + g < FP_N;
+            const int ko = kok ? 4 * ks : 0;
+            const double t0 = nb_[j * FP_N + ko];
+            const double t1 = nb_[(h1 ? j + 1 : j) * FP_N + ko];
+            const double t2 = nb_[(h2 ? j + 2 : j) * FP_N + ko];
+            v0[ks] = kok ? t0 : 0.0; v1[ks] = (kok && h1) ? t1 : 0.0; v2[ks] = (kok && h2) ? t2 : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = panel * FP_NP + 4 * r + g;
+            const double* nr = nuws + (size_t)(pr < batch ? pr : batch - 1) * nus;
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+                const int row = 16 * I + c16;
+                const int rc = row < FP_N ? row : 0;
+                nj[I][r] = nr[j * FP_N + rc];
+                const double t_ = nr[(xfl ? T : j) * FP_N + rc];
+                nx[I][r] = xfl ? t_ : 0.0;
+            }
+        }
+    }
+    FD_TICK(1);
+    double* zq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = panel * FP_NP + 4 * r + g;         // problem 4 r + g of the panel
+        zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + (size_t)j * s + c16;
+    }
+    double eps2[4] = {0.0, 0.0, 0.0, 0.0};
+    // ---- x entries first (they free 30 of the 37 loaded values): d_x = (2Q)^-1 (-dx0 - nu+_j + A1' nu+_{j+1} + A2' nu+_{j+2} [- nu+_T])
+    const bool last = j + 1 == T;
+    const fd_clds_t xcv = XQ + (last ? 32 : 0), iqv = XQ + 64 + (last ? 32 : 0);
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        d4 hh = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < FP_KS; ++ks) hh = MFMA64(v1[ks], A1T[(I * FP_KS + ks) * 64], hh);
+#pragma unroll
+        for (int ks = 0; ks < FP_KS; ++ks) hh = MFMA64(v2[ks], A2T[(I * FP_KS + ks) * 64], hh);
+        const int row = 16 * I + c16;
+        const bool rok = row < FP_N;
+        const int rc = rok ? row : 0;
+        const double xc = xcv[rc], iq = iqv[rc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double zx = xc + iq * (hh[r] - nj[I][r] - nx[I][r]);
+            if (rok) zq[r][m + 16 * I] = zx;            // rows 27..31 of the second row block do not exist
+        }
+    }
+    // ---- u entries: d_u = wc o (B' nu+_j - cu); the MFMAs of the next column block are issued before the
+    // element-wise work of the current one
+    auto mm = [&](int J) {
+        d4 acc = {0, 0, 0, 0};
+        const fd_clds_t im = BT + J * FP_KS * 64;
+#pragma unroll
+        for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(v0[ks], im[ks * 64], acc);
+        return acc;
+    };
+    auto epi = [&](int J, d4 acc) {
+        const fd_clds_t uc = UC + 16 * J;
+        const double c1 = uc[0], wc = uc[mp], hc = uc[2 * mp], ub = uc[3 * mp];
+        const bool cok = J < NJF || 16 * J + c16 < m;    // partial last column block when m % 16 != 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double du = fma(wc, acc[r], c1);
+            const double e = hc * du;
+            if (cok) {
+                eps2[r] = fma(e, e, eps2[r]);
+                zq[r][16 * J] = ub + du;
+            }
+        }
+    };
+    {
+        d4 a0 = mm(0);
+        int J = 0;
+        for (; J + 2 < NJ; J += 2) {
+            const d4 a1 = mm(J + 1);
+            epi(J, a0);
+            a0 = mm(J + 2);
+            epi(J + 1, a1);
+        }
+        if (J + 1 < NJ) {
+            const d4 a1 = mm(J + 1);
+            epi(J, a0);
+            epi(J + 1, a1);
+        } else {
+            epi(J, a0);
+        }
+    }
+    // ---- ||e||^2 of this stage per problem
+    double* ep = P->epsp + ((size_t)panel * T + j) * FP_NP;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = eps2[r];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (c16 == 0) ep[4 * r + g] = v;
+    }
+    FD_TICK(2);
+#ifdef FW_TIMING
+    if (lane == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&fd_timing[q], _ka[q]); atomicAdd(&fd_timing[7], 1ull); }
+#endif
+}
+
+// ---------------------------------------------------------------- host side
+size_t fmpc_dz_lds_bytes(int mp) { return (size_t)fd_lds_layout(mp).total * sizeof(double); }
+
+hipError_t fmpc_dz_prepare(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void*)fmpc_cold_dz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(fmpc_cold_dz, dim3(grid), dim3(FD_THREADS), lds_bytes, stream, P);
+    return hipGetLastError();
+}

@@ -454,6 +454,15 @@ fmpc_unpack_kernel(int n, int m, int T, int batch, const double* __restrict__ z,
                    double* __restrict__ U, double* __restrict__ X, double* __restrict__ u0) {
     const int s = n + m;
     const size_t Nz = (size_t)T * s, total = Nz * batch;
+    if (!U && !X) {                                   // only the first move: read m entries per problem, not all of z
+        if (!u0) return;
+        for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < (size_t)batch * m;
+             g += (size_t)gridDim.x * blockDim.x) {
+            const size_t p = g / m;
+            u0[g] = z[p * Nz + (g - p * m)];
+        }
+        return;
+    }
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (size_t)gridDim.x * blockDim.x) {
         const size_t p = g / Nz;

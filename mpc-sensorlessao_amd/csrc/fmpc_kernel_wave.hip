@@ -127,9 +127,10 @@ struct FwParams {
     double* ws; size_t ws_stride;
     double* sh_fac; double* sh_rs; int* sh_ok;     // shared (cold-start) factor owned by the handle
     const double* cold;                             // cold-start constants (FwCold layout), k-dependent
-    // optional selection: solve only problems sel[0 .. *sel_count-1] (those the panel kernel handed over);
-    // *sel_reset is zeroed for the next call (the two counters of the handle alternate)
-    const int* sel; const int* sel_count; int* sel_reset;
+    // panel path (fmpc_kernel_panel.hip + fmpc_kernel_dz.hip ran before this launch): per problem ||r_p||^2 and a
+    // lower bound of rho^2 (gate), per (panel, stage, problem) the partial ||e||^2 (epsp).  Non-null: decide the
+    // step length of every problem first and solve only those whose decision is not clear-cut.
+    const double* gate; const double* epsp; int* handed;
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -1390,6 +1391,29 @@ FW_FN void fw_phase_update(FwKP Pin, int p, double t) {
     fw_mem_fence();
 }
 
+// Panel path: step-length / exit decision of problem p from what the two panel kernels left behind.
+// The line search (backtracking_inf_newton.m:2-11) accepts t = 1 iff ||e||^2 <= (1-alpha)^2 rho^2
+// and the exit test (inf_newton_solver.m:19-22) needs rho and ||r_p||.  Both are decided here only with a wide
+// margin (||e||^2 <= rho_lb^2 / 2 with rho_lb <= rho; ||r_p|| or rho_lb a factor 2 above the exit thresholds);
+// returns false for every other problem, which the caller then solves exactly, overwriting the panel result.
+// Wave-uniform; fixed summation order.
+__device__ __forceinline__ bool fw_panel_decide(FwKP P, int p, bool write) {
+    const int lane = threadIdx.x & 63, T = P->M.T;
+    const double* e0 = P->epsp + ((size_t)(p >> 4) * T) * 16 + (p & 15);
+    double e = 0.0;
+    for (int j = lane; j < T; j += 64) e += e0[(size_t)j * 16];
+    const double e2 = fw_wave_sum(e);
+    const double rp2 = P->gate[2 * p], rho2 = P->gate[2 * p + 1];
+    const bool fin = rp2 < 1e300 && rho2 < 1e300 && e2 < 1e300;       // false for NaN
+    const bool clear = fin && (rp2 > 4e-16 || rho2 > 4e-12) && e2 <= 0.5 * rho2;
+    if (clear && write && lane == 0) {
+        if (P->status) P->status[p] = FMPC_OK;
+        if (P->iters) P->iters[p] = 1;
+        if (P->step) for (int q = 0; q < P->step_ld; ++q) P->step[(size_t)p * P->step_ld + q] = q == 0 ? 1.0 : -1.0;
+    }
+    return clear;
+}
+
 template <int N>
 __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     using C = FwCfg<N>;
@@ -1397,10 +1421,19 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const FwKP P = fw_params();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int mp = P->V.mp;
-    const int* sel = P->sel;
-    const int batch = sel ? *P->sel_count : P->batch;
-    if (sel && blockIdx.x == 0 && threadIdx.x == 0 && P->sel_reset) *P->sel_reset = 0;
-    if (blockIdx.x * FW_WAVES >= batch) return;            // nothing selected for this workgroup
+    const int batch = P->batch;
+    const bool panel_mode = P->gate != nullptr;
+    const int wave_g = blockIdx.x * FW_WAVES + wv, nwaves = gridDim.x * FW_WAVES;
+    const int rounds = (batch + nwaves - 1) / nwaves;
+    if (panel_mode) {
+        // decisions of all problems of this workgroup; leave if none of them needs the exact path
+        int need = 0;
+        for (int rnd = 0; rnd < rounds; ++rnd) {
+            const int q = wave_g + rnd * nwaves;
+            if (q < batch && !fw_panel_decide(P, q, true)) { need = 1; if (lane == 0 && P->handed) atomicAdd(P->handed, 1); }
+        }
+        if (!__syncthreads_or(need)) return;
+    }
     for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
     {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
         double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
@@ -1410,7 +1443,6 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     // scalars handed back by the phases: a 4-double LDS slot per wave behind the tiles
     double* red = lds + (size_t)mp * FW_LDB + (size_t)FW_WAVES * C::PER_WAVE + wv * 4;
 
-    const int wave_g = blockIdx.x * FW_WAVES + wv, nwaves = gridDim.x * FW_WAVES;
     {   // zero the k-step padding of winv once (columns m..mp-1 never change)
         const FwView<N> W(P, 0);
         for (int idx = lane; idx < W.T * mp; idx += 64) W.winv[idx] = 0.0;
@@ -1425,11 +1457,9 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     // cold: first Newton step from the mid-box start with the handle's shared factor and constants.
     // All waves of a workgroup run the same number of rounds (the shared sweeps are collective).
     const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
-    const int rounds = (batch + nwaves - 1) / nwaves;
     for (int rnd = 0; rnd < rounds; ++rnd) {
-        const int q = wave_g + rnd * nwaves;
-        const bool active = q < batch;
-        const int p = active && sel ? sel[q] : q;
+        const int p = wave_g + rnd * nwaves;
+        const bool active = p < batch && !(panel_mode && fw_panel_decide(P, p, false));
         if (cold_mode) {
             // [cu | hc | wc | ubar] into LDS for the cold step's epilogue.  The region overlaps the per-wave
             // tiles of the general path, so wait until every wave has left the previous round.
@@ -1611,10 +1641,10 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const int* sel, const int* sel_count, int* sel_reset) {
+                            const double* gate, const double* epsp, int* handed) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
-    P.sel = sel; P.sel_count = sel_count; P.sel_reset = sel_reset;
+    P.gate = gate; P.epsp = epsp; P.handed = handed;
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;

@@ -29,7 +29,7 @@
 #define FP_AIMG_BBT 4
 
 // row-indexed constants (leading dimension 32), offsets in doubles into FpParams::vec
-struct FpVec { int ct, cp, xc, iq, dx0, bcu, total; };
+struct FpVec { int ct, cp, xc, iq, dx0, bcu, rt, total; };
 __host__ __device__ static inline FpVec fp_vec_layout(int nb, int T) {
     FpVec v; int o = 0;
     v.ct = o; o += nb * 32;            // rhs_i = ct_i - b_i
@@ -38,27 +38,51 @@ __host__ __device__ static inline FpVec fp_vec_layout(int nb, int T) {
     v.iq = o; o += T * 32;             // (2Q_j)^-1
     v.dx0 = o; o += T * 32;            // 2Q_j xbar + q_j
     v.bcu = o; o += 32;                // B cu
+    v.rt = o; o += nb * 32;            // Linv_i ct_i
     v.total = o;
     return v;
 }
 
+// LDS map of the d_z kernel (doubles); the host packs FpParams::dzimg in exactly this order
+struct FdLds { int BT, A1T, A2T, UC, XQ, total; };
+__host__ __device__ static inline FdLds fd_lds_layout(int mp) {
+    FdLds L; int o = 0;
+    L.BT = o;  o += (mp / 16) * FP_KS * 64;         // B' images
+    L.A1T = o; o += FP_IMG;
+    L.A2T = o; o += FP_IMG;
+    L.UC = o;  o += 4 * mp;                         // [c1 | wc | hc | ubar], c1 = -wc cu
+    L.XQ = o;  o += 4 * 32;                         // [xc | xc(last stage) | iq | iq(last stage)]
+    L.total = o;
+    return L;
+}
+
+// One parameter block for both kernels of the panel path.
 struct FpParams {
     int m, mp, T, nb, has_xf, var2;
     int batch, npanels, step_ld;
     const double* x0; const double* x0p; const double* w; const double* nu0;
-    double* zout; double* nuout; int* status; int* iters; double* step;
-    const double* simg;                 // sweep images (k-dependent), nb + 1 stage slots, the last all zero
+    double* zout; int* status; int* iters; double* step;
+    double* nuws;                       // nu+ (the caller's nu_out or a workspace): written by the panel kernel, read by d_z
+    const double* simg;                 // sweep images (k-dependent): nb + 1 stage slots, the last all zero,
+                                        // then -Linv_0 A1, -Linv_0 A2, -Linv_1 A2 (prediction terms of b_0, b_1)
     const double* btimg;                // B' images, [mp/16][7][64]
     const double* aimg;                 // model images
     const double* vec;                  // FpVec
     const double* ucon;                 // [cu | wc | hc | ubar], each mp
     double rd2_0;                       // ||r_d||^2 at nu = 0
-    double sa_cu;                       // |cu|^2
-    int* sel; int* sel_count;           // problems handed to the exact path
-    int dbg;
+    double rp2c;                        // sum_{i>=2} |cp_i|^2: ||r_p||^2 of the stages >= 2 when w = NULL
+    double* gate;                       // per problem: ||r_p||^2, lower bound of rho^2   (read by fmpc_newton_wave)
+    double* epsp;                       // per (panel, stage, problem): partial ||e||^2   (read by fmpc_newton_wave)
+    const double* dzimg;                // LDS image of the d_z kernel: [B' | A1' | A2' | c1 wc hc ubar | xc xc' iq iq']
+    int dzimg_len;
+    int dbg;                            // development switches (FMPC_PANEL_DBG), 0 in production
+    int* handed;                        // number of problems the exact path had to solve (diagnostic), zeroed here
     double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
 };
 
 size_t fmpc_panel_lds_bytes(int nb, int mp);
 hipError_t fmpc_panel_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_panel(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
+size_t fmpc_dz_lds_bytes(int mp);
+hipError_t fmpc_dz_prepare(size_t lds_bytes);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);

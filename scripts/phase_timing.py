@@ -33,9 +33,15 @@ if nw == 1 and hasattr(lib, "fmpc_debug_panel_timing"):
     lib.fmpc_debug_panel_timing(out)
     npan = (B + 15) // 16
     nwav = min(npan, 256) * 8
-    tot = sum(out[i] for i in range(6))
+    tot = sum(out[i] for i in range(5))
     if tot:
-        print("panel kernel, per-wave-average cycles (%d panels):" % npan)
-        for nm, i in [("S1 rhs + Linv rhs", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep", 3), ("S5 d_z, write-out", 4), ("acceptance", 5)]:
+        print("panel kernel (dual solve), per-wave-average cycles (%d panels):" % npan)
+        for nm, i in [("S1 Linv rhs", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep + nu out", 3), ("gate values", 4)]:
             print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwav, 100.0 * out[i] / tot))
         print("  total %.0f cycles/wave" % (tot / nwav))
+if nw == 1 and hasattr(lib, "fmpc_debug_dz_timing"):
+    lib.fmpc_debug_dz_timing(out)
+    nwv = out[7] or 1
+    print("d_z kernel, per-wave-average cycles (%d waves over 3 reps):" % nwv)
+    for nm, i in [("LDS init", 0), ("loads issued", 1), ("products, element-wise work, stores", 2)]:
+        print("  %-36s %12.0f" % (nm, out[i] / nwv))
