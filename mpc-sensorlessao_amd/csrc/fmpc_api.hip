@@ -2,6 +2,7 @@
 // iteration-invariant blocks, launches.  No CPU solve path exists in this library.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -69,14 +70,16 @@ struct fmpc_handle_s {
     int last_path;
     size_t pn_lds;
     double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
-    size_t pn_o_simg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
+    size_t pn_o_simg, pn_o_limg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
     int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
     size_t pn_cap;                       // per-batch buffers of the panel path, grown together
     double* pn_gate; double* pn_epsp; double* pn_nuws;
     size_t pn_o_dz; int pn_dz_len;
     size_t pn_dz_lds;
     double pn_rd2_0, pn_sa_cu, pn_rp2c;
-    std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf;
+    std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf, hm_blocks;
+    std::vector<int> hm_idxD, hm_idx1, hm_idx2;
+    int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
@@ -168,7 +171,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
-    h->last_path = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -357,7 +360,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             if (n == FP_N && !(nopn && nopn[0] == '1') && plds <= FMPC_LDS_LIMIT) {
                 const FpVec V = fp_vec_layout(h->nb, T);
                 size_t o = 0;
-                h->pn_o_simg = o; o += (size_t)(h->nb + 1) * 6 * FP_IMG + 3 * FP_IMG;
+                h->pn_o_simg = o; o += (size_t)h->nb * FP_IMG + 3 * FP_IMG;          // Linv per stage, then the prediction images
+                h->pn_limg_cap = 9 * h->nb + 2;                                        // Linv' per stage, a zero image, the edges
+                h->pn_o_limg = o; o += (size_t)h->pn_limg_cap * FP_IMGL;
                 h->pn_o_bt = o;   o += (size_t)(pmp / 16) * FP_KS * 64;
                 h->pn_o_aimg = o; o += 5 * FP_IMG;
                 h->pn_o_vec = o;  o += V.total;
@@ -367,11 +372,12 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                 h->pn_doubles = o;
                 h->pn_o_dump = o; o += (size_t)T * (n + m) + (size_t)h->nb * n;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_cnt, sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                    hipMalloc((void**)&h->pn_cnt, sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_sched, (size_t)2 * FP_MAX_STEPS(h->nb) * FP_STEP_INTS * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 (void)hipMemset(h->pn_cnt, 0, sizeof(int));
                 h->pn_dz_lds = fmpc_dz_lds_bytes(pmp);
                 if (fmpc_panel_prepare(plds) != hipSuccess || fmpc_dz_prepare(h->pn_dz_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
-                h->hm_Q2 = Q2; h->hm_Qf2 = Qf2;
+                h->hm_Q2 = Q2; h->hm_Qf2 = Qf2; h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2;
                 h->hm_ql.assign(n, 0.0); if (q) h->hm_ql.assign(q, q + n);
                 h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
                 if (xf) h->hm_xf.assign(xf, xf + n);
@@ -397,6 +403,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->cold_d) (void)hipFree(h->cold_d);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
+    if (h->pn_sched) (void)hipFree(h->pn_sched);
     if (h->pn_gate) (void)hipFree(h->pn_gate);
     if (h->pn_epsp) (void)hipFree(h->pn_epsp);
     if (h->pn_nuws) (void)hipFree(h->pn_nuws);
@@ -475,37 +482,91 @@ static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
 // A-operand image.  Called once per (handle, k); synchronises the stream.
 static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
     typedef long double ld;
-    const int n = h->n, m = h->m, T = h->T, nb = h->nb, mp = h->pn_mp, LDG = 28, TS = n * LDG;
+    const int n = h->n, m = h->m, T = h->T, nb = h->nb, mp = h->pn_mp;
+    const int nn = n * n;
     h->pn_valid = 0;
-    if (hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
-    int ok = 0;
-    if (hipMemcpy(&ok, h->sh_ok, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
-    if (!ok) return FMPC_OK;                                     // Y not PD at the start point: exact path reports it
-    std::vector<double> fac((size_t)nb * 6 * TS), rs((size_t)nb * 32);
-    if (hipMemcpy(fac.data(), h->sh_fac, fac.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(rs.data(), h->sh_rs, rs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    (void)stream;
     std::vector<double> pool(h->pn_doubles, 0.0);
-    auto image = [&](const std::vector<ld>& M, double sign, double* out, bool perm = false) {      // M: n x n row-major
+    auto image = [&](const std::vector<ld>& M, double sign, double* out) {      // standard A-operand image of M (n x n row-major)
         for (int I = 0; I < 2; ++I)
             for (int ks = 0; ks < FP_KS; ++ks)
                 for (int l = 0; l < 64; ++l) {
-                    const int i = l & 15;
-                    const int r = 16 * I + (perm ? 4 * (i & 3) + (i >> 2) : i), c = 4 * ks + (l >> 4);
+                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
                     out[(I * FP_KS + ks) * 64 + l] = (r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
                 }
     };
-    const int nn = n * n;
-    std::vector<std::vector<ld>> Linv(nb, std::vector<ld>(nn, 0.0L));
-    auto U = [&](int i, int which, int r, int c) -> ld {          // which: 1 = U_{i,i+1}, 2 = U_{i,i+2}
-        return (ld)fac[((size_t)i * 6 + which) * TS + r * LDG + c];
+    auto limage = [&](const std::vector<ld>& M, double sign, double* out) {     // the same, lane-major (FP_IMGL doubles)
+        for (int I = 0; I < 2; ++I)
+            for (int l = 0; l < 64; ++l)
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
+                    out[(I * 64 + l) * 8 + ks] = (ks < FP_KS && r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
+                }
     };
-    for (int i = 0; i < nb; ++i) {
-        std::vector<ld> Lm(nn, 0.0L);
-        for (int r = 0; r < n; ++r) {
-            for (int j = 0; j < r; ++j) Lm[r * n + j] = (ld)fac[((size_t)i * 6 + 0) * TS + j * LDG + r];
-            Lm[r * n + r] = 1.0L / (ld)rs[(size_t)i * 32 + r];
+    // ---- u constants (needed for G = B diag(wc) B')
+    double* uc = pool.data() + h->pn_o_ucon;
+    double sa_cu = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double sp = h->hm_umax[j] - h->hm_umid[j], sm = h->hm_umid[j] - h->hm_umin[j];
+        const double dp = 1.0 / sp, dm = 1.0 / sm;
+        const double hc = k * (dp * dp + dm * dm);
+        const double cu = h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] + k * (dp - dm);
+        uc[j] = cu; uc[mp + j] = 1.0 / (h->hm_R2[j] + hc); uc[2 * mp + j] = hc; uc[3 * mp + j] = h->hm_umid[j];
+        sa_cu += cu * cu;
+    }
+    const double* bt = h->hm_bt.data();                           // bt[c*n + r] = B[r][c]
+    // ---- Y = C Phi^-1 C' at the cold start, block by block: Y_ii = const + G (i < T), Y_{i,i+1}, Y_{i,i+2}
+    std::vector<ld> G(nn, 0.0L);
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            ld t = 0.0L;
+            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + a] * (ld)uc[mp + j] * (ld)bt[(size_t)j * n + b];
+            G[a * n + b] = t;
         }
-        std::vector<ld>& X = Linv[i];
+    // Elimination order ("twisted" factorisation): the stages 0 .. hs-1 top-down, then nb-1 .. hs+2 bottom-up, then
+    // hs, hs+1.  The two chains are independent until the middle, which halves the serial length of both sweeps.
+    const int hs = nb >= 8 ? nb / 2 - 1 : nb;
+    std::vector<int> perm, rank(nb);
+    for (int i = 0; i < (hs < nb ? hs : nb); ++i) perm.push_back(i);
+    if (hs < nb) { for (int i = nb - 1; i >= hs + 2; --i) perm.push_back(i); perm.push_back(hs); perm.push_back(hs + 1); }
+    for (int a = 0; a < nb; ++a) rank[perm[a]] = a;
+    // P[a][b] (a <= b in elimination rank): the block Y[perm[a]][perm[b]]
+    std::vector<std::vector<std::vector<ld>>> Pm(nb, std::vector<std::vector<ld>>(nb));
+    auto yblock = [&](int i, int j, std::vector<ld>& out) -> bool {     // Y_ij (|i-j| <= 2), false if structurally zero
+        out.assign(nn, 0.0L);
+        const int lo = i < j ? i : j, d = i < j ? j - i : i - j;
+        int id = -1;
+        if (d == 0) id = h->hm_idxD[lo]; else if (d == 1) id = h->hm_idx1[lo]; else if (d == 2) id = h->hm_idx2[lo];
+        if (d > 2 || id < 0) return false;
+        const double* src = h->hm_blocks.data() + (size_t)id * nn;
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) out[r * n + c] = i <= j ? (ld)src[r * n + c] : (ld)src[c * n + r];
+        if (d == 0 && i < T) for (int q = 0; q < nn; ++q) out[q] += G[q];
+        return true;
+    };
+    for (int a = 0; a < nb; ++a)
+        for (int b = a; b < nb; ++b) {
+            std::vector<ld> blk;
+            if (yblock(perm[a], perm[b], blk)) Pm[a][b] = blk;
+        }
+    std::vector<std::vector<ld>> Linv(nb, std::vector<ld>(nn, 0.0L));        // by rank
+    std::vector<std::vector<std::vector<ld>>> Um(nb, std::vector<std::vector<ld>>(nb));   // U[a][b] = L_a^-1 P[a][b], b > a
+    for (int a = 0; a < nb; ++a) {
+        // L = chol(P[a][a]) (lower), X = L^-1
+        std::vector<ld> Lm(nn, 0.0L);
+        const std::vector<ld>& S = Pm[a][a];
+        for (int c = 0; c < n; ++c) {
+            ld d = S[c * n + c];
+            for (int q = 0; q < c; ++q) d -= Lm[c * n + q] * Lm[c * n + q];
+            if (!(d > 0.0L)) return FMPC_OK;                          // not PD at the start point: the exact path reports it
+            const ld ldiag = sqrtl(d);
+            Lm[c * n + c] = ldiag;
+            for (int r = c + 1; r < n; ++r) {
+                ld t = S[r * n + c];
+                for (int q = 0; q < c; ++q) t -= Lm[r * n + q] * Lm[c * n + q];
+                Lm[r * n + c] = t / ldiag;
+            }
+        }
+        std::vector<ld>& X = Linv[a];
         for (int c = 0; c < n; ++c) {
             X[c * n + c] = 1.0L / Lm[c * n + c];
             for (int r = c + 1; r < n; ++r) {
@@ -514,38 +575,108 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
                 X[r * n + c] = -sacc / Lm[r * n + r];
             }
         }
-    }
-    std::vector<ld> M(nn);
-    for (int i = 0; i < nb; ++i) {
-        double* dst = pool.data() + h->pn_o_simg + (size_t)i * 6 * FP_IMG;
-        const std::vector<ld>& X = Linv[i];
-        image(X, 1.0, dst + FP_SIMG_LINV * FP_IMG);
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = X[c * n + r];
-        image(M, 1.0, dst + FP_SIMG_LINVT * FP_IMG);
-        for (int lag = 1; lag <= 2; ++lag) {
-            // W_lag,i = Linv_i U_{i-lag,i}'
-            std::fill(M.begin(), M.end(), 0.0L);
-            if (i - lag >= 0)
+        for (int b = a + 1; b < nb; ++b) {
+            if (Pm[a][b].empty()) continue;
+            std::vector<ld> u(nn);
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                ld t = 0.0L;
+                for (int q = 0; q <= r; ++q) t += X[r * n + q] * Pm[a][b][q * n + c];
+                u[r * n + c] = t;
+            }
+            Um[a][b] = u;
+        }
+        for (int b1 = a + 1; b1 < nb; ++b1) {
+            if (Um[a][b1].empty()) continue;
+            for (int b2 = b1; b2 < nb; ++b2) {
+                if (Um[a][b2].empty()) continue;
+                if (Pm[b1][b2].empty()) Pm[b1][b2].assign(nn, 0.0L);
+                std::vector<ld>& dst = Pm[b1][b2];
+                const std::vector<ld>& u1 = Um[a][b1]; const std::vector<ld>& u2 = Um[a][b2];
                 for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                    ld a = 0.0L;
-                    for (int q = 0; q <= r; ++q) a += X[r * n + q] * U(i - lag, lag, c, q);
-                    M[r * n + c] = a;
+                    ld t = 0.0L;
+                    for (int q = 0; q < n; ++q) t += u1[q * n + r] * u2[q * n + c];
+                    dst[r * n + c] -= t;
                 }
-            image(M, -1.0, dst + (lag == 1 ? FP_SIMG_W1 : FP_SIMG_W2) * FP_IMG);
-            // V_lag,i = Linv_i' U_{i,i+lag}
-            std::fill(M.begin(), M.end(), 0.0L);
-            if (i + lag < nb)
-                for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                    ld a = 0.0L;
-                    for (int q = r; q < n; ++q) a += X[q * n + r] * U(i, lag, q, c);
-                    M[r * n + c] = a;
-                }
-            image(M, -1.0, dst + (lag == 1 ? FP_SIMG_V1 : FP_SIMG_V2) * FP_IMG);
+            }
         }
     }
+    // ---- images: Linv (standard, by stage), Linv' (lane-major id = stage), a zero image (id nb), one per edge
+    std::vector<ld> M(nn);
+    double* limg = pool.data() + h->pn_o_limg;
+    for (int i = 0; i < nb; ++i) {
+        const std::vector<ld>& X = Linv[rank[i]];
+        image(X, 1.0, pool.data() + h->pn_o_simg + (size_t)i * FP_IMG);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = X[c * n + r];
+        limage(M, 1.0, limg + (size_t)i * FP_IMGL);
+    }
+    int nimg = nb + 1;                                            // id nb stays all zero
+    struct Edge { int tgt, src, img; };
+    std::vector<Edge> ef, eb;                                     // forward: y_tgt += img y_src ; backward: nu_tgt += img nu_src
+    for (int a = 0; a < nb; ++a)
+        for (int b = a + 1; b < nb; ++b) {
+            if (Um[a][b].empty()) continue;
+            if (nimg + 2 > h->pn_limg_cap) return FMPC_OK;        // cannot happen for the penta-diagonal structure
+            const std::vector<ld>& u = Um[a][b];
+            // forward: -Linv_b U_ab'          (target rank b, source rank a)
+            const std::vector<ld>& Xb = Linv[b];
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                ld t = 0.0L;
+                for (int q = 0; q <= r; ++q) t += Xb[r * n + q] * u[c * n + q];
+                M[r * n + c] = t;
+            }
+            limage(M, -1.0, limg + (size_t)nimg * FP_IMGL);
+            ef.push_back({perm[b], perm[a], nimg++});
+            // backward: -Linv_a' U_ab         (target rank a, source rank b)
+            const std::vector<ld>& Xa = Linv[a];
+            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
+                ld t = 0.0L;
+                for (int q = r; q < n; ++q) t += Xa[q * n + r] * u[q * n + c];
+                M[r * n + c] = t;
+            }
+            limage(M, -1.0, limg + (size_t)nimg * FP_IMGL);
+            eb.push_back({perm[a], perm[b], nimg++});
+        }
+    // ---- schedules: list scheduling of the edges, <= 4 targets per step (one wave pair each), one edge per target and step
+    std::vector<int> sched((size_t)2 * FP_MAX_STEPS(nb) * FP_STEP_INTS, -1);
+    auto schedule = [&](const std::vector<Edge>& E, int* out) -> int {
+        const int ne = (int)E.size();
+        std::vector<int> done_step(nb, -1), pending(nb, 0), estep(ne, -1);
+        for (const Edge& e : E) pending[e.tgt]++;
+        for (int i = 0; i < nb; ++i) if (pending[i] == 0) done_step[i] = 0;       // final before the sweep starts
+        int left = ne, step = 0;
+        while (left > 0) {
+            ++step;
+            if (step > FP_MAX_STEPS(nb)) return -1;
+            int groups = 0; int gt[4];
+            int* row = out + (size_t)(step - 1) * FP_STEP_INTS;
+            std::vector<int> newly;
+            for (int e = 0; e < ne && true; ++e) {
+                if (estep[e] >= 0) continue;
+                const int sd = done_step[E[e].src];
+                if (sd < 0 || sd >= step) continue;                   // source not final before this step
+                bool taken = false;                                   // one edge per target and step
+                for (int q = 0; q < groups; ++q) if (gt[q] == E[e].tgt) taken = true;
+                if (taken || groups == 4) continue;
+                const int gi = groups; gt[groups++] = E[e].tgt;
+                for (int I = 0; I < 2; ++I) {
+                    int* ent = row + (2 * gi + I) * 3;
+                    ent[0] = E[e].tgt; ent[1] = E[e].src; ent[2] = E[e].img;
+                }
+                estep[e] = step; --left;
+                if (--pending[E[e].tgt] == 0) newly.push_back(E[e].tgt);
+            }
+            for (int t : newly) done_step[t] = step;
+        }
+        return step;
+    };
+    h->pn_nsf = schedule(ef, sched.data());
+    h->pn_nsb = schedule(eb, sched.data() + (size_t)FP_MAX_STEPS(nb) * FP_STEP_INTS);
+    if (h->pn_nsf < 0 || h->pn_nsb < 0) return FMPC_OK;
+    if (getenv("FMPC_PANEL_VERBOSE")) fprintf(stderr, "fastmpc panel: nb %d, split %d, %d images, %d forward / %d backward edges, %d / %d steps\n", nb, hs, nimg, (int)ef.size(), (int)eb.size(), h->pn_nsf, h->pn_nsb);
+    if (hipMemcpy(h->pn_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     // ---- the prediction terms of stages 0 and 1 folded into product images: -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
     {
-        double* dst = pool.data() + h->pn_o_simg + (size_t)(nb + 1) * 6 * FP_IMG;
+        double* dst = pool.data() + h->pn_o_simg + (size_t)nb * FP_IMG;
         auto prod = [&](const std::vector<ld>& X, const std::vector<double>& A) {
             for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
                 ld a = 0.0L;
@@ -553,12 +684,11 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
                 M[r * n + c] = a;
             }
         };
-        prod(Linv[0], h->hm_a1); image(M, -1.0, dst);
-        prod(Linv[0], h->hm_a2); image(M, -1.0, dst + FP_IMG);
-        if (nb > 1) { prod(Linv[1], h->hm_a2); image(M, -1.0, dst + 2 * FP_IMG); }
+        prod(Linv[rank[0]], h->hm_a1); image(M, -1.0, dst);
+        prod(Linv[rank[0]], h->hm_a2); image(M, -1.0, dst + FP_IMG);
+        if (nb > 1) { prod(Linv[rank[1]], h->hm_a2); image(M, -1.0, dst + 2 * FP_IMG); }
     }
     // ---- model images
-    const double* bt = h->hm_bt.data();                           // bt[c*n + r] = B[r][c]
     {
         double* dst = pool.data() + h->pn_o_bt;
         for (int J = 0; J < mp / 16; ++J)
@@ -587,16 +717,6 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
     // ---- vectors
     const FpVec V = fp_vec_layout(nb, T);
     double* vec = pool.data() + h->pn_o_vec;
-    double* uc = pool.data() + h->pn_o_ucon;
-    double sa_cu = 0.0;
-    for (int j = 0; j < m; ++j) {
-        const double sp = h->hm_umax[j] - h->hm_umid[j], sm = h->hm_umid[j] - h->hm_umin[j];
-        const double dp = 1.0 / sp, dm = 1.0 / sm;
-        const double hc = k * (dp * dp + dm * dm);
-        const double cu = h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] + k * (dp - dm);
-        uc[j] = cu; uc[mp + j] = 1.0 / (h->hm_R2[j] + hc); uc[2 * mp + j] = hc; uc[3 * mp + j] = h->hm_umid[j];
-        sa_cu += cu * cu;
-    }
     std::vector<double> cbu(n), bu(n), a1x(n), a2x(n);
     for (int a = 0; a < n; ++a) {
         double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -644,7 +764,7 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
     for (int i = 0; i < nb; ++i)
         for (int r = 0; r < n; ++r) {
             ld a = 0.0L;
-            for (int q = 0; q <= r; ++q) a += Linv[i][r * n + q] * (ld)vec[V.ct + i * 32 + q];
+            for (int q = 0; q <= r; ++q) a += Linv[rank[i]][r * n + q] * (ld)vec[V.ct + i * 32 + q];
             vec[V.rt + i * 32 + r] = (double)a;
             if (i >= 2) rp2c += vec[V.cp + i * 32 + r] * vec[V.cp + i * 32 + r];
         }
@@ -740,7 +860,7 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                 h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_cap = 0;
                 if (hipMalloc((void**)&h->pn_gate, (size_t)batch * 2 * sizeof(double)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_epsp, (size_t)npanels * h->T * FP_NP * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_nuws, (size_t)batch * h->nb * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                    hipMalloc((void**)&h->pn_nuws, (size_t)npanels * FP_NP * h->nb * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
                 h->pn_cap = batch;
             }
             FpParams Q;
@@ -748,8 +868,10 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             Q.batch = batch; Q.npanels = npanels; Q.step_ld = fmpc_step_ld(n_newton);
             Q.x0 = x0; Q.x0p = x0_pre; Q.w = w; Q.nu0 = nu0;
             Q.zout = z_out; Q.status = status; Q.iters = iters; Q.step = step;
-            Q.nuws = nu_out ? nu_out : h->pn_nuws;
-            Q.simg = h->pn_pool + h->pn_o_simg; Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
+            Q.nuws = h->pn_nuws; Q.nuout = nu_out;
+            Q.simg = h->pn_pool + h->pn_o_simg; Q.limg = h->pn_pool + h->pn_o_limg;
+            Q.sched_f = h->pn_sched; Q.sched_b = h->pn_sched + (size_t)FP_MAX_STEPS(h->nb) * FP_STEP_INTS; Q.nsf = h->pn_nsf; Q.nsb = h->pn_nsb;
+            Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
             Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
             Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
             Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;

@@ -28,7 +28,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 typedef __attribute__((address_space(3))) double* fd_lds_t;
 typedef const __attribute__((address_space(3))) double* fd_clds_t;
-typedef const FpParams __attribute__((address_space(4))) * FdKP;
+typedef const FpParams* FdKP;          // points at a LOCAL copy of the kernel argument (fields loaded once at kernel entry)
 
 #ifdef FW_TIMING
 __device__ unsigned long long fd_timing[8];
@@ -44,7 +44,8 @@ extern "C" int fmpc_debug_dz_timing(unsigned long long* out) {
 
 __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const FdKP P = (FdKP)__builtin_amdgcn_kernarg_segment_ptr();
+    const FpParams Q = Pv;
+    const FdKP P = &Q;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb, T = P->T, m = P->m, mp = P->mp, batch = P->batch, s = FP_N + m;
     const FdLds L = fd_lds_layout(mp);
@@ -88,38 +89,36 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     double v0[FP_KS], v1[FP_KS], v2[FP_KS];        // nu+_j, nu+_{j+1}, nu+_{j+2} in B-operand layout (problem = lane % 16)
     double nj[2][4], nx[2][4];                      // nu+_j, nu+_T at (problem 4 r + g, row 16 I + lane % 16)
     {
-        const int pb = panel * FP_NP + c16;
-        const double* nb_ = nuws + (size_t)(pb < batch ? pb : batch - 1) * nus + g;
+        // nu+ arrives in panel layout, [stage row][16 problems]: the B-operand loads are 512 contiguous bytes
+        const double* pnl = nuws + (size_t)panel * nus * FP_NP;
         const bool h1 = j + 1 < T, h2 = j + 2 < T && var2, xfl = j + 1 == T && has_xf;
 #pragma unroll
         for (int ks = 0; ks < FP_KS; ++ks) {
             const bool kok = 4 * ks + g < FP_N;
-            const int ko = kok ? 4 * ks : 0;
-            const double t0 = nb_[j * FP_N + ko];
-            const double t1 = nb_[(h1 ? j + 1 : j) * FP_N + ko];
-            const double t2 = nb_[(h2 ? j + 2 : j) * FP_N + ko];
+            const int ko = (kok ? 4 * ks + g : 0) * FP_NP + c16;
+            const double t0 = pnl[j * FP_N * FP_NP + ko];
+            const double t1 = pnl[(h1 ? j + 1 : j) * FP_N * FP_NP + ko];
+            const double t2 = pnl[(h2 ? j + 2 : j) * FP_N * FP_NP + ko];
             v0[ks] = kok ? t0 : 0.0; v1[ks] = (kok && h1) ? t1 : 0.0; v2[ks] = (kok && h2) ? t2 : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pr = panel * FP_NP + 4 * r + g;
-            const double* nr = nuws + (size_t)(pr < batch ? pr : batch - 1) * nus;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 const int row = 16 * I + c16;
                 const int rc = row < FP_N ? row : 0;
-                nj[I][r] = nr[j * FP_N + rc];
-                const double t_ = nr[(xfl ? T : j) * FP_N + rc];
+                nj[I][r] = pnl[(j * FP_N + rc) * FP_NP + 4 * r + g];
+                const double t_ = pnl[((xfl ? T : j) * FP_N + rc) * FP_NP + 4 * r + g];
                 nx[I][r] = xfl ? t_ : 0.0;
             }
-        }
     }
     FD_TICK(1);
-    double* zq[4];
+    double* zq[4]; double* nq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int p = panel * FP_NP + 4 * r + g;         // problem 4 r + g of the panel
         zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + (size_t)j * s + c16;
+        nq[r] = P->nuout ? (p < batch ? P->nuout + (size_t)p * nus : P->dump + (size_t)T * s) + c16 : nullptr;
     }
     double eps2[4] = {0.0, 0.0, 0.0, 0.0};
     // ---- x entries first (they free 30 of the 37 loaded values): d_x = (2Q)^-1 (-dx0 - nu+_j + A1' nu+_{j+1} + A2' nu+_{j+2} [- nu+_T])
@@ -139,7 +138,13 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double zx = xc + iq * (hh[r] - nj[I][r] - nx[I][r]);
-            if (rok) zq[r][m + 16 * I] = zx;            // rows 27..31 of the second row block do not exist
+            if (rok) {                                  // rows 27..31 of the second row block do not exist
+                zq[r][m + 16 * I] = zx;
+                if (nq[r]) {                            // nu_out: one contiguous vector per problem
+                    nq[r][j * FP_N + 16 * I] = nj[I][r];
+                    if (last && has_xf) nq[r][T * FP_N + 16 * I] = nx[I][r];
+                }
+            }
         }
     }
     // ---- u entries: d_u = wc o (B' nu+_j - cu); the MFMAs of the next column block are issued before the

@@ -40,10 +40,12 @@
 #define FP_FN __device__ __forceinline__
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 typedef __attribute__((address_space(3))) double* fp_lds_t;
 typedef const __attribute__((address_space(3))) double* fp_clds_t;
-typedef const FpParams __attribute__((address_space(4))) * FpKP;
+typedef const FpParams* FpKP;          // points at a LOCAL copy of the kernel argument: every field is loaded from the
+                                        // kernarg segment once, at kernel entry (scattered s_load + s_waitcnt pairs cost ~6k cycles per panel)
 
 #ifdef FW_TIMING
 __device__ unsigned long long fp_timing[16];
@@ -62,20 +64,14 @@ __device__ __forceinline__ void fp_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ FpKP fp_uniform(FpKP P) {          // see fw_uniform (fmpc_kernel_wave.hip)
-    const unsigned long long a = (unsigned long long)P;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return (FpKP)(((unsigned long long)hi << 32) | lo);
-}
-
 // LDS map (doubles)
-struct FpLds { int Y, RED, total; };
+struct FpLds { int Y, RED, SCH, total; };
 __host__ __device__ static inline FpLds fp_lds_layout(int nb, int mp) {
     (void)mp;
     FpLds L; int o = 0;
     L.Y = o;   o += (nb * FP_N + 1) * FP_NP;
-    L.RED = o; o += FP_WAVES * FP_NP;               // per wave and problem: ||r_p||^2
+    L.RED = o; o += (FP_WAVES + 1) * FP_NP;         // per wave and problem: ||r_p||^2; then the lower bound of ||r_d||^2
+    L.SCH = o; o += FP_MAX_STEPS(nb) * FP_STEP_INTS; // both sweep schedules (ints; forward rows, then backward rows)
     L.total = o;
     return L;
 }
@@ -130,9 +126,10 @@ __device__ __forceinline__ double fp_sum_g(double v) {         // sum over the 4
 //     Y[i][I] = rt_i[I] - Linv_i[I] w_i        rt_i = Linv_i ct_i (host)
 //               [+ i = 0: -Linv_0 (A1 x0 + A2 x0_pre), i = 1: -Linv_1 A2 x0, as precomputed product images]
 // and ||r_p||^2 per problem: tasks with I = 0 add stage i >= 2 (a host constant without w); the tasks of
-// stages 0 and 1 add the rows of their block (they need A1 x0 + A2 x0_pre itself).
+// stages 0 and 1 add the rows of their block (they need A1 x0 + A2 x0_pre itself).  *rdlb (last wave only): a
+// lower bound of ||r_d(nu0)||^2, per lane.
 template <int HAS_W>
-FP_FN double fp_s1(FpKP P, double* lds_g, int panel) {
+FP_FN double fp_s1(FpKP P, double* lds_g, int panel, double* rdlb) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int T = P->T, nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
@@ -147,34 +144,76 @@ FP_FN double fp_s1(FpKP P, double* lds_g, int panel) {
     const double* rt = P->vec + V.rt;
     const bool var2 = P->var2 != 0;
     double rp2 = 0.0;
-    for (int task = wv; task < 2 * nb; task += FP_WAVES) {
-        const int i = task >> 1, I = task & 1;
+    // (the code of this phase runs once per panel: it is kept small, cold instruction fetch is what it costs)
+#ifdef FW_TIMING
+    unsigned long long _s0 = __builtin_readcyclecounter(), _s1;
+#define FP_STICK(k)
+#else
+#define FP_STICK(k)
+#endif
+    if (wv == FP_WAVES - 1 && P->nu0) {
+        // ||r_d(nu0)||^2 >= its x entries of the last stage, dx0_{T-1} + nu0_{T-1} [+ nu0_T]: no product needed
+        const double* nu = P->nu0 + pc * (size_t)nb * FP_N;
+        const double* dx0 = P->vec + V.dx0 + (T - 1) * 32;
+        double a = 0.0;
+#pragma unroll
+        for (int e = 0; e < FP_KS; ++e) {
+            const bool rok = 4 * e + g < FP_N;
+            const int rc = rok ? 4 * e + g : 0;
+            double x = dx0[rc] + nu[(T - 1) * FP_N + rc];
+            if (P->has_xf) x += nu[T * FP_N + rc];
+            if (rok) a = fma(x, x, a);
+        }
+        *rdlb = a;
+    }
+    FP_STICK(0);
+    if (wv < 4 && (wv >> 1) < nb) {
+        // ---- stages 0 and 1: one (stage, row block) task per wave
+        const int i = wv >> 1, I = wv & 1;
         d4 acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * I + 4 * r + g;
             acc[r] = rt[i * 32 + (row < FP_N ? row : 0)];
         }
-        if (i < 2) {
+        {
             // ---- the prediction terms, and ||r_p||^2 of this stage restricted to the rows of block I
             double xv[FP_KS], xp[FP_KS];               // x0, x0_pre in B-operand layout
 #pragma unroll
             for (int ks = 0; ks < FP_KS; ++ks) {
-                const int k = 4 * ks + g;
-                const double t0 = x0[k < FP_N ? k : 0];
-                const double t1 = x0p ? x0p[k < FP_N ? k : 0] : 0.0;
-                xv[ks] = k < FP_N ? t0 : 0.0; xp[ks] = k < FP_N ? t1 : 0.0;
+                const int k2 = 4 * ks + g;
+                const double t0 = x0[k2 < FP_N ? k2 : 0];
+                const double t1 = x0p ? x0p[k2 < FP_N ? k2 : 0] : 0.0;
+                xv[ks] = k2 < FP_N ? t0 : 0.0; xp[ks] = k2 < FP_N ? t1 : 0.0;
             }
-            const double* ximg = P->simg + (size_t)(nb + 1) * 6 * FP_IMG;      // -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
+            const double* ximg = P->simg + (size_t)nb * FP_IMG + (size_t)I * FP_KS * 64 + lane;   // -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
+            const double* aim = P->aimg + (size_t)I * FP_KS * 64 + lane;
+            // all four images first (one memory latency), then the products
+            double m0[FP_KS], m1[FP_KS], m2[FP_KS], m3[FP_KS];
+            const bool st0 = i == 0, st1 = i == 1 && i < T;
+#pragma unroll
+            for (int ks = 0; ks < FP_KS; ++ks) {
+                m0[ks] = ximg[(st0 ? 0 : 2 * FP_IMG) + ks * 64];            // acts on x0
+                m1[ks] = ximg[FP_IMG + ks * 64];                             // acts on x0_pre (stage 0)
+                m2[ks] = aim[(st0 ? FP_AIMG_A1 : FP_AIMG_A2) * FP_IMG + ks * 64];   // b: A1 x0 (stage 0) | A2 x0 (stage 1)
+                m3[ks] = aim[FP_AIMG_A2 * FP_IMG + ks * 64];                // b: A2 x0_pre (stage 0)
+            }
             d4 bx = {0, 0, 0, 0};
-            if (i == 0) {
-                acc = fp_mm_g(ximg, I, lane, xv, acc);
-                acc = fp_mm_g(ximg + FP_IMG, I, lane, xp, acc);
-                bx = fp_mm_g(P->aimg + FP_AIMG_A1 * FP_IMG, I, lane, xv, bx);
-                if (var2) bx = fp_mm_g(P->aimg + FP_AIMG_A2 * FP_IMG, I, lane, xp, bx);
-            } else if (i < T) {
-                acc = fp_mm_g(ximg + 2 * FP_IMG, I, lane, xv, acc);
-                if (var2) bx = fp_mm_g(P->aimg + FP_AIMG_A2 * FP_IMG, I, lane, xv, bx);
+            if (st0 || st1) {
+#pragma unroll
+                for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(m0[ks], xv[ks], acc);
+                if (st0 || var2) {
+#pragma unroll
+                    for (int ks = 0; ks < FP_KS; ++ks) bx = MFMA64(m2[ks], xv[ks], bx);
+                }
+            }
+            if (st0) {
+#pragma unroll
+                for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(m1[ks], xp[ks], acc);
+                if (var2) {
+#pragma unroll
+                    for (int ks = 0; ks < FP_KS; ++ks) bx = MFMA64(m3[ks], xp[ks], bx);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -196,83 +235,135 @@ FP_FN double fp_s1(FpKP P, double* lds_g, int panel) {
                 if (rok && i >= 2 && I == 0) { const double rp = cp[i * 32 + rc] - wi; rp2 = fma(rp, rp, rp2); }
                 v[e] = rok ? -wi : 0.0;
             }
-            acc = fp_mm_g(P->simg + ((size_t)i * 6 + FP_SIMG_LINV) * FP_IMG, I, lane, v, acc);
-        } else if (HAS_W && i >= 2 && I == 0) {          // the xf row: b_T = 0
+            acc = fp_mm_g(P->simg + (size_t)i * FP_IMG, I, lane, v, acc);
+        } else if (false) {
 #pragma unroll
             for (int e = 0; e < FP_KS; ++e)
                 if (4 * e + g < FP_N) { const double c = cp[i * 32 + 4 * e + g]; rp2 = fma(c, c, rp2); }
         }
         fp_store_d(Y, i, I, g, c16, acc);
     }
+    FP_STICK(1);
+    if (!HAS_W) {
+        // ---- stages >= 2 without w: Y[i][row][problem] = rt_i[row], a broadcast fill.  One load per stage
+        // (lane r holds rt_i[r]), all of a wave's stages requested before the first use: one memory latency.
+        double rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 2 + wv + k * FP_WAVES;
+            rv[k] = rt[(i < nb ? i : 0) * 32 + (lane & 31)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 2 + wv + k * FP_WAVES;
+            if (i < nb) {
+#pragma unroll
+                for (int q = 0; q < FP_KS; ++q) {            // element q*64 + lane of the stage: row 4 q + g, problem c16
+                    const double val = __shfl(rv[k], 4 * q + g, 64);
+                    if (4 * q + g < FP_N) Y[(i * FP_N + 4 * q + g) * FP_NP + c16] = val;
+                }
+            }
+        }
+        for (int i = 2 + wv + 4 * FP_WAVES; i < nb; i += FP_WAVES) {     // horizons beyond 33 stages
+            const double r0 = rt[i * 32 + (lane & 31)];
+#pragma unroll
+            for (int q = 0; q < FP_KS; ++q) {
+                const double val = __shfl(r0, 4 * q + g, 64);
+                if (4 * q + g < FP_N) Y[(i * FP_N + 4 * q + g) * FP_NP + c16] = val;
+            }
+        }
+    } else {
+        // ---- stages >= 2 with w: tasks (stage, row block) dealt to the waves
+        for (int task = 4 + wv; task < 2 * nb; task += FP_WAVES) {
+            const int i = task >> 1, I = task & 1;
+            d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + 4 * r + g;
+                acc[r] = rt[i * 32 + (row < FP_N ? row : 0)];
+            }
+            if (i < T) {
+                double v[FP_KS];
+#pragma unroll
+                for (int e = 0; e < FP_KS; ++e) {
+                    const bool rok = 4 * e + g < FP_N;
+                    const int rc = rok ? 4 * e + g : 0;
+                    const double wi = w[i * FP_N + rc];
+                    if (rok && I == 0) { const double rp = cp[i * 32 + rc] - wi; rp2 = fma(rp, rp, rp2); }
+                    v[e] = rok ? -wi : 0.0;
+                }
+                acc = fp_mm_g(P->simg + (size_t)i * FP_IMG, I, lane, v, acc);
+            } else if (I == 0) {                             // the xf row: b_T = 0
+#pragma unroll
+                for (int e = 0; e < FP_KS; ++e)
+                    if (4 * e + g < FP_N) { const double cc = cp[i * 32 + 4 * e + g]; rp2 = fma(cc, cc, rp2); }
+            }
+            fp_store_d(Y, i, I, g, c16, acc);
+        }
+    }
+    FP_STICK(2);
     return rp2;
 }
 
 // ------------------------------------------------------------------------------------------------
-// S2 / S4: the serial sweeps.  Waves 0..3: row block I = wave & 1, term = wave >> 1; loop index q, `nq` barriers.
-//   forward  (BWD = 0): stage s = q + 1:      term 0: Y[s] += -W1_s Y[s-1] ;  term 1: Y[s+1] += -W2_{s+1} Y[s-1]
-//   backward (BWD = 1): stage s = nb - 2 - q: term 0: Y[s] += -V1_s Y[s+1] ;  term 1: Y[s-1] += -V2_{s-1} Y[s+1]
-// The image loads are unconditional (slot nb of the image buffer is all zero) and prefetched one step ahead
-// into two alternating register sets: the compiler's s_waitcnt placement gives up on conditional loads.  The
-// barrier orders LDS only, so the prefetches stay in flight across it.
-// Waves 4..7 only take part in the barriers; backward they also write the nu+ stage that became final in the
-// previous step to HBM (layout of nu_out: one contiguous vector per problem).
-template <int BWD>
-FP_FN void fp_sweep(FpKP P, double* lds_g, int panel, int nq) {
+// S2 / S4: the sweeps, executed from a host-built schedule (fmpc_panel.h; copied to LDS at kernel start): per
+// step every wave has at most one edge  Y[tgt][I] += IMG Y[src]  (wave 2p + I: row block I of the step's p-th
+// target); one LDS-only barrier per step.
+// A global load takes 1-2 k cycles here, more than a step should: nothing a step needs may have been requested
+// less than TWO steps earlier.  The images are therefore prefetched two steps ahead into three rotating register
+// sets, with unconditional loads (id nb is a zero image; the compiler's s_waitcnt placement gives up on
+// conditional ones) in a straight-line loop body (the step count is padded to a multiple of 3 with empty
+// steps), so that the sets rotate by position and are never copied.
+FP_FN void fp_sweep(FpKP P, double* lds_g, int row0, int nsteps) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb;
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_lds_t Y = (fp_lds_t)lds_g + L.Y;
-    if (wv >= 4) {
-        const int p = panel * FP_NP + c16;
-        double* nup = (p < P->batch ? P->nuws + (size_t)p * nb * FP_N : P->dump) + g;
-        for (int q = 0; q < nq; ++q) {
-            const int j = nb - 1 - q;                       // final since the previous step
-            if (BWD && j >= 0 && ((q & 3) == wv - 4)) {
-                double v[FP_KS];
-                fp_load_b(Y, j, g, c16, v);
-#pragma unroll
-                for (int ks = 0; ks < FP_KS; ++ks)
-                    if (4 * ks + g < FP_N) nup[j * FP_N + 4 * ks] = v[ks];
-            }
-            fp_barrier();
+    const int I = wv & 1;
+    const double* limg = P->limg + (size_t)(I * 64 + lane) * 8;
+    const __attribute__((address_space(3))) int* mine = (const __attribute__((address_space(3))) int*)((fp_lds_t)lds_g + L.SCH) + row0 * FP_STEP_INTS + wv * 3;
+    struct Ent { int t, s, i; };
+    auto entry = [&](int q) {                               // wave-uniform
+        Ent e = {0, 0, -1};
+        if (q < nsteps) {
+            const __attribute__((address_space(3))) int* r = mine + q * FP_STEP_INTS;
+            e.t = __builtin_amdgcn_readfirstlane(r[0]); e.s = __builtin_amdgcn_readfirstlane(r[1]);
+            e.i = __builtin_amdgcn_readfirstlane(r[2]);
         }
-        return;
-    }
-    const int I = wv & 1, term = wv >> 1;
-    const double* simg = P->simg + (size_t)((BWD ? FP_SIMG_V1 : FP_SIMG_W1) + term) * FP_IMG + (size_t)I * FP_KS * 64 + lane;
-    auto stage = [&](int q) { return BWD ? nb - 2 - q : q + 1; };
-    auto target = [&](int q) {
-        const int s = stage(q);
-        if (BWD ? (s < 0) : (s > nb - 1)) return -1;
-        const int t = BWD ? s - term : s + term;
-        return (t >= 0 && t < nb) ? t : -1;
+        return e;
     };
-    auto load_img = [&](int q, double a[FP_KS]) {
-        const int t = target(q);
-        const double* s = simg + (size_t)(t < 0 ? nb : t) * 6 * FP_IMG;
-#pragma unroll
-        for (int ks = 0; ks < FP_KS; ++ks) a[ks] = s[ks * 64];
+    auto load_img = [&](int id, double a[FP_KS]) {
+        const d2* s = (const d2*)(limg + (size_t)(id < 0 ? nb : id) * FP_IMGL);
+        const d2 q0 = s[0], q1 = s[1], q2 = s[2], q3 = s[3];            // 4 x 16 bytes: the lane's 7 values
+        a[0] = q0[0]; a[1] = q0[1]; a[2] = q1[0]; a[3] = q1[1]; a[4] = q2[0]; a[5] = q2[1]; a[6] = q3[0];
     };
-    auto step = [&](int q, const double a[FP_KS]) {
-        const int t = target(q);
-        if (t >= 0) {
-            const int s = stage(q);
+    // executes entry e with image a; requests the image of the entry two steps later into a2
+    auto step = [&](const Ent& e, const double a[FP_KS], const Ent& e2, double a2[FP_KS]) {
+        if (e.i >= 0) {
             double v[FP_KS];
-            fp_load_b(Y, BWD ? s + 1 : s - 1, g, c16, v);
-            d4 acc = fp_load_d(Y, t, I, g, c16);
+            fp_load_b(Y, e.s, g, c16, v);
+            d4 acc = fp_load_d(Y, e.t, I, g, c16);
+            __builtin_amdgcn_sched_barrier(0);
+            load_img(e2.i, a2);                            // issued in the shadow of the LDS latency
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(a[ks], v[ks], acc);
-            fp_store_d(Y, t, I, g, c16, acc);
+            fp_store_d(Y, e.t, I, g, c16, acc);
+        } else {
+            load_img(e2.i, a2);
         }
         fp_barrier();
     };
-    double a0[FP_KS], a1[FP_KS];
-    load_img(0, a0);
-    for (int q = 0; q < nq; q += 2) {
-        load_img(q + 1, a1);
-        step(q, a0);
-        load_img(q + 2, a0);
-        step(q + 1, a1);
+    double a0[FP_KS], a1[FP_KS], a2[FP_KS];
+    Ent e0 = entry(0), e1 = entry(1), e2 = entry(2);
+    load_img(e0.i, a0); load_img(e1.i, a1);
+    for (int q = 0; q < nsteps; q += 3) {
+        step(e0, a0, e2, a2);
+        e0 = entry(q + 3);
+        step(e1, a1, e0, a0);
+        e1 = entry(q + 4);
+        step(e2, a2, e1, a1);
+        e2 = entry(q + 5);
     }
 }
 
@@ -283,13 +374,15 @@ FP_FN void fp_s3(FpKP P, double* lds_g) {
     const int nb = P->nb;
     const FpLds L = fp_lds_layout(nb, P->mp);
     const fp_lds_t Y = (fp_lds_t)lds_g + L.Y;
-    const double* simg = P->simg + FP_SIMG_LINVT * FP_IMG + lane;
+    const double* limg = P->limg + (size_t)lane * 8;              // image id = stage: Linv_i'
     auto ld = [&](int i, double a[2][FP_KS]) {
-        const double* im = simg + (size_t)(i < nb ? i : nb - 1) * 6 * FP_IMG;
+        const double* im = limg + (size_t)(i < nb ? i : nb - 1) * FP_IMGL;
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int ks = 0; ks < FP_KS; ++ks) a[I][ks] = im[(I * FP_KS + ks) * 64];
+        for (int I = 0; I < 2; ++I) {
+            const d2* s = (const d2*)(im + I * 64 * 8);
+            const d2 q0 = s[0], q1 = s[1], q2 = s[2], q3 = s[3];
+            a[I][0] = q0[0]; a[I][1] = q0[1]; a[I][2] = q1[0]; a[I][3] = q1[1]; a[I][4] = q2[0]; a[I][5] = q2[1]; a[I][6] = q3[0];
+        }
     };
     auto comp = [&](int i, const double a[2][FP_KS]) {
         if (i >= nb) return;
@@ -314,13 +407,19 @@ FP_FN void fp_s3(FpKP P, double* lds_g) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const FpKP P = (FpKP)__builtin_amdgcn_kernarg_segment_ptr();
+    const FpParams Q = Pv;
+    const FpKP P = &Q;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb, T = P->T, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
     if (blockIdx.x == 0 && tid == 0 && P->handed) *P->handed = 0;
     // a finite panel: pad rows are read (and multiplied by zero image columns)
     for (int i = tid; i < (nb * FP_N + 1) * FP_NP; i += FP_THREADS) lds[L.Y + i] = 0.0;
+    {   // both sweep schedules, packed: forward rows 0 .. nsf-1, backward rows nsf .. nsf+nsb-1
+        int* sch = (int*)(lds + L.SCH);
+        for (int i = tid; i < P->nsf * FP_STEP_INTS; i += FP_THREADS) sch[i] = P->sched_f[i];
+        for (int i = tid; i < P->nsb * FP_STEP_INTS; i += FP_THREADS) sch[P->nsf * FP_STEP_INTS + i] = P->sched_b[i];
+    }
     __syncthreads();
 #ifdef FW_TIMING
     unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -329,43 +428,40 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
 #define FP_TICK(k)
 #endif
     double* red = lds + L.RED;
-    const int nqf = nb & ~1;                                  // forward: stages 1 .. nb-1, nb-1 steps rounded up to even
-    const int nqb = (nb + 1) & ~1;                            // backward: stages nb-2 .. 0 and the write-out of nu+_0 one step later
     const bool has_w = P->w != nullptr;
     for (int panel = blockIdx.x; panel < P->npanels; panel += gridDim.x) {
-        double rp2 = has_w ? fp_s1<1>(P, lds, panel) : fp_s1<0>(P, lds, panel);
+        double rdl = 0.0;
+        double rp2 = has_w ? fp_s1<1>(P, lds, panel, &rdl) : fp_s1<0>(P, lds, panel, &rdl);
+        FP_TICK(4);
         rp2 = fp_sum_g(rp2);
-        if (g == 0) red[wv * FP_NP + c16] = rp2;
+        rdl = fp_sum_g(rdl);
+        if (g == 0) { red[wv * FP_NP + c16] = rp2; if (wv == FP_WAVES - 1) red[FP_WAVES * FP_NP + c16] = rdl; }
         __syncthreads();
         FP_TICK(0);
-        fp_sweep<0>(P, lds, panel, nqf);
-        FP_TICK(1);
-        fp_s3(P, lds);
-        __syncthreads();
-        FP_TICK(2);
-        fp_sweep<1>(P, lds, panel, nqb);
-        FP_TICK(3);
         // ---- per problem: ||r_p||^2 and a lower bound of rho^2 (exact without nu0) for the step-length decision
         if (tid < FP_NP) {
             const int p = panel * FP_NP + tid;
             double s = has_w ? 0.0 : P->rp2c;                  // stages >= 2 without w: r_p,i = cp_i
             for (int w = 0; w < FP_WAVES; ++w) s += red[w * FP_NP + tid];
-            double rd = P->rd2_0;                              // ||r_d||^2 at nu = 0
-            if (P->nu0 && p < batch) {
-                // ||r_d(nu0)||^2 >= its x entries of the last stage: dx0_{T-1} + nu0_{T-1} [+ nu0_T], no product needed
-                const FpVec V = fp_vec_layout(nb, T);
-                const double* nu = P->nu0 + (size_t)p * nb * FP_N;
-                rd = 0.0;
-                for (int r = 0; r < FP_N; ++r) {
-                    double x = P->vec[V.dx0 + (T - 1) * 32 + r] + nu[(T - 1) * FP_N + r];
-                    if (P->has_xf) x += nu[T * FP_N + r];
-                    rd = fma(x, x, rd);
-                }
-            }
+            const double rd = P->nu0 ? red[FP_WAVES * FP_NP + tid] : P->rd2_0;
             if (p < batch) { P->gate[2 * p] = s; P->gate[2 * p + 1] = s + rd; }
         }
-        __syncthreads();
-        FP_TICK(4);
+        fp_sweep(P, lds, 0, P->nsf);
+        FP_TICK(1);
+        fp_s3(P, lds);
+        fp_barrier();
+        FP_TICK(2);
+        fp_sweep(P, lds, P->nsf, P->nsb);
+        FP_TICK(3);
+        {   // ---- nu+ to HBM in PANEL layout ([stage row][16 problems], as it sits in LDS): full-rate, fully
+            // coalesced stores.  The d_z kernel reads it back and produces the per-problem nu_out if asked to.
+            const int nrow = nb * FP_N * FP_NP;
+            double* dst = P->nuws + (size_t)panel * nrow;
+            const double* src = lds + L.Y;
+            for (int e = tid; e < nrow; e += FP_THREADS) dst[e] = src[e];
+        }
+        fp_barrier();                                          // the panel may be reused
+        FP_TICK(5);
     }
 #ifdef FW_TIMING
     if ((tid & 63) == 0) for (int q = 0; q < 8; ++q) atomicAdd(&fp_timing[q], _ka[q]);

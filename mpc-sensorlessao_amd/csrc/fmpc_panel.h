@@ -14,13 +14,17 @@
 // The same image is a valid B operand of the TRANSPOSED product (panel registers as A operand, problems as
 // rows): lane (g, c) then holds M'[4 ks + g][16 I + c].
 
-// per-stage sweep images, [stage][6][FP_IMG]
-#define FP_SIMG_LINV 0                  //  Linv_i
-#define FP_SIMG_W1 1                    // -Linv_i U_{i-1,i}'
-#define FP_SIMG_W2 2                    // -Linv_i U_{i-2,i}'
-#define FP_SIMG_LINVT 3                 //  Linv_i'
-#define FP_SIMG_V1 4                    // -Linv_i' U_{i,i+1}
-#define FP_SIMG_V2 5                    // -Linv_i' U_{i,i+2}
+// FpParams::simg: Linv_i per stage (standard layout; S1 with w), then -Linv_0 A1, -Linv_0 A2, -Linv_1 A2.
+// FpParams::limg: LANE-MAJOR images, FP_IMGL doubles each, element [(I*64 + l)*8 + ks]: the 7 (+1 pad) values of a
+// lane are contiguous, 4 x 16-byte loads instead of 7 x 8-byte ones (the sweeps are bound by the ISSUE of their
+// operand loads).  Image id i < nb: Linv_i'; id nb: all zero; then one image per edge of the two sweeps.
+#define FP_IMGL (2 * 64 * 8)
+// Sweep schedules (host: fmpc_upload_panel).  The block Cholesky factor of Y is computed on the host in an
+// elimination order chosen for a short dependency chain; a sweep is then a list of EDGES  y_tgt += IMG y_src
+// executed in steps with one workgroup barrier per step.  Per step and wave (8 waves; wave 2p + I does row
+// block I of the p-th target of the step): one entry {target stage, source stage, image id} (id < 0: none).
+#define FP_STEP_INTS (8 * 3)
+#define FP_MAX_STEPS(nb) (2 * (nb) + 4)
 // model images, [5][FP_IMG]
 #define FP_AIMG_A1 0
 #define FP_AIMG_A2 1
@@ -62,9 +66,11 @@ struct FpParams {
     int batch, npanels, step_ld;
     const double* x0; const double* x0p; const double* w; const double* nu0;
     double* zout; int* status; int* iters; double* step;
-    double* nuws;                       // nu+ (the caller's nu_out or a workspace): written by the panel kernel, read by d_z
-    const double* simg;                 // sweep images (k-dependent): nb + 1 stage slots, the last all zero,
-                                        // then -Linv_0 A1, -Linv_0 A2, -Linv_1 A2 (prediction terms of b_0, b_1)
+    double* nuws;                       // nu+ in panel layout [panel][stage row][16]: written by the panel kernel, read by d_z
+    double* nuout;                      // the caller's nu_out (may be NULL): written by d_z
+    const double* simg;                 // Linv per stage (standard layout), then -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
+    const double* limg;                 // lane-major images: Linv' per stage, zero, edges
+    const int* sched_f; const int* sched_b; int nsf, nsb;        // sweep schedules and their step counts
     const double* btimg;                // B' images, [mp/16][7][64]
     const double* aimg;                 // model images
     const double* vec;                  // FpVec

@@ -33,10 +33,10 @@ if nw == 1 and hasattr(lib, "fmpc_debug_panel_timing"):
     lib.fmpc_debug_panel_timing(out)
     npan = (B + 15) // 16
     nwav = min(npan, 256) * 8
-    tot = sum(out[i] for i in range(5))
+    tot = sum(out[i] for i in range(6))
     if tot:
         print("panel kernel (dual solve), per-wave-average cycles (%d panels):" % npan)
-        for nm, i in [("S1 Linv rhs", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep + nu out", 3), ("gate values", 4)]:
+        for nm, i in [("S1 own work (before barrier)", 4), ("S1 barrier wait", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep", 3), ("nu+ write-out", 5)]:
             print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwav, 100.0 * out[i] / tot))
         print("  total %.0f cycles/wave" % (tot / nwav))
 if nw == 1 and hasattr(lib, "fmpc_debug_dz_timing"):
