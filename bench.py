@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--n-newton", type=int, default=N_NEWTON)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the general-path / budget-5 variants")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of one step instead of launching from Python "
+                                                          "(measured slower here: the step is GPU-bound, not launch-bound)")
     args = ap.parse_args()
 
     import numpy as np
@@ -137,7 +139,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def run(handle, n_newton, steps, warmup):
+    def run(handle, n_newton, steps, warmup, use_graph=False):
         """W warm-up steps, then K timed steps between barriers; per-launch kernel time from HIP
         events recorded on the launch stream (torch's current stream is passed to the library)."""
         def step(ev=None):
@@ -156,22 +158,37 @@ def main():
         for _ in range(warmup):
             step()
         sync()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # per-launch device time of the solve (HIP events on the launch stream), outside the timed region
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, min(steps, 20)))]
+        for ev in evs:
+            step(ev)
+        sync()
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        graph = None
+        if use_graph and world == 1:
+            # the step is launch-bound: capture its launches once (hipGraph) and replay them
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            sync()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(evs[i])
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         iters_cpu = it.cpu().numpy()
         assert (st.cpu().numpy() >= 0).all(), "solver reported errors"
         return elapsed, kern_ms, iters_cpu
 
-    elapsed, kern_ms, iters_cpu = run(h, args.n_newton, args.steps, args.warmup)
+    elapsed, kern_ms, iters_cpu = run(h, args.n_newton, args.steps, args.warmup, use_graph=args.graph)
     shared = os.environ.get("FMPC_NO_SHARED", "0") != "1" and os.environ.get("FMPC_FORCE_GENERIC", "0") != "1"
     units_first = float((iters_cpu >= 1).sum())           # first Newton steps (shared factor when enabled)
     units_later = float(iters_cpu.sum()) - units_first    # later steps: per-problem factorisation
@@ -231,7 +248,9 @@ def main():
                        "newton_iters_per_problem": float(iters_cpu.sum()) / B,
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)"
                                             if shared else "per problem",
-                       "gather": "u0 all-gather (RCCL)" if world > 1 else "none (1 GPU)"},
+                       "gather": "u0 all-gather (RCCL)" if world > 1 else "none (1 GPU)",
+                       "launch": "hipGraph replay of one step (solve + first-move unpack)" if (world == 1 and args.graph)
+                                 else "one Python call per step"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "fmpc_newton_wave<27>", "kernel_ms": kern_ms,

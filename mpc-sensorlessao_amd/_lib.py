@@ -21,6 +21,11 @@ FMPC_E_NOT_PD_SCHUR = -5
 FMPC_E_HIP = -6
 FMPC_E_ALLOC = -7
 FMPC_E_NO_DEVICE = -8
+# fmpc_last_dispatch paths
+FMPC_PATH_GENERIC = 0
+FMPC_PATH_WAVE = 1
+FMPC_PATH_SHARED = 2
+FMPC_PATH_PANEL = 3
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

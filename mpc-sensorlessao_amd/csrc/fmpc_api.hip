@@ -39,7 +39,8 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr);
+                            const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
+                            const double* nuws = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -848,9 +849,10 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             }
             mode = 1;
         }
-        if (mode == 1 && h->pn_enabled && h->pn_valid && max_iter == 1) {
-            // the reference's own call (one Newton step from the cold start): 16-problem panels on the matrix
-            // cores; problems whose step-length / exit decision is not clear-cut go to the exact path below
+        if (mode == 1 && h->pn_enabled && h->pn_valid) {
+            // first Newton step from the cold start (the reference's own call has just this one): 16-problem panels
+            // on the matrix cores; the exact-path launch below decides every problem's step length, redoes the
+            // problems whose decision is not clear-cut and runs the remaining iterations of the budget
             const int npanels = (batch + FP_NP - 1) / FP_NP;
             if ((size_t)batch > h->pn_cap) {
                 (void)hipDeviceSynchronize();
@@ -891,7 +893,7 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                  z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                                  h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
-                                 h->pn_gate, h->pn_epsp, h->pn_cnt);
+                                 h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws);
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }

@@ -129,7 +129,7 @@ __device__ __forceinline__ double fp_sum_g(double v) {         // sum over the 4
 // stages 0 and 1 add the rows of their block (they need A1 x0 + A2 x0_pre itself).  *rdlb (last wave only): a
 // lower bound of ||r_d(nu0)||^2, per lane.
 template <int HAS_W>
-FP_FN double fp_s1(FpKP P, double* lds_g, int panel, double* rdlb) {
+FP_FN double fp_s1(FpKP P, double* lds_g, int panel, double* rdlb, unsigned long long* tk) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c16 = lane & 15;
     const int T = P->T, nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
@@ -147,7 +147,7 @@ FP_FN double fp_s1(FpKP P, double* lds_g, int panel, double* rdlb) {
     // (the code of this phase runs once per panel: it is kept small, cold instruction fetch is what it costs)
 #ifdef FW_TIMING
     unsigned long long _s0 = __builtin_readcyclecounter(), _s1;
-#define FP_STICK(k)
+#define FP_STICK(k) do { _s1 = __builtin_readcyclecounter(); tk[k] += _s1 - _s0; _s0 = _s1; } while (0)
 #else
 #define FP_STICK(k)
 #endif
@@ -431,7 +431,11 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
     const bool has_w = P->w != nullptr;
     for (int panel = blockIdx.x; panel < P->npanels; panel += gridDim.x) {
         double rdl = 0.0;
-        double rp2 = has_w ? fp_s1<1>(P, lds, panel, &rdl) : fp_s1<0>(P, lds, panel, &rdl);
+        unsigned long long tk[3] = {0, 0, 0};
+        double rp2 = has_w ? fp_s1<1>(P, lds, panel, &rdl, tk) : fp_s1<0>(P, lds, panel, &rdl, tk);
+#ifdef FW_TIMING
+        if (lane == 0) { atomicAdd(&fp_timing[8], tk[0]); atomicAdd(&fp_timing[9], tk[1]); atomicAdd(&fp_timing[10], tk[2]); }
+#endif
         FP_TICK(4);
         rp2 = fp_sum_g(rp2);
         rdl = fp_sum_g(rdl);

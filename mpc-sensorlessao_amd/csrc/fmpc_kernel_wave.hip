@@ -131,6 +131,7 @@ struct FwParams {
     // lower bound of rho^2 (gate), per (panel, stage, problem) the partial ||e||^2 (epsp).  Non-null: decide the
     // step length of every problem first and solve only those whose decision is not clear-cut.
     const double* gate; const double* epsp; int* handed;
+    const double* nuws;             // nu+ of the panel kernels, panel layout [panel][stage row][16]
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -1430,7 +1431,10 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         int need = 0;
         for (int rnd = 0; rnd < rounds; ++rnd) {
             const int q = wave_g + rnd * nwaves;
-            if (q < batch && !fw_panel_decide(P, q, true)) { need = 1; if (lane == 0 && P->handed) atomicAdd(P->handed, 1); }
+            if (q < batch) {
+                if (!fw_panel_decide(P, q, true)) { need = 1; if (lane == 0 && P->handed) atomicAdd(P->handed, 1); }
+                else if (P->max_iter > 1) need = 1;          // accepted first step, further iterations follow here
+            }
         }
         if (!__syncthreads_or(need)) return;
     }
@@ -1459,7 +1463,9 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
     for (int rnd = 0; rnd < rounds; ++rnd) {
         const int p = wave_g + rnd * nwaves;
-        const bool active = p < batch && !(panel_mode && fw_panel_decide(P, p, false));
+        // panel mode: `accepted` = the panel kernels' first Newton step stands (z, nu+ are in place)
+        const bool accepted = p < batch && panel_mode && fw_panel_decide(P, p, false);
+        const bool active = p < batch && !(accepted && max_iter <= 1);
         if (cold_mode) {
             // [cu | hc | wc | ubar] into LDS for the cold step's epilogue.  The region overlaps the per-wave
             // tiles of the general path, so wait until every wave has left the previous round.
@@ -1475,7 +1481,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         if (cold_mode) {
             double rho2 = 0.0;
             int go = 0;
-            if (active) {
+            if (active && !accepted) {
                 fw_phase_init<N>(P, p, 0);
                 FW_KTICK(0);
                 fw_cold_resid<N>(P, p, lds, red);
@@ -1522,6 +1528,17 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                 if (P->step && lane == 0 && P->step_ld > 0) P->step[(size_t)p * P->step_ld] = t;
                 nsteps = 1;
                 FW_KTICK(5);
+            }
+            if (active && accepted) {
+                // continue after the panel kernels' step: b, the step record, and nu+ from the panel workspace
+                fw_phase_init<N>(P, p, 0);
+                const FwView<N> W(P, p);
+                const int nbn = W.nb * N;
+                const double* src = P->nuws + ((size_t)(p >> 4) * nbn) * 16 + (p & 15);
+                for (int idx = lane; idx < nbn; idx += 64) W.nu[idx] = src[(size_t)idx * 16];
+                if (P->step && lane == 0 && P->step_ld > 0) P->step[(size_t)p * P->step_ld] = 1.0;
+                fw_mem_fence();
+                nsteps = 1;
             }
             it0 = 1;
         } else if (active) {
@@ -1641,10 +1658,10 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const double* gate, const double* epsp, int* handed) {
+                            const double* gate, const double* epsp, int* handed, const double* nuws) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
-    P.gate = gate; P.epsp = epsp; P.handed = handed;
+    P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws;
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;

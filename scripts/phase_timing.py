@@ -39,6 +39,7 @@ if nw == 1 and hasattr(lib, "fmpc_debug_panel_timing"):
         for nm, i in [("S1 own work (before barrier)", 4), ("S1 barrier wait", 0), ("S2 forward sweep", 1), ("S3 Linv' y", 2), ("S4 backward sweep", 3), ("nu+ write-out", 5)]:
             print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwav, 100.0 * out[i] / tot))
         print("  total %.0f cycles/wave" % (tot / nwav))
+        print("  S1 detail per wave: setup + lower bound of ||r_d|| %.0f, stages 0/1 %.0f, stages >= 2 %.0f" % tuple(out[8 + i] / nwav for i in range(3)))
 if nw == 1 and hasattr(lib, "fmpc_debug_dz_timing"):
     lib.fmpc_debug_dz_timing(out)
     nwv = out[7] or 1
