@@ -222,6 +222,17 @@ def main():
                             "newton_iters_per_problem": float(i5.sum()) / B}
 
     if rank == 0:
+        path, handed = h.last_dispatch()
+        if path == pkg.FMPC_PATH_PANEL:
+            kernel_name = "fmpc_cold_panel + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed
+            nbk = T                                            # no terminal row in the bench model
+            mfma = 2 * (2 * nbk - 3) * 14 + nbk * 14 + T * (7 * ((m + 15) // 16) + 28) + 63    # per 16-problem panel
+            ex_fl = mfma * 2048.0 / 16.0
+            executed = {"mfma_flops_per_unit": ex_fl, "tflops": ex_fl * units_first / (kern_ms * 1e-3) / 1e12,
+                        "frac_of_peak": ex_fl * units_first / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        else:
+            kernel_name = "fmpc_newton_wave<27>" if path != pkg.FMPC_PATH_GENERIC else "fmpc_newton_generic"
+            executed = None
         flops = f_first * units_first + flops_per_problem_factor(n, m, T) * units_later
         byts = b_first * units_first + bytes_streamed_factor(n, m, T) * units_later
         ach_tf = flops / (kern_ms * 1e-3) / 1e12
@@ -253,10 +264,15 @@ def main():
                                  else "one Python call per step"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "fmpc_newton_wave<27>", "kernel_ms": kern_ms,
+                         "kernel": kernel_name, "kernel_ms": kern_ms,
                          "flops_per_unit": f_first, "units_per_launch": units_first + units_later,
-                         "note": "shared-factor regime: 1.60 MFLOP and 48 KB per unit (SURVEY 8d); the per-problem "
-                                 "factor path is priced at 11.64 MFLOP under extra.general_path"},
+                         "executed": executed,
+                         "note": "achieved = SURVEY 8d's algorithmic figure for the shared-factor regime (1.60 MFLOP and 48 KB per "
+                                 "unit) x units / device time of one solve (all its kernels, HIP events on the launch stream); "
+                                 "`executed` is what the panel kernels actually issue on the matrix cores (padded 16x16x4 "
+                                 "tiles), less than the algorithmic figure because the constant primal start lets the step "
+                                 "skip the nu-dependent residual products; the per-problem factor path is priced at 11.64 MFLOP "
+                                 "under extra.general_path"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_unit": b_first},
         }

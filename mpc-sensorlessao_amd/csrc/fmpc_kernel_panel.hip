@@ -25,10 +25,13 @@
 // One 512-thread workgroup per panel, one workgroup per CU.  LDS: the rhs -> y -> nu+ panel
 // ((27 nb + 1) x 16 doubles, 107 KB).  Phases:
 //   S1  stage-parallel: Y[i] = Linv_i rhs_i                         (8 waves; no product at all without w)
-//   S2  forward sweep, serial over the stages: 4 waves = (row block) x (lag-1 | lag-2 term), 7 MFMAs each per
-//       stage, one LDS-only barrier per stage
+//   S2  forward sweep: per step up to 4 edges  Y[t] += IMG Y[s]  (a wave pair = the two row blocks of a target,
+//       7 MFMAs per wave), one LDS-only barrier per step
 //   S3  stage-parallel: Y[i] = Linv_i' y_i                          (8 waves)
-//   S4  backward sweep like S2; the idle waves write every finished nu+_j to HBM
+//   S4  backward sweep like S2; then nu+ leaves for HBM in panel layout (full-rate coalesced stores)
+// S2 and S4 execute a host-built SCHEDULE (fmpc_upload_panel in fmpc_api.hip): the factor of Y is computed on the
+// host in a twisted elimination order (two independent chains that meet in the middle of the horizon), so the
+// device only sees operator images and a list of edges per step.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fmpc_device.h"
