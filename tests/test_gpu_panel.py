@@ -62,6 +62,23 @@ def test_panel_step_matches_oracle_and_exact_path(pkg, gpu, T, batch, xf, use_w,
     hp.close(); hw.close()
 
 
+def test_panel_step_var1_and_odd_actuator_count(pkg, gpu):
+    """VAR(1) (no lag-2 blocks: Y is block-tridiagonal, the schedule has fewer edges) and m not a multiple of 16
+    (partial last column block of B')."""
+    for var_order, m in [(1, 144), (2, 97)]:
+        md = pkg.synthetic.make_model(27, m, 12, var_order=var_order)
+        data = pkg.synthetic.make_replay_batch(md, r=4, steps=19)
+        hp = handle_from_model(pkg, md)
+        z, info = hp.solve(data["x0"], data["x0_pre"] if var_order == 2 else None, None, nu0=data["nu0"], n_newton=1,
+                           k=1e-2, return_info=True)
+        assert hp.last_dispatch() == (pkg.FMPC_PATH_PANEL, 0)
+        zo, nuo, ito, sto, _ = oracle_batch(md, data, 1, 1e-2)
+        assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
+        assert max(rel_err(z[p], zo[p]) for p in range(19)) <= TOL_Z
+        assert max(rel_err(info["nu"][p], nuo[p]) for p in range(19)) <= TOL_NU
+        hp.close()
+
+
 def test_unclear_step_length_goes_to_the_exact_path(pkg, gpu):
     """Tight bounds: the barrier is active at the cold start, ||e||^2 is not small against rho^2, and the panel
     path must not decide the step length: every problem is redone by the exact path (bit-identical to it)."""
