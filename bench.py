@@ -216,6 +216,28 @@ def main():
                                              "unit": "GB/s", "frac": bs / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "bytes_per_unit": bytes_streamed_factor(n, m, T)}}
         hg.close()
+        # closed loop (SURVEY 8d C2 "sequential closed loop (latency)" and C3 "512 realisations"): loop inputs +
+        # solve + first-move unpack per step, all device-resident (mpc-sensorlessao_amd/closed_loop.py)
+        cl = {}
+        for R_, nsteps_ in ((1, 300), (512, 100)):
+            a_np = np.stack([pkg.synthetic.make_realisation(model, r=r_, steps=nsteps_)[1:nsteps_ + 1] for r_ in range(min(R_, 8))], axis=1)
+            a_np = np.ascontiguousarray(np.tile(a_np, (1, (R_ + a_np.shape[1] - 1) // a_np.shape[1], 1))[:, :R_])
+            a_t = torch.from_numpy(a_np).to(dev)
+            loop = pkg.ClosedLoop(h, R_, n_newton=args.n_newton, k=K_BAR)
+            for s_ in range(5):
+                loop.step(a_t[s_])
+            torch.cuda.synchronize(dev)
+            loop = pkg.ClosedLoop(h, R_, n_newton=args.n_newton, k=K_BAR)
+            t0 = time.perf_counter()
+            for s_ in range(nsteps_):
+                loop.step(a_t[s_])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            assert int(loop.status.abs().sum()) == 0
+            cl["realisations_%d" % R_] = {"value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3,
+                                          "sequential_steps": nsteps_}
+        extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
+                                         "depends on the previous first move, so only realisations batch", **cl)
         e5, k5, i5 = run(h, 5, ksteps, 2)
         extra["budget5"] = {"what": "Newton budget 5 with the reference's exit test (test_fast_mpc.m:53,59)",
                             "value": B * ksteps / e5, "unit": "MPC steps/s", "kernel_ms": k5,

@@ -150,6 +150,22 @@ int fmpc_solve_once(int n, int m, int T, int var_order,
                     double* x_opt, int* iters);
 
 /*
+ * Coefficient-space closed loop: the steps either side of the solver in the reference's simulation loop
+ * (README.md:482-497, 589-590; M1, M2 of MPC_DesignMatrices, main.mlx "System Matrix design").  From the
+ * turbulence coefficients a_k of the current step and the two previous first moves it produces the inputs of
+ * the next solve:
+ *     x0     = a_k + B u1                  residual after the mirror's correction ad_cor = B u_prev (u1 NULL: a_k)
+ *     x0_pre = x0_last                     (NULL: zeros, the first step)
+ *     w      = b_ref = -M1 B u1 - M2 B u2  (a NULL input drops its term: steps 1 and 2 of the loop)
+ * Device pointers, column-major: a_k, x0_last, x0, x0_pre n x batch; u1, u2 m x batch; w T n x batch.
+ * x0 may alias x0_last.  The estimator that produces the residual coefficients in the reference
+ * (README.md:456-480) is out of scope: a_k is the caller's.
+ */
+int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                            const double* u1, const double* u2,
+                            double* x0, double* x0_pre, double* w, void* stream);
+
+/*
  * Diagnostic (no counterpart in the reference): which device path the last fmpc_solve[_device] call of
  * this handle took, and how many problems the panel kernel handed to the exact per-problem path because
  * their step-length / exit decision was not clear-cut.  Synchronises the device.

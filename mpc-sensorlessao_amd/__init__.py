@@ -9,6 +9,7 @@ from .handle import FastMPCHandle
 from .fast_mpc2 import Fast_MPC2, Fast_MPC2_VAR1, deinterleave
 from . import synthetic
 from .sharded import ShardedFastMPC, shard_range
+from .closed_loop import ClosedLoop
 
 __all__ = ["FastMPCHandle", "Fast_MPC2", "Fast_MPC2_VAR1", "deinterleave", "FastMPCError",
-           "ShardedFastMPC", "shard_range", "synthetic", "load", "LIB_PATH"]
+           "ShardedFastMPC", "shard_range", "ClosedLoop", "synthetic", "load", "LIB_PATH"]

@@ -45,6 +45,7 @@ SIGNATURES = {
     "fmpc_unpack_device": (C.c_int, [_vp, C.c_int] + [_vp] * 4 + [_vp]),
     "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "fmpc_last_dispatch": (C.c_int, [_vp, _ip, _ip]),
+    "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
 }
 
 _lib = None

@@ -23,6 +23,9 @@ hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const
                                double* ws, size_t ws_stride, hipStream_t stream);
 hipError_t fmpc_launch_unpack(int n, int m, int T, int batch, const double* z, double* U,
                               double* X, double* u0, hipStream_t stream);
+hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
+                                   const double* a, const double* x0_last, const double* u1, const double* u2,
+                                   double* x0, double* x0_pre, double* w, hipStream_t stream);
 
 // one-wave-per-problem MFMA kernel (fmpc_kernel_wave.hip)
 size_t fmpc_wave_lds_bytes(int n, int mp);
@@ -50,6 +53,7 @@ struct fmpc_handle_s {
     int n, m, T, nb, var_order, has_xf, device;
     int num_cu;
     FmpcDevModel dev;            // device pointers into `pool`
+    const double* loop_M1; const double* loop_M2;   // closed-loop prediction matrices (T n) x n, row-major
     double* pool_d;              // one allocation for all shared doubles
     int* pool_i;                 // and one for the index arrays
     size_t lds_bytes;
@@ -267,6 +271,29 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     for (int i = 0; i < n; ++i) xmid[i] = (x_min[i] + x_max[i]) / 2;
     const size_t oumid = push(umid.data(), m), oxmid = push(xmid.data(), n);
     const size_t oxf = push_opt(xf, n);
+    // closed-loop prediction matrices (main.mlx, MPC_DesignMatrices): M1_0 = A1, M2_0 = A2, M1_1 = A1^2 + A2,
+    // M2_1 = A1 A2, M1_i = A1 M1_{i-1} + A2 M1_{i-2}, M2_i = M1_{i-1} A2
+    std::vector<double> lm1((size_t)T * nn, 0.0), lm2((size_t)T * nn, 0.0);
+    {
+        auto mul = [&](const double* X, const double* Y, double* Z, double beta) {     // Z = beta Z + X Y (n x n row-major)
+            for (int rr = 0; rr < n; ++rr)
+                for (int c = 0; c < n; ++c) {
+                    double t = 0.0;
+                    for (int qq = 0; qq < n; ++qq) t += X[rr * n + qq] * Y[qq * n + c];
+                    Z[rr * n + c] = beta * Z[rr * n + c] + t;
+                }
+        };
+        for (int i = 0; i < T; ++i) {
+            double* m1 = lm1.data() + (size_t)i * nn; double* m2 = lm2.data() + (size_t)i * nn;
+            if (i == 0) { for (int e = 0; e < nn; ++e) { m1[e] = a1[e]; m2[e] = a2[e]; } }
+            else if (i == 1) { for (int e = 0; e < nn; ++e) m1[e] = a2[e]; mul(a1.data(), a1.data(), m1, 1.0); mul(a1.data(), a2.data(), m2, 0.0); }
+            else {
+                mul(a1.data(), m1 - nn, m1, 0.0); mul(a2.data(), m1 - 2 * nn, m1, 1.0);
+                mul(m1 - nn, a2.data(), m2, 0.0);
+            }
+        }
+    }
+    const size_t oM1 = push(lm1.data(), lm1.size()), oM2 = push(lm2.data(), lm2.size());
     // blocks are indexed as Yblk + idx*n*n by the kernels: pack them without padding
     std::vector<double> yall;
     for (auto& bk : blocks) yall.insert(yall.end(), bk.begin(), bk.end());
@@ -295,6 +322,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     D.umin = h->pool_d + oumin; D.umax = h->pool_d + oumax; D.umid = h->pool_d + oumid;
     D.xmid = h->pool_d + oxmid; D.xf = h->pool_d + oxf; D.Yblk = h->pool_d + oY;
     D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
+    h->loop_M1 = h->pool_d + oM1; h->loop_M2 = h->pool_d + oM2;
 
     if (fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
 
@@ -999,6 +1027,17 @@ extern "C" int fmpc_unpack_device(fmpc_handle h, int batch, const double* z, dou
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
     return fmpc_launch_unpack(h->n, h->m, h->T, batch, z, U, X, u0, (hipStream_t)stream) == hipSuccess
                ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                                       const double* u1, const double* u2,
+                                       double* x0, double* x0_pre, double* w, void* stream) {
+    if (!h || !a_k || !x0 || !x0_pre || !w) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    return fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_k, x0_last, u1, u2,
+                                   x0, x0_pre, w, (hipStream_t)stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
 extern "C" int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U, double* X, double* u0) {

@@ -478,6 +478,46 @@ fmpc_unpack_kernel(int n, int m, int T, int batch, const double* __restrict__ z,
     }
 }
 
+// Closed-loop inputs (fmpc_loop_inputs_device in include/fastmpc.h; README.md:482-497): one workgroup per problem.
+//   x0 = a + B u1 ,  x0_pre = x0_last ,  w = -M1 (B u1) - M2 (B u2)      M1, M2: (T n) x n row-major
+extern "C" __global__ void __launch_bounds__(256)
+fmpc_loop_inputs_kernel(int n, int m, int T, const double* __restrict__ Bt, const double* __restrict__ M1,
+                        const double* __restrict__ M2, const double* __restrict__ a, const double* x0_last,
+                        const double* __restrict__ u1, const double* __restrict__ u2,
+                        double* x0, double* __restrict__ x0_pre, double* __restrict__ w) {
+    extern __shared__ double sh[];                      // bu1[n], bu2[n]
+    double* bu1 = sh; double* bu2 = sh + n;
+    const size_t p = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < 2 * n; r += blockDim.x) {
+        const int rr = r < n ? r : r - n;
+        const double* u = r < n ? u1 : u2;
+        double acc = 0.0;
+        if (u) for (int c = 0; c < m; ++c) acc += Bt[(size_t)c * n + rr] * u[p * m + c];
+        sh[r] = acc;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += blockDim.x) {
+        const double xl = x0_last ? x0_last[p * n + r] : 0.0;
+        x0_pre[p * n + r] = xl;
+        x0[p * n + r] = a[p * n + r] + bu1[r];
+    }
+    for (int e = tid; e < T * n; e += blockDim.x) {
+        double acc = 0.0;
+        const double* r1 = M1 + (size_t)e * n; const double* r2 = M2 + (size_t)e * n;
+        for (int q = 0; q < n; ++q) acc -= r1[q] * bu1[q] + r2[q] * bu2[q];
+        w[p * (size_t)T * n + e] = acc;
+    }
+}
+
+hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
+                                   const double* a, const double* x0_last, const double* u1, const double* u2,
+                                   double* x0, double* x0_pre, double* w, hipStream_t stream) {
+    hipLaunchKernelGGL(fmpc_loop_inputs_kernel, dim3(batch), dim3(256), 2 * n * sizeof(double), stream,
+                       n, m, T, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w);
+    return hipGetLastError();
+}
+
 size_t fmpc_generic_lds_bytes(int n, int m) {
     const size_t d = (size_t)m * n + 6 * (size_t)n * (n + 1) + m + 3 * (size_t)n + 8 + 2;
     return d * sizeof(double);

@@ -177,6 +177,23 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_solve_device")
         return z_out, status, iters
 
+    def loop_inputs_device(self, a_k, x0_last, u1, u2, x0, x0_pre, w):
+        """fmpc_loop_inputs_device: x0 = a_k + B u1, x0_pre = x0_last (None: zeros), w = -M1 B u1 - M2 B u2 (torch
+        tensors on the device; None drops a term; x0 may be x0_last)."""
+        import torch
+        batch = a_k.shape[0]
+        for t, cols, name in ((a_k, self.n, "a_k"), (x0_last, self.n, "x0_last"), (u1, self.m, "u1"), (u2, self.m, "u2"),
+                              (x0, self.n, "x0"), (x0_pre, self.n, "x0_pre"), (w, self.T * self.n, "w")):
+            if t is None:
+                continue
+            if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != batch * cols:
+                raise FastMPCError(_lib.FMPC_E_DIM, f"{name}: need a contiguous float64 HIP tensor of {(batch, cols)}")
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(a_k.device).cuda_stream)
+        rc = self._lib.fmpc_loop_inputs_device(self._h, batch, p(a_k), p(x0_last), p(u1), p(u2), p(x0), p(x0_pre), p(w), stream)
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_loop_inputs_device")
+
     def unpack_device(self, z, U=None, X=None, u0=None):
         import torch
         batch = z.shape[0]

@@ -1,0 +1,37 @@
+"""GPU test of the coefficient-space closed loop (README.md:482-497, 589): the device loop
+(`ClosedLoop`: fmpc_loop_inputs_device + solve + unpack per step, nothing leaves HBM) against the CPU oracle
+`oracle/closed_loop_ref.py`.  The loop feeds its own first moves back through B, so errors accumulate over the
+steps: tolerance 1e-8 relative on the trajectories after 6 steps (1e-9 per solve)."""
+import numpy as np
+import pytest
+
+from oracle.closed_loop_ref import closed_loop, design_matrices
+from tests.util import handle_from_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,m,T,nw", [(27, 144, 30, 1), (27, 144, 10, 3), (8, 5, 6, 2)])
+def test_closed_loop_matches_oracle(pkg, gpu, n, m, T, nw):
+    import torch
+    md = pkg.synthetic.make_model(n, m, T)
+    R, steps = 5, 6
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)   # (steps, R, n)
+    h = handle_from_model(pkg, md)
+    dev = torch.device("cuda:0")
+    loop = pkg.ClosedLoop(h, R, n_newton=nw, k=1e-2)
+    U0, X0 = loop.run(torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+    torch.cuda.synchronize()
+    U0, X0 = U0.cpu().numpy(), X0.cpu().numpy()
+    assert int(loop.status.abs().sum()) == 0
+    for r in range(R):
+        ref = closed_loop(md, a[:, r], nw, 1e-2)
+        assert (ref["status"] == 0).all()
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    # the inputs kernel alone: b_ref of the last step against M1, M2 applied on the host
+    M1, M2 = design_matrices(md["A1"], md["A2"], T)
+    w_dev = loop.w.cpu().numpy()
+    for r in range(R):
+        w_ref = -M1 @ (md["B"] @ U0[steps - 2, r]) - M2 @ (md["B"] @ U0[steps - 3, r])
+        assert rel_err(w_dev[r], w_ref) <= 1e-12
+    h.close()

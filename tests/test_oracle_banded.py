@@ -94,3 +94,21 @@ def test_line_search_closed_form_T4():
     assert np.array_equal(canon_steps(j1["t"]), canon_steps(j2["t"]))
     assert 0.0 in canon_steps(j1["t"]) and st2 == 1 and max(j1["halvings"]) >= 40
     assert rel_err(zb2, zd2) <= 1e-9
+
+
+def test_closed_loop_design_matrices_predict_the_var2_recursion():
+    """oracle/closed_loop_ref.design_matrices (MPC_DesignMatrices, main.mlx): with no control the stacked
+    prediction M1 x0 + M2 x0_pre must equal iterating x[i+1] = A1 x[i] + A2 x[i-1] (the recursion the solver's
+    equality constraints encode, fast_mpc_eq_const.m:38-47)."""
+    from oracle.closed_loop_ref import design_matrices
+    rng = np.random.default_rng(7)
+    n, T = 5, 6
+    A1 = 0.5 * rng.standard_normal((n, n)); A2 = 0.3 * rng.standard_normal((n, n))
+    M1, M2 = design_matrices(A1, A2, T)
+    x0 = rng.standard_normal(n); xp = rng.standard_normal(n)
+    pred = (M1 @ x0 + M2 @ xp).reshape(T, n)
+    a, b = x0, xp
+    for i in range(T):
+        nxt = A1 @ a + A2 @ b
+        assert np.allclose(pred[i], nxt, rtol=1e-13, atol=1e-13)
+        a, b = nxt, a
