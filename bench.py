@@ -130,8 +130,11 @@ def main():
     z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
     st = torch.empty(B, dtype=torch.int32, device=dev)
     it = torch.empty(B, dtype=torch.int32, device=dev)
-    u0 = torch.empty((B, m), dtype=torch.float64, device=dev)
-    u0_all = torch.empty((world * B, m), dtype=torch.float64, device=dev) if world > 1 else None
+    # two first-move buffers: the gather of step i overlaps the solve of step i + 1 (RCCL runs on its own stream)
+    u0s = [torch.empty((B, m), dtype=torch.float64, device=dev) for _ in range(2)]
+    u0 = u0s[0]
+    u0_alls = [torch.empty((world * B, m), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gather = {"pending": [None, None], "i": 0, "overlap": world > 1 and not rehearse}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -148,20 +151,39 @@ def main():
             handle.solve_device(x0, x0p, None, None, nu0, n_newton, K_BAR, z_out=z, status=st, iters=it)
             if ev:
                 ev[1].record()
-            handle.unpack_device(z, None, None, u0)              # first move u0 (README.md:589)
+            b = gather["i"] & 1
+            gather["i"] += 1
+            if gather["pending"][b] is not None:                 # the gather that last used this buffer pair
+                gather["pending"][b].wait()
+                gather["pending"][b] = None
+            handle.unpack_device(z, None, None, u0s[b])          # first move u0 (README.md:589)
             if world > 1:
                 if rehearse:
                     parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
-                    dist.all_gather(parts, u0.cpu())
+                    dist.all_gather(parts, u0s[b].cpu())
+                elif gather["overlap"]:
+                    try:                                         # the one collective: final gather of the first moves (RCCL)
+                        gather["pending"][b] = dist.all_gather_into_tensor(u0_alls[b], u0s[b], async_op=True)
+                    except Exception:                            # no async support: gather in line
+                        gather["overlap"] = False
+                        dist.all_gather_into_tensor(u0_alls[b], u0s[b])
                 else:
-                    dist.all_gather_into_tensor(u0_all, u0)      # the one collective: final gather (RCCL)
+                    dist.all_gather_into_tensor(u0_alls[b], u0s[b])
+
+        def drain():
+            for b in range(2):
+                if gather["pending"][b] is not None:
+                    gather["pending"][b].wait()
+                    gather["pending"][b] = None
         for _ in range(warmup):
             step()
+        drain()
         sync()
         # per-launch device time of the solve (HIP events on the launch stream), outside the timed region
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, min(steps, 20)))]
         for ev in evs:
             step(ev)
+        drain()
         sync()
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         graph = None
@@ -178,6 +200,7 @@ def main():
                 graph.replay()
             else:
                 step()
+        drain()
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -281,7 +304,8 @@ def main():
                        "newton_iters_per_problem": float(iters_cpu.sum()) / B,
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)"
                                             if shared else "per problem",
-                       "gather": "u0 all-gather (RCCL)" if world > 1 else "none (1 GPU)",
+                       "gather": ("u0 all-gather (RCCL), overlapped with the next step's solve" if gather["overlap"] else "u0 all-gather")
+                                 if world > 1 else "none (1 GPU)",
                        "launch": "hipGraph replay of one step (solve + first-move unpack)" if (world == 1 and args.graph)
                                  else "one Python call per step"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
