@@ -81,7 +81,7 @@ struct fmpc_handle_s {
     double* pn_gate; double* pn_epsp; double* pn_nuws;
     size_t pn_o_dz; int pn_dz_len;
     size_t pn_dz_lds;
-    double pn_rd2_0, pn_sa_cu, pn_rp2c;
+    double pn_rd2_0, pn_rp2c;
     std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf, hm_blocks;
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
@@ -177,7 +177,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_sa_cu = 0.0;
+    h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -798,7 +798,7 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
             if (i >= 2) rp2c += vec[V.cp + i * 32 + r] * vec[V.cp + i * 32 + r];
         }
     h->pn_rp2c = rp2c;
-    h->pn_rd2_0 = rd2_0; h->pn_sa_cu = sa_cu;
+    h->pn_rd2_0 = rd2_0;
     {   // LDS image of the d_z kernel, in LDS order
         const FdLds D = fd_lds_layout(mp);
         double* dz = pool.data() + h->pn_o_dz;
@@ -906,7 +906,6 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
             Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;
             Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
-            { const char* d = getenv("FMPC_PANEL_DBG"); Q.dbg = d ? atoi(d) : 0; }
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             e = fmpc_launch_panel(Q, pgrid, h->pn_lds, (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;

@@ -113,11 +113,6 @@ __device__ __forceinline__ d4 fp_mm_g(const double* img, int I, int lane, const 
     for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(a[ks], v[ks], acc);
     return acc;
 }
-__device__ __forceinline__ d4 fp_mm_l(fp_clds_t img, int I, int lane, const double v[FP_KS], d4 acc) {
-#pragma unroll
-    for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(img[(I * FP_KS + ks) * 64 + lane], v[ks], acc);
-    return acc;
-}
 __device__ __forceinline__ double fp_sum_g(double v) {         // sum over the 4 lane groups (same problem)
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -413,7 +408,7 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
     const FpParams Q = Pv;
     const FpKP P = &Q;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
-    const int nb = P->nb, T = P->T, batch = P->batch;
+    const int nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
     if (blockIdx.x == 0 && tid == 0 && P->handed) *P->handed = 0;
     // a finite panel: pad rows are read (and multiplied by zero image columns)

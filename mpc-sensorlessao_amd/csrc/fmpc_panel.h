@@ -81,7 +81,6 @@ struct FpParams {
     double* epsp;                       // per (panel, stage, problem): partial ||e||^2   (read by fmpc_newton_wave)
     const double* dzimg;                // LDS image of the d_z kernel: [B' | A1' | A2' | c1 wc hc ubar | xc xc' iq iq']
     int dzimg_len;
-    int dbg;                            // development switches (FMPC_PANEL_DBG), 0 in production
     int* handed;                        // number of problems the exact path had to solve (diagnostic), zeroed here
     double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
 };
