@@ -79,6 +79,30 @@ def test_panel_step_var1_and_odd_actuator_count(pkg, gpu):
         hp.close()
 
 
+def test_panel_step_with_linear_costs_and_asymmetric_box(pkg, gpu):
+    """Every host constant of the panel path that vanishes in the symmetric AO model: linear costs q, r, qf,
+    a box that is not centred on zero (ubar, xbar != 0), a terminal state, per-entry different bounds."""
+    rng = np.random.default_rng(21)
+    md = pkg.synthetic.make_model(27, 144, 12)
+    md["q"] = 50.0 * rng.standard_normal(27); md["r"] = 0.3 * rng.standard_normal(144); md["qf"] = 80.0 * rng.standard_normal(27)
+    md["u_min"] = -28.0 + 6.0 * rng.random(144); md["u_max"] = 20.0 + 10.0 * rng.random(144)
+    md["x_min"] = -90.0 + 20.0 * rng.random(27); md["x_max"] = 70.0 + 40.0 * rng.random(27)
+    md["xf"] = 0.5 * rng.standard_normal(27)
+    data = pkg.synthetic.make_replay_batch(md, r=6, steps=21)
+    data["w"] = 0.05 * rng.standard_normal((21, 12 * 27))
+    data["nu0"] = rng.standard_normal((21, 13 * 27))
+    hp = handle_from_model(pkg, md)
+    for k in (1e-2, 3.0):
+        z, info = hp.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=k, return_info=True)
+        assert hp.last_dispatch()[0] == pkg.FMPC_PATH_PANEL
+        zo, nuo, ito, sto, steps = oracle_batch(md, data, 1, k)
+        assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
+        assert np.array_equal(canon_steps(info["step"][:, 0]), canon_steps([s_[0] for s_ in steps]))
+        assert max(rel_err(z[p], zo[p]) for p in range(21)) <= TOL_Z
+        assert max(rel_err(info["nu"][p], nuo[p]) for p in range(21)) <= TOL_NU
+    hp.close()
+
+
 def test_unclear_step_length_goes_to_the_exact_path(pkg, gpu):
     """Tight bounds: the barrier is active at the cold start, ||e||^2 is not small against rho^2, and the panel
     path must not decide the step length: every problem is redone by the exact path (bit-identical to it)."""
