@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--n-newton", type=int, default=N_NEWTON)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the general-path / budget-5 variants")
+    ap.add_argument("--in-flight", type=int, default=2, help="independent steps in flight per GPU (SolveLanes: one handle + HIP "
+                                                             "stream each); 1 = strictly one step after the other")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of one step instead of launching from Python "
                                                           "(measured slower here: the step is GPU-bound, not launch-bound)")
     args = ap.parse_args()
@@ -123,18 +125,10 @@ def main():
                                  model["u_min"], model["u_max"], model["x_min"], model["x_max"], T,
                                  device=local_rank)
 
-    h = make_handle()
     x0 = torch.from_numpy(data["x0"]).to(dev)
     x0p = torch.from_numpy(data["x0_pre"]).to(dev)
     nu0 = torch.from_numpy(data["nu0"]).to(dev)
-    z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
-    st = torch.empty(B, dtype=torch.int32, device=dev)
-    it = torch.empty(B, dtype=torch.int32, device=dev)
-    # two first-move buffers: the gather of step i overlaps the solve of step i + 1 (RCCL runs on its own stream)
-    u0s = [torch.empty((B, m), dtype=torch.float64, device=dev) for _ in range(2)]
-    u0 = u0s[0]
-    u0_alls = [torch.empty((world * B, m), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    gather = {"pending": [None, None], "i": 0, "overlap": world > 1 and not rehearse}
+    overlap = {"gather": world > 1 and not rehearse}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -142,44 +136,50 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def run(handle, n_newton, steps, warmup, use_graph=False):
-        """W warm-up steps, then K timed steps between barriers; per-launch kernel time from HIP
-        events recorded on the launch stream (torch's current stream is passed to the library)."""
+    def run(lanes, n_newton, steps, warmup, use_graph=False):
+        """W warm-up steps, then K timed steps between barriers.  A step = solve + first-move unpack (+ the gather of
+        the first moves for N > 1) of one batch, submitted to the next of `lanes` (SolveLanes): consecutive steps are
+        independent batches and overlap when there is more than one lane.  Per-launch kernel time: HIP events
+        recorded on the lane's stream around the solve, one step at a time (no overlap), outside the timed region."""
+        u0_all = {id(l): torch.empty((world * B, m), dtype=torch.float64, device=dev) for l in lanes.lanes} if world > 1 else None
+        pending = {id(l): None for l in lanes.lanes}
+
         def step(ev=None):
+            lane = lanes.lanes[0] if ev else lanes.next_lane()   # the evented steps run back to back on ONE lane
+            with torch.cuda.stream(lane.stream):
+                if pending[id(lane)] is not None:                # the gather that last read this lane's u0
+                    pending[id(lane)].wait()
+                    pending[id(lane)] = None
+                if ev:
+                    ev[0].record(lane.stream)
+            lanes.submit(x0, x0p, None, None, nu0, n_newton, K_BAR, after_current=False,
+                         lane=lane if ev else None)                      # solve + first move u0 (README.md:589)
             if ev:
-                ev[0].record()
-            handle.solve_device(x0, x0p, None, None, nu0, n_newton, K_BAR, z_out=z, status=st, iters=it)
-            if ev:
-                ev[1].record()
-            b = gather["i"] & 1
-            gather["i"] += 1
-            if gather["pending"][b] is not None:                 # the gather that last used this buffer pair
-                gather["pending"][b].wait()
-                gather["pending"][b] = None
-            handle.unpack_device(z, None, None, u0s[b])          # first move u0 (README.md:589)
+                ev[1].record(lane.stream)
             if world > 1:
-                if rehearse:
-                    parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
-                    dist.all_gather(parts, u0s[b].cpu())
-                elif gather["overlap"]:
-                    try:                                         # the one collective: final gather of the first moves (RCCL)
-                        gather["pending"][b] = dist.all_gather_into_tensor(u0_alls[b], u0s[b], async_op=True)
-                    except Exception:                            # no async support: gather in line
-                        gather["overlap"] = False
-                        dist.all_gather_into_tensor(u0_alls[b], u0s[b])
-                else:
-                    dist.all_gather_into_tensor(u0_alls[b], u0s[b])
+                with torch.cuda.stream(lane.stream):
+                    if rehearse:
+                        parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
+                        dist.all_gather(parts, lane.u0.cpu())
+                    elif overlap["gather"]:
+                        try:                                     # the one collective: final gather of the first moves (RCCL)
+                            pending[id(lane)] = dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0, async_op=True)
+                        except Exception:                        # no async support: gather in line
+                            overlap["gather"] = False
+                            dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0)
+                    else:
+                        dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0)
 
         def drain():
-            for b in range(2):
-                if gather["pending"][b] is not None:
-                    gather["pending"][b].wait()
-                    gather["pending"][b] = None
+            for lane in lanes.lanes:
+                if pending[id(lane)] is not None:
+                    with torch.cuda.stream(lane.stream):
+                        pending[id(lane)].wait()
+                    pending[id(lane)] = None
         for _ in range(warmup):
             step()
         drain()
         sync()
-        # per-launch device time of the solve (HIP events on the launch stream), outside the timed region
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(3, min(steps, 20)))]
         for ev in evs:
             step(ev)
@@ -187,10 +187,10 @@ def main():
         sync()
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         graph = None
-        if use_graph and world == 1:
-            # the step is launch-bound: capture its launches once (hipGraph) and replay them
+        if use_graph and world == 1 and lanes.depth == 1:
+            # capture the launches of one step once (hipGraph) and replay them
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=lanes.lanes[0].stream):
                 step()
             graph.replay()
             sync()
@@ -207,11 +207,17 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        iters_cpu = it.cpu().numpy()
-        assert (st.cpu().numpy() >= 0).all(), "solver reported errors"
+        iters_cpu = lanes.lanes[0].iters.cpu().numpy()
+        for lane in lanes.lanes:
+            assert (lane.status.cpu().numpy() >= 0).all(), "solver reported errors"
         return elapsed, kern_ms, iters_cpu
 
-    elapsed, kern_ms, iters_cpu = run(h, args.n_newton, args.steps, args.warmup, use_graph=args.graph)
+    depth = max(1, args.in_flight)
+    main_lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev)
+    h = main_lanes.lanes[0].handle
+    u0 = main_lanes.lanes[0].u0
+    elapsed, kern_ms, iters_cpu = run(main_lanes, args.n_newton, args.steps, args.warmup, use_graph=args.graph)
+    path, handed = h.last_dispatch()
     shared = os.environ.get("FMPC_NO_SHARED", "0") != "1" and os.environ.get("FMPC_FORCE_GENERIC", "0") != "1"
     units_first = float((iters_cpu >= 1).sum())           # first Newton steps (shared factor when enabled)
     units_later = float(iters_cpu.sum()) - units_first    # later steps: per-problem factorisation
@@ -219,14 +225,20 @@ def main():
     b_first = bytes_compulsory(n, m, T) if shared else bytes_streamed_factor(n, m, T)
 
     extra = {}
+    one_lane = pkg.SolveLanes(lambda: h, B, depth=1, device=dev) if depth > 1 else main_lanes     # shares lane 0's handle
+    if rank == 0 and world == 1 and depth > 1:
+        e1, k1, _ = run(one_lane, args.n_newton, args.steps, args.warmup)
+        extra["one_step_at_a_time"] = {"what": "same workload with --in-flight 1: every step waits for the previous one "
+                                               "(the latency-bound dual solve leaves half of the CUs idle)",
+                                       "value": B * args.steps / e1, "unit": "MPC steps/s", "ms_per_step": e1 / args.steps * 1e3}
     if rank == 0 and world == 1 and not args.no_extra:
         ksteps = max(5, args.steps // 5)
         os.environ["FMPC_NO_SHARED"] = "1"
         try:
-            hg = make_handle()                             # per-problem factorisation in every Newton step
+            lg = pkg.SolveLanes(make_handle, B, depth=1, device=dev)     # per-problem factorisation in every Newton step
         finally:
             del os.environ["FMPC_NO_SHARED"]
-        e2, k2, i2 = run(hg, args.n_newton, ksteps, 2)
+        e2, k2, i2 = run(lg, args.n_newton, ksteps, 2)
         fl = flops_per_problem_factor(n, m, T) * float(i2.sum())
         bs = bytes_streamed_factor(n, m, T) * float(i2.sum())
         extra["general_path"] = {
@@ -238,7 +250,7 @@ def main():
             "roofline_hbm_streamed_factor": {"bound": "hbm", "achieved": bs / (k2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                              "unit": "GB/s", "frac": bs / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "bytes_per_unit": bytes_streamed_factor(n, m, T)}}
-        hg.close()
+        lg.close()
         # closed loop (SURVEY 8d C2 "sequential closed loop (latency)" and C3 "512 realisations"): loop inputs +
         # solve + first-move unpack per step, all device-resident (mpc-sensorlessao_amd/closed_loop.py)
         cl = {}
@@ -261,13 +273,12 @@ def main():
                                           "sequential_steps": nsteps_}
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
                                          "depends on the previous first move, so only realisations batch", **cl)
-        e5, k5, i5 = run(h, 5, ksteps, 2)
+        e5, k5, i5 = run(one_lane, 5, ksteps, 2)
         extra["budget5"] = {"what": "Newton budget 5 with the reference's exit test (test_fast_mpc.m:53,59)",
                             "value": B * ksteps / e5, "unit": "MPC steps/s", "kernel_ms": k5,
                             "newton_iters_per_problem": float(i5.sum()) / B}
 
     if rank == 0:
-        path, handed = h.last_dispatch()
         if path == pkg.FMPC_PATH_PANEL:
             kernel_name = "fmpc_cold_panel + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed
             nbk = T                                            # no terminal row in the bench model
@@ -304,7 +315,11 @@ def main():
                        "newton_iters_per_problem": float(iters_cpu.sum()) / B,
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)"
                                             if shared else "per problem",
-                       "gather": ("u0 all-gather (RCCL), overlapped with the next step's solve" if gather["overlap"] else "u0 all-gather")
+                       "in_flight": depth,
+                       "in_flight_note": "consecutive steps are independent batches (other realisations / horizon windows) and are "
+                                         "dealt round-robin to `in_flight` solver lanes, one handle + HIP stream each "
+                                         "(mpc-sensorlessao_amd/lanes.py); extra.one_step_at_a_time has the strictly sequential figure",
+                       "gather": ("u0 all-gather (RCCL), overlapped with the next step's solve" if overlap["gather"] else "u0 all-gather")
                                  if world > 1 else "none (1 GPU)",
                        "launch": "hipGraph replay of one step (solve + first-move unpack)" if (world == 1 and args.graph)
                                  else "one Python call per step"},
@@ -327,7 +342,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, model, data, args.n_newton)
         print(json.dumps(out), flush=True)
-    h.close()
+    main_lanes.close()
     if world > 1:
         dist.destroy_process_group()
 

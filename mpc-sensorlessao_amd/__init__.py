@@ -10,6 +10,7 @@ from .fast_mpc2 import Fast_MPC2, Fast_MPC2_VAR1, deinterleave
 from . import synthetic
 from .sharded import ShardedFastMPC, shard_range
 from .closed_loop import ClosedLoop
+from .lanes import SolveLanes
 
 __all__ = ["FastMPCHandle", "Fast_MPC2", "Fast_MPC2_VAR1", "deinterleave", "FastMPCError",
-           "ShardedFastMPC", "shard_range", "ClosedLoop", "synthetic", "load", "LIB_PATH"]
+           "ShardedFastMPC", "shard_range", "ClosedLoop", "SolveLanes", "synthetic", "load", "LIB_PATH"]
