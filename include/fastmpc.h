@@ -133,9 +133,11 @@ int fmpc_unpack_device(fmpc_handle h, int batch, const double* z, double* U, dou
 /*
  * One-shot form taking the reference's full 23-argument constructor set
  * (Fast_MPC/VAR_2/Fast_MPC2.m:28-29) plus (nw, k) of mpc_fixed_log_newton (:124) and nu0.
- * S, x_min/x_max (beyond the cold start), du_min, du_max, u_prev are accepted and ignored as
- * in the reference.  Empty MATLAB arguments are NULL.  x_opt: N_z.
- * var_order 1 ignores x0_pre/A2.
+ * S and x_min/x_max (beyond the cold start) are accepted and ignored as in the reference.
+ * du_min, du_max, u_prev: ignored for var_order 2 (the VAR_2 ramp rows are commented out,
+ * VAR_2/fast_mpc_ineq_const.m:61-79); for var_order 1 they add the ramp-rate rows of
+ * VAR_1/fast_mpc_ineq_const.m:58-76 when all three are given (NULL: box rows only).
+ * Empty MATLAB arguments are NULL.  x_opt: N_z.  var_order 1 ignores x0_pre/A2.
  */
 int fmpc_solve_once(int n, int m, int T, int var_order,
                     const double* Q, const double* R, const double* S, const double* Qf,
@@ -166,16 +168,37 @@ int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const d
                             double* x0, double* x0_pre, double* w, void* stream);
 
 /*
+ * Ramp-rate rows of the VAR_1 variant (VAR_1/Fast_MPC2.m:26-27 arguments dumin, dumax, u_prev;
+ * VAR_1/fast_mpc_ineq_const.m:58-76): per stage j   du_min <= u_j - u_{j-1} <= du_max,  u_{-1} = u_prev.
+ * fmpc_set_ramp stores the bounds (m each, du_min < du_max) in the handle; fmpc_solve_ramp[_device] is
+ * fmpc_solve[_device] with the extra per-problem input u_prev (m x batch).  The rows couple consecutive stages, so
+ * Y = C Phi^-1 C' is dense across the horizon: this path factors a dense (T n)^2 matrix per problem and Newton
+ * step (fmpc_kernel_ramp.hip); it needs diagonal Q, R, Qf like the other device paths.
+ * FMPC_E_UNSUPPORTED: fmpc_set_ramp has not been called (or n > 64).
+ */
+int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* du_max);
+int fmpc_solve_ramp(fmpc_handle h, int batch,
+                    const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                    const double* z_init, const double* nu0, int n_newton, double k,
+                    double* z_out, double* nu_out, int* status, int* iters, double* step);
+int fmpc_solve_ramp_device(fmpc_handle h, int batch,
+                           const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                           const double* z_init, const double* nu0, int n_newton, double k,
+                           double* z_out, double* nu_out, int* status, int* iters, double* step,
+                           void* stream);
+
+/*
  * Diagnostic (no counterpart in the reference): which device path the last fmpc_solve[_device] call of
  * this handle took, and how many problems the panel kernel handed to the exact per-problem path because
  * their step-length / exit decision was not clear-cut.  Synchronises the device.
  *   path  0 generic kernel, 1 wave kernel (per-problem factor), 2 wave kernel (shared cold-start factor),
- *         3 panel kernel (+ exact path for `handed_over` problems).
+ *         3 panel kernel (+ exact path for `handed_over` problems), 4 ramp-rate kernel.
  */
 #define FMPC_PATH_GENERIC 0
 #define FMPC_PATH_WAVE    1
 #define FMPC_PATH_SHARED  2
 #define FMPC_PATH_PANEL   3
+#define FMPC_PATH_RAMP    4
 int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
 
 #ifdef __cplusplus

@@ -26,6 +26,7 @@ FMPC_PATH_GENERIC = 0
 FMPC_PATH_WAVE = 1
 FMPC_PATH_SHARED = 2
 FMPC_PATH_PANEL = 3
+FMPC_PATH_RAMP = 4
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -46,6 +47,9 @@ SIGNATURES = {
     "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "fmpc_last_dispatch": (C.c_int, [_vp, _ip, _ip]),
     "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
+    "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),
+    "fmpc_solve_ramp": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5),
+    "fmpc_solve_ramp_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5 + [_vp]),
 }
 
 _lib = None

@@ -16,6 +16,15 @@
 // kernels / launchers (fmpc_kernel_generic.hip)
 size_t fmpc_generic_lds_bytes(int n, int m);
 hipError_t fmpc_generic_prepare(size_t lds_bytes);
+// fmpc_kernel_ramp.hip
+size_t fmpc_ramp_lds_bytes(int n, int m);
+size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb);
+hipError_t fmpc_ramp_prepare(size_t lds_bytes);
+hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const double* dumax, int batch, int grid,
+                            const double* x0, const double* x0p, const double* w, const double* uprev,
+                            const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
+                            double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
+                            size_t ws_stride, hipStream_t stream);
 hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const double* x0,
                                const double* x0p, const double* w, const double* zinit,
                                const double* nu0, int max_iter, double kbar, double* zout,
@@ -86,6 +95,9 @@ struct fmpc_handle_s {
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
+    // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
+    double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
+    double* ramp_ws; size_t ramp_ws_doubles;
     // workspace, grown on demand; guarded because a handle may be shared between threads
     std::mutex mu;
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
@@ -174,6 +186,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->nb = T + h->has_xf; h->device = device;
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
+    h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
@@ -436,6 +449,8 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->pn_gate) (void)hipFree(h->pn_gate);
     if (h->pn_epsp) (void)hipFree(h->pn_epsp);
     if (h->pn_nuws) (void)hipFree(h->pn_nuws);
+    if (h->ramp_du) (void)hipFree(h->ramp_du);
+    if (h->ramp_ws) (void)hipFree(h->ramp_ws);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
@@ -907,7 +922,8 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;
             Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
-            e = fmpc_launch_panel(Q, pgrid, h->pn_lds, (hipStream_t)stream);
+            // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
+            e = fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;
             const int ntasks = npanels * h->T;
             // one task per wave, 8 per workgroup; workgroups b, b + 8, ... take the panels b % 8, b % 8 + 8, ...
@@ -956,11 +972,63 @@ extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {
     return FMPC_OK;
 }
 
-extern "C" int fmpc_solve(fmpc_handle h, int batch,
-                          const double* x0, const double* x0_pre, const double* w,
-                          const double* z_init, const double* nu0,
-                          int n_newton, double k,
-                          double* z_out, double* nu_out, int* status, int* iters, double* step) {
+extern "C" int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* du_max) {
+    if (!h || !du_min || !du_max) return FMPC_E_NULL;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    for (int c = 0; c < h->m; ++c)
+        if (!(du_min[c] < du_max[c])) return FMPC_E_DIM;
+    const size_t lds = fmpc_ramp_lds_bytes(h->n, h->m);
+    if (h->n > 64 || lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->ramp_du) {
+        if (hipMalloc((void**)&h->ramp_du, 2 * (size_t)h->m * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        if (fmpc_ramp_prepare(lds) != hipSuccess) return FMPC_E_HIP;
+    } else if (hipDeviceSynchronize() != hipSuccess) {
+        return FMPC_E_HIP;
+    }
+    if (hipMemcpy(h->ramp_du, du_min, h->m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->ramp_du + h->m, du_max, h->m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    return FMPC_OK;
+}
+
+extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
+                                      const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                                      const double* z_init, const double* nu0, int n_newton, double k,
+                                      double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                      void* stream) {
+    if (!h || !x0 || !z_out || !u_prev) return FMPC_E_NULL;
+    if (!h->ramp_du) return FMPC_E_UNSUPPORTED;                    // fmpc_set_ramp first
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int max_iter = n_newton > 0 ? n_newton : 1000;
+    // one workgroup per problem in flight; the workspace holds the dense Y of each (nb n)^2 doubles
+    const size_t stride = fmpc_ramp_ws_doubles(h->n, h->m, h->T, h->nb);
+    int cap = 2 * h->num_cu;
+    const size_t budget = (size_t)2 << 30;                         // doubles (16 GB) for all workgroups together
+    if ((size_t)cap * stride > budget) cap = (int)(budget / stride);
+    if (cap < 1) return FMPC_E_ALLOC;
+    const int grid = batch < cap ? batch : cap;
+    const size_t need = stride * (size_t)grid;
+    if (need > h->ramp_ws_doubles) {
+        if (h->ramp_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ramp_ws); h->ramp_ws = nullptr; h->ramp_ws_doubles = 0; }
+        if (hipMalloc((void**)&h->ramp_ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->ramp_ws_doubles = need;
+    }
+    h->last_path = FMPC_PATH_RAMP;
+    const hipError_t e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_init,
+                                          nu0, max_iter, k, z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
+                                          h->ramp_ws, stride, (hipStream_t)stream);
+    return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+// host-pointer solve; u_prev != NULL selects the ramp-rate path
+static int fmpc_solve_host(fmpc_handle h, int batch,
+                           const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                           const double* z_init, const double* nu0,
+                           int n_newton, double k,
+                           double* z_out, double* nu_out, int* status, int* iters, double* step) {
     if (!h || !x0 || !z_out) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
@@ -974,6 +1042,7 @@ extern "C" int fmpc_solve(fmpc_handle h, int batch,
     const size_t o_x0 = take(n * B * 8), o_x0p = take(n * B * 8), o_w = take(Tn * B * 8);
     const size_t o_zi = take(Nz * B * 8), o_nu0 = take(nbn * B * 8), o_z = take(Nz * B * 8);
     const size_t o_nu = take(nbn * B * 8), o_st = take(B * 4), o_it = take(B * 4), o_step = take(sld * B * 8);
+    const size_t o_up = take(u_prev ? (size_t)h->m * B * 8 : 0);
     char* base;
     {
         std::lock_guard<std::mutex> lk(h->mu);
@@ -994,13 +1063,17 @@ extern "C" int fmpc_solve(fmpc_handle h, int batch,
     const double* d_w = up(o_w, w, Tn * B);
     const double* d_zi = up(o_zi, z_init, Nz * B);
     const double* d_nu0 = up(o_nu0, nu0, nbn * B);
+    const double* d_up = up(o_up, u_prev, (size_t)h->m * B);
     const double* bad = (const double*)-1;
-    if (d_x0 == bad || d_x0p == bad || d_w == bad || d_zi == bad || d_nu0 == bad) return FMPC_E_HIP;
+    if (d_x0 == bad || d_x0p == bad || d_w == bad || d_zi == bad || d_nu0 == bad || d_up == bad) return FMPC_E_HIP;
     int* d_st = (int*)(base + o_st);
     int* d_it = (int*)(base + o_it);
-    int rc = fmpc_solve_device(h, batch, d_x0, d_x0p, d_w, d_zi, d_nu0, n_newton, k,
-                               (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
-                               step ? (double*)(base + o_step) : nullptr, nullptr);
+    int rc = u_prev ? fmpc_solve_ramp_device(h, batch, d_x0, d_x0p, d_w, d_up, d_zi, d_nu0, n_newton, k,
+                                             (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
+                                             step ? (double*)(base + o_step) : nullptr, nullptr)
+                    : fmpc_solve_device(h, batch, d_x0, d_x0p, d_w, d_zi, d_nu0, n_newton, k,
+                                        (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
+                                        step ? (double*)(base + o_step) : nullptr, nullptr);
     if (rc != FMPC_OK) return rc;
     if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
     std::vector<int> st(B);
@@ -1016,6 +1089,23 @@ extern "C" int fmpc_solve(fmpc_handle h, int batch,
         else if (worst >= 0 && st[i] > worst) worst = st[i];
     }
     return worst;
+}
+
+extern "C" int fmpc_solve(fmpc_handle h, int batch,
+                          const double* x0, const double* x0_pre, const double* w,
+                          const double* z_init, const double* nu0,
+                          int n_newton, double k,
+                          double* z_out, double* nu_out, int* status, int* iters, double* step) {
+    return fmpc_solve_host(h, batch, x0, x0_pre, w, nullptr, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step);
+}
+
+extern "C" int fmpc_solve_ramp(fmpc_handle h, int batch,
+                               const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                               const double* z_init, const double* nu0,
+                               int n_newton, double k,
+                               double* z_out, double* nu_out, int* status, int* iters, double* step) {
+    if (!u_prev) return FMPC_E_NULL;
+    return fmpc_solve_host(h, batch, x0, x0_pre, w, u_prev, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step);
 }
 
 extern "C" int fmpc_unpack_device(fmpc_handle h, int batch, const double* z, double* U, double* X,
@@ -1075,14 +1165,22 @@ extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
                                const double* w, const double* xf, const double* x_init,
                                const double* nu0, int nw, double k, int device,
                                double* x_opt, int* iters) {
-    (void)S; (void)du_min; (void)du_max; (void)u_prev;     // unused by the reference too (D8)
+    (void)S;                                                  // stored, never used (Fast_MPC2.m:33)
+    // VAR_2 ignores du_min, du_max, u_prev (its ramp rows are commented out, D8); VAR_1 builds ramp rows from them
+    // (VAR_1/fast_mpc_ineq_const.m:58-76)
+    const bool ramp = var_order == 1 && du_min && du_max && u_prev;
     if (!x0 || (var_order == 2 && !x0_pre)) return FMPC_E_DIM;   // fast_mpc_eq_const.m:27-30
     fmpc_handle h = nullptr;
     int rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max,
                          u_min, u_max, xf, device);
     if (rc != FMPC_OK) return rc;
     int st = 0;
-    rc = fmpc_solve(h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+    if (ramp) {
+        rc = fmpc_set_ramp(h, du_min, du_max);
+        if (rc == FMPC_OK) rc = fmpc_solve_ramp(h, 1, x0, x0_pre, w, u_prev, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+    } else {
+        rc = fmpc_solve(h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+    }
     fmpc_destroy(h);
     return rc;
 }

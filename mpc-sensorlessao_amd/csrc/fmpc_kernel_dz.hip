@@ -31,13 +31,12 @@ typedef const __attribute__((address_space(3))) double* fd_clds_t;
 typedef const FpParams* FdKP;          // points at a LOCAL copy of the kernel argument (fields loaded once at kernel entry)
 
 #ifdef FW_TIMING
-__device__ unsigned long long fd_timing[8];
-extern "C" int fmpc_debug_dz_timing(unsigned long long* out) {
-    unsigned long long z[8] = {0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_timing), sizeof(z)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(fd_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+#define FD_TICK(k) do { _tr[k + 1] = (unsigned long long)wall_clock64(); } while (0)
+// per-wave trace (constant 100 MHz clock): entry, LDS image ready, loads issued, done; of the LAST launch
+__device__ unsigned long long fd_trace[4 * 8192];
+extern "C" int fmpc_debug_dz_trace(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fd_trace), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
 }
-#define FD_TICK(k) do { _k1 = __builtin_readcyclecounter(); _ka[k] += _k1 - _k0; _k0 = _k1; } while (0)
 #else
 #define FD_TICK(k)
 #endif
@@ -50,7 +49,7 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     const int nb = P->nb, T = P->T, m = P->m, mp = P->mp, batch = P->batch, s = FP_N + m;
     const FdLds L = fd_lds_layout(mp);
 #ifdef FW_TIMING
-    unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long _tr[4] = {(unsigned long long)wall_clock64(), 0, 0, 0};
 #endif
     {   // the LDS image is packed by the host in LDS order: all loads first, then the stores
         const double* src = P->dzimg;
@@ -197,7 +196,10 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     }
     FD_TICK(2);
 #ifdef FW_TIMING
-    if (lane == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&fd_timing[q], _ka[q]); atomicAdd(&fd_timing[7], 1ull); }
+    if (lane == 0) {       // (no atomics here: thousands of waves adding to one address take longer than the kernel)
+        const int wid = blockIdx.x * FD_WAVES + wv;
+        if (wid < 8192) for (int q = 0; q < 4; ++q) fd_trace[4 * wid + q] = _tr[q];
+    }
 #endif
 }
 

@@ -472,6 +472,10 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
 
 // ---------------------------------------------------------------- host side
 size_t fmpc_panel_lds_bytes(int nb, int mp) { return (size_t)fp_lds_layout(nb, mp).total * sizeof(double); }
+// what a launch with nsteps (= forward + backward) schedule rows really needs: the schedule region is the last one
+size_t fmpc_panel_lds_used(int nb, int mp, int nsteps) {
+    return (size_t)fp_lds_layout(nb, mp).SCH * sizeof(double) + (size_t)nsteps * FP_STEP_INTS * sizeof(int);
+}
 
 hipError_t fmpc_panel_prepare(size_t lds_bytes) {
     return hipFuncSetAttribute((const void*)fmpc_cold_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

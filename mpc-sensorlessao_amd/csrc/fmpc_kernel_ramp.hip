@@ -1,0 +1,497 @@
+// fastMPC Newton kernel WITH ramp-rate rows (the VAR_1 variant of the reference) for gfx950: any (n <= 64, m, T).
+//
+// Reference: Fast_MPC/VAR_1/fast_mpc_ineq_const.m:58-76 appends, per stage j, the rows
+//      u_j - u_{j-1} <= du_max ,  -(u_j - u_{j-1}) <= -du_min          (u_{-1} = u_prev, moved into h: :70-72)
+// to the box rows; everything else is the solver of inf_newton_solver.m:10-41 / inf_newton_KKT_H.m:3-13 /
+// backtracking_inf_newton.m:2-11 unchanged.  With D = diag(1/slack^2) over ALL rows:
+//   * Phi = 2H + k P'DP couples u_j with u_{j+-1} through DIAGONAL m x m blocks: for every actuator c the u-part of
+//     Phi is an independent T x T symmetric tridiagonal matrix
+//         diag_j = 2R_cc + k(1/s+^2 + 1/s-^2)_j + er_j + er_{j+1} ,  off_{j,j+1} = -er_{j+1} ,
+//         er_j = k(1/sr+_j^2 + 1/sr-_j^2)                                    (sr: the two ramp slacks of stage j)
+//     (R diagonal, as on the other device paths); the x-part stays 2Q;
+//   * Y = C Phi^-1 C' is therefore DENSE across stages (SURVEY.md §8 a6'):  Y_IJ = Yx_IJ + B diag(g^{IJ}) B' with
+//     g^{IJ}_c = (Phi_u,c^-1)_{IJ} and Yx the iteration-invariant block-penta-diagonal part the handle already holds.
+// One 256-thread workgroup owns one problem at a time:
+//   P1  slacks, barrier terms, r_d, r_p, exit test
+//   P2  per actuator: LDL' of its tridiagonal, Phi_u^-1 r_d, the explicit inverse g^{IJ} (O(T^2) recurrence);
+//       rhs = r_p - C Phi^-1 r_d
+//   P3  Y assembled block by block into the HBM workspace (lower block triangle)
+//   P4  blocked left-looking Cholesky of Y (n x n tiles through LDS), forward and backward substitution -> d_nu
+//   P5  d_z = Phi^-1(-r_d - C' d_nu) (tridiagonal solves), closed-form line search, update
+// This is the functional path for BASELINE config 0 (VAR(1), T = 10); it is written for clarity on plain VALU
+// code, not tuned like the box-only paths.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "fmpc_device.h"
+#include "../../include/fastmpc.h"
+
+#define FR_THREADS 256
+#define FR_MAX_HALVINGS 64
+
+__device__ __forceinline__ double fr_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// Sum over the workgroup, result to every thread; fixed order -> bitwise reproducible.
+__device__ __forceinline__ double fr_block_sum(double v, double* red) {
+    v = fr_wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (FR_THREADS >> 6); ++i) s += red[i];
+    return s;
+}
+
+struct FrWsLayout { size_t b, nu, hs, er, gr, dg, lo, rdu, rdx, phx, phu, rp, y, dnu, G, Y, total; };
+__host__ __device__ static inline FrWsLayout fr_ws_layout(int n, int m, int T, int nb) {
+    FrWsLayout L; size_t o = 0;
+    const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
+    L.b = o; o += nbn;   L.nu = o; o += nbn;
+    L.hs = o; o += Tm;   L.er = o; o += Tm;   L.gr = o; o += Tm;   L.dg = o; o += Tm;   L.lo = o; o += Tm;
+    L.rdu = o; o += Tm;  L.rdx = o; o += Tn;  L.phx = o; o += Tn;  L.phu = o; o += Tm;
+    L.rp = o; o += nbn;  L.y = o; o += nbn;   L.dnu = o; o += nbn;
+    L.G = o; o += (size_t)T * (T + 1) / 2 * m;
+    L.Y = o; o += nbn * nbn;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+
+// Solve the tridiagonal system of actuator c in place (LDL' factors dg = pivots, lo = multipliers), stride m.
+__device__ __forceinline__ void fr_tri_solve(const double* dg, const double* lo, double* f, int T, int m, int c) {
+    for (int j = 1; j < T; ++j) f[j * m + c] -= lo[(j - 1) * m + c] * f[(j - 1) * m + c];
+    f[(T - 1) * m + c] /= dg[(T - 1) * m + c];
+    for (int j = T - 2; j >= 0; --j) f[j * m + c] = f[j * m + c] / dg[j * m + c] - lo[j * m + c] * f[(j + 1) * m + c];
+}
+
+extern "C" __global__ void __launch_bounds__(FR_THREADS)
+fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double* __restrict__ dumax, int batch,
+                 const double* __restrict__ x0, const double* __restrict__ x0p, const double* __restrict__ w,
+                 const double* __restrict__ uprev, const double* zinit, const double* __restrict__ nu0,
+                 int max_iter, double kbar, double* zout, double* __restrict__ nuout, int* __restrict__ status,
+                 int* __restrict__ iters, double* __restrict__ step, int step_ld, double* __restrict__ ws,
+                 size_t ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = M.n, m = M.m, T = M.T, nb = M.nb;
+    const int s = n + m, Nz = T * s, nbn = nb * n, ldt = n + 1, tsz = n * ldt;
+    const int tid = threadIdx.x;
+    const bool var2 = M.var2 != 0;
+
+    // ---- LDS carve
+    double* sBt = lds;                    // m*n   Bt[c*n + r] = B[r][c]
+    double* tA = sBt + (size_t)m * n;     // tiles n*ldt
+    double* tB = tA + tsz;
+    double* tC = tB + tsz;
+    double* sg = tC + tsz;                // m     g^{IJ} of the current block pair
+    double* sv = sg + m;                  // n     vector of the triangular solves
+    double* srs = sv + n;                 // n     1/sqrt(pivot)
+    double* red = srs + n;                // 8
+
+    for (int i = tid; i < m * n; i += FR_THREADS) sBt[i] = M.Bt[i];
+
+    const FrWsLayout L = fr_ws_layout(n, m, T, nb);
+    double* wsp = ws + (size_t)blockIdx.x * ws_stride;
+    double* b = wsp + L.b;     double* nu = wsp + L.nu;   double* hs = wsp + L.hs;   double* er = wsp + L.er;
+    double* gr = wsp + L.gr;   double* dg = wsp + L.dg;   double* lo = wsp + L.lo;   double* rdu = wsp + L.rdu;
+    double* rdx = wsp + L.rdx; double* phx = wsp + L.phx; double* phu = wsp + L.phu; double* rp = wsp + L.rp;
+    double* y = wsp + L.y;     double* dnu = wsp + L.dnu; double* G = wsp + L.G;     double* Yd = wsp + L.Y;
+
+    for (int p = blockIdx.x; p < batch; p += gridDim.x) {
+        double* zp = zout + (size_t)p * Nz;
+        const double* x0v = x0 + (size_t)p * n;
+        const double* x0pv = x0p ? x0p + (size_t)p * n : nullptr;
+        const double* upv = uprev + (size_t)p * m;
+        __syncthreads();
+        // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m)
+        for (int idx = tid; idx < Nz; idx += FR_THREADS) {
+            const int e = idx % s;
+            zp[idx] = zinit ? zinit[(size_t)p * Nz + idx] : (e < m ? M.umid[e] : M.xmid[e - m]);
+        }
+        for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+            nu[idx] = nu0 ? nu0[(size_t)p * nbn + idx] : 0.0;
+            const int i = idx / n, r = idx - i * n;
+            double v = (i < T && w) ? w[(size_t)p * T * n + idx] : 0.0;
+            if (i == 0) {
+                for (int c = 0; c < n; ++c) v += M.A1t[c * n + r] * x0v[c];
+                if (var2 && x0pv)
+                    for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0pv[c];
+            } else if (i == 1 && i < T && var2) {
+                for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0v[c];
+            }
+            if (i == T) v = M.xf[r];
+            b[idx] = v;
+        }
+        if (step)
+            for (int idx = tid; idx < step_ld; idx += FR_THREADS) step[(size_t)p * step_ld + idx] = -1.0;
+        __syncthreads();
+
+        int st = FMPC_OK, nsteps = 0;
+        for (int it = 0; it < max_iter; ++it) {
+            // ================= P1: slacks and residuals
+            double acc_d = 0.0, acc_p = 0.0;
+            for (int idx = tid; idx < T * m; idx += FR_THREADS) {       // ramp terms of stage j (needed by j and j-1)
+                const int j = idx / m, c = idx - j * m;
+                const double dl = zp[j * s + c] - (j == 0 ? upv[c] : zp[(j - 1) * s + c]);
+                const double rpv = 1.0 / (dumax[c] - dl), rmv = 1.0 / (dl - dumin[c]);
+                er[idx] = kbar * (rpv * rpv + rmv * rmv);
+                gr[idx] = kbar * (rpv - rmv);
+            }
+            __syncthreads();
+            for (int idx = tid; idx < T * m; idx += FR_THREADS) {
+                const int j = idx / m, c = idx - j * m;
+                const double u = zp[j * s + c];
+                const double dp = 1.0 / (M.umax[c] - u), dm = 1.0 / (u - M.umin[c]);
+                const double hb = kbar * (dp * dp + dm * dm);
+                const bool nx = j + 1 < T;
+                double dot = 0.0;
+                const double* bt = sBt + c * n;
+                const double* nj = nu + j * n;
+                for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
+                const double rd = M.R2[c] * u + M.rl[c] + kbar * (dp - dm) + gr[idx] - (nx ? gr[idx + m] : 0.0) - dot;
+                hs[idx] = hb + er[idx] + (nx ? er[idx + m] : 0.0);          // diagonal of k P'DP
+                rdu[idx] = rd;
+                acc_d += rd * rd;
+            }
+            for (int idx = tid; idx < T * n; idx += FR_THREADS) {
+                const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
+                const double x = zp[jj * s + m + r];
+                double v = (j == T ? M.Qf2[r] * x + M.qfl[r] : M.Q2[r] * x + M.ql[r]) + nu[jj * n + r];
+                if (j < T) {
+                    const double* nj = nu + j * n;
+                    for (int c = 0; c < n; ++c) v -= M.A1[c * n + r] * nj[c];
+                }
+                if (var2 && j + 1 < T) {
+                    const double* nj = nu + (j + 1) * n;
+                    for (int c = 0; c < n; ++c) v -= M.A2[c * n + r] * nj[c];
+                }
+                if (j == T && M.has_xf) v += nu[T * n + r];
+                rdx[idx] = v;
+                phx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);           // Phi^-1 r_d on x_j
+                acc_d += v * v;
+            }
+            for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+                const int i = idx / n, r = idx - i * n;
+                double v;
+                if (i < T) {
+                    v = zp[i * s + m + r] - b[idx];
+                    const double* ui = zp + i * s;
+                    for (int c = 0; c < m; ++c) v -= sBt[c * n + r] * ui[c];
+                    if (i >= 1) {
+                        const double* xi = zp + (i - 1) * s + m;
+                        for (int c = 0; c < n; ++c) v -= M.A1t[c * n + r] * xi[c];
+                    }
+                    if (var2 && i >= 2) {
+                        const double* xi = zp + (i - 2) * s + m;
+                        for (int c = 0; c < n; ++c) v -= M.A2t[c * n + r] * xi[c];
+                    }
+                } else {
+                    v = zp[(T - 1) * s + m + r] - b[idx];
+                }
+                rp[idx] = v;
+                acc_p += v * v;
+            }
+            const double rp2 = fr_block_sum(acc_p, red);
+            const double rho2 = fr_block_sum(acc_d, red) + rp2;
+            // early exit, tested before the step (inf_newton_solver.m:19-22)
+            if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
+
+            // ================= P2: per actuator LDL' of the tridiagonal u-part of Phi, Phi_u^-1 r_d, explicit inverse
+            int bad = 0;
+            for (int c = tid; c < m; c += FR_THREADS) {
+                double lprev = 0.0, oprev = 0.0;
+                for (int j = 0; j < T; ++j) {
+                    double d = M.R2[c] + hs[j * m + c];
+                    if (j > 0) d -= lprev * oprev;
+                    if (!(d > 0.0) || isinf(d)) bad = 1;
+                    dg[j * m + c] = d;
+                    if (j + 1 < T) {
+                        oprev = -er[(j + 1) * m + c];
+                        lprev = oprev / d;
+                        lo[j * m + c] = lprev;
+                    }
+                }
+                for (int j = 0; j < T; ++j) phu[j * m + c] = rdu[j * m + c];
+                fr_tri_solve(dg, lo, phu, T, m, c);
+                // inverse, pairs (i <= j) at index i*T - i(i-1)/2 + (j - i):  inv[j][k] = -l_j inv[j+1][k] (k > j),
+                // inv[j][j] = 1/d_j + l_j^2 inv[j+1][j+1]
+                for (int j = T - 1; j >= 0; --j) {
+                    const size_t rowj = (size_t)j * T - (size_t)j * (j - 1) / 2;
+                    if (j == T - 1) {
+                        G[rowj * m + c] = 1.0 / dg[j * m + c];
+                    } else {
+                        const size_t rown = (size_t)(j + 1) * T - (size_t)(j + 1) * j / 2;
+                        const double lj = lo[j * m + c];
+                        for (int k2 = j + 1; k2 < T; ++k2)
+                            G[(rowj + (k2 - j)) * m + c] = -lj * G[(rown + (k2 - j - 1)) * m + c];
+                        G[rowj * m + c] = 1.0 / dg[j * m + c] + lj * lj * G[rown * m + c];
+                    }
+                }
+            }
+            const double badsum = fr_block_sum((double)bad, red);
+            if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
+            // rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into y)
+            for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+                const int i = idx / n, r = idx - i * n;
+                double cv;
+                if (i < T) {
+                    cv = phx[i * n + r];
+                    const double* pu = phu + i * m;
+                    for (int c = 0; c < m; ++c) cv -= sBt[c * n + r] * pu[c];
+                    if (i >= 1) {
+                        const double* px = phx + (i - 1) * n;
+                        for (int c = 0; c < n; ++c) cv -= M.A1t[c * n + r] * px[c];
+                    }
+                    if (var2 && i >= 2) {
+                        const double* px = phx + (i - 2) * n;
+                        for (int c = 0; c < n; ++c) cv -= M.A2t[c * n + r] * px[c];
+                    }
+                } else {
+                    cv = phx[(T - 1) * n + r];
+                }
+                y[idx] = rp[idx] - cv;
+            }
+            __syncthreads();
+
+            // ================= P3: Y (lower block triangle, dense) into the workspace
+            for (int I = 0; I < nb; ++I)
+                for (int J = 0; J <= I; ++J) {
+                    const bool hasu = I < T;                         // (J <= I): both stages carry u
+                    if (hasu) {
+                        const size_t pr = (size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J);
+                        for (int c = tid; c < m; c += FR_THREADS) sg[c] = G[pr * m + c];
+                    }
+                    __syncthreads();
+                    const double* Yc = nullptr; bool tr = false;
+                    if (I == J) Yc = M.Yblk + (size_t)M.idxD[I] * n * n;
+                    else if (I == J + 1 && M.idx1[J] >= 0) { Yc = M.Yblk + (size_t)M.idx1[J] * n * n; tr = true; }
+                    else if (I == J + 2 && M.idx2[J] >= 0) { Yc = M.Yblk + (size_t)M.idx2[J] * n * n; tr = true; }
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int a = idx / n, bb = idx - a * n;
+                        double acc = Yc ? (tr ? Yc[bb * n + a] : Yc[idx]) : 0.0;
+                        if (hasu) {
+                            double t = 0.0;
+                            for (int c = 0; c < m; ++c) t += sBt[c * n + a] * sg[c] * sBt[c * n + bb];
+                            acc += t;
+                        }
+                        Yd[(size_t)(I * n + a) * nbn + J * n + bb] = acc;
+                    }
+                    __syncthreads();
+                }
+
+            // ================= P4: blocked left-looking Cholesky of Y, in place (L overwrites the lower triangle)
+            bool fail = false;
+            for (int J = 0; J < nb && !fail; ++J) {
+                // ---- diagonal block: S = Y_JJ - sum_K L_JK L_JK'
+                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                    const int a = idx / n, bb = idx - a * n;
+                    tA[a * ldt + bb] = Yd[(size_t)(J * n + a) * nbn + J * n + bb];
+                }
+                for (int K = 0; K < J; ++K) {
+                    __syncthreads();
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int a = idx / n, k2 = idx - a * n;
+                        tB[a * ldt + k2] = Yd[(size_t)(J * n + a) * nbn + K * n + k2];
+                    }
+                    __syncthreads();
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int a = idx / n, bb = idx - a * n;
+                        if (bb > a) continue;
+                        double t = 0.0;
+                        for (int k2 = 0; k2 < n; ++k2) t += tB[a * ldt + k2] * tB[bb * ldt + k2];
+                        tA[a * ldt + bb] -= t;
+                    }
+                }
+                __syncthreads();
+                // ---- potrf, right-looking, one barrier per column; scaling deferred
+                for (int k2 = 0; k2 < n; ++k2) {
+                    const double piv = tA[k2 * ldt + k2];
+                    if (!(piv > 0.0) || isinf(piv)) { fail = true; break; }      // uniform
+                    const double ip = 1.0 / piv;
+                    if (tid == 0) srs[k2] = 1.0 / sqrt(piv);
+                    const int rem = n - k2 - 1;
+                    for (int idx = tid; idx < rem * rem; idx += FR_THREADS) {
+                        const int r = k2 + 1 + idx / rem, c = k2 + 1 + idx % rem;
+                        if (c <= r) tA[r * ldt + c] -= tA[r * ldt + k2] * tA[c * ldt + k2] * ip;
+                    }
+                    __syncthreads();
+                }
+                if (fail) break;
+                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                    const int r = idx / n, c = idx - r * n;
+                    if (c <= r) {
+                        const double v = tA[r * ldt + c] * srs[c];               // L[r][c] = S[r][c]/sqrt(p_c)
+                        tA[r * ldt + c] = v;
+                        Yd[(size_t)(J * n + r) * nbn + J * n + c] = v;
+                    }
+                }
+                __syncthreads();
+                // ---- blocks below: L_IJ = (Y_IJ - sum_K L_IK L_JK') L_JJ^-T
+                for (int I = J + 1; I < nb; ++I) {
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int a = idx / n, bb = idx - a * n;
+                        tC[a * ldt + bb] = Yd[(size_t)(I * n + a) * nbn + J * n + bb];
+                    }
+                    for (int K = 0; K < J; ++K) {
+                        __syncthreads();
+                        for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                            const int a = idx / n, k2 = idx - a * n;
+                            tB[a * ldt + k2] = Yd[(size_t)(J * n + a) * nbn + K * n + k2];
+                        }
+                        __syncthreads();
+                        for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                            const int a = idx / n, bb = idx - a * n;
+                            const double* li = Yd + (size_t)(I * n + a) * nbn + K * n;       // row a of L_IK (HBM/L2)
+                            double t = 0.0;
+                            for (int k2 = 0; k2 < n; ++k2) t += li[k2] * tB[bb * ldt + k2];
+                            tC[a * ldt + bb] -= t;
+                        }
+                    }
+                    __syncthreads();
+                    for (int a = tid; a < n; a += FR_THREADS) {                    // row a: x L_JJ' = tC[a, :]
+                        for (int bb = 0; bb < n; ++bb) {
+                            double v = tC[a * ldt + bb];
+                            for (int j = 0; j < bb; ++j) v -= tC[a * ldt + j] * tA[bb * ldt + j];
+                            tC[a * ldt + bb] = v / tA[bb * ldt + bb];
+                        }
+                    }
+                    __syncthreads();
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int a = idx / n, bb = idx - a * n;
+                        Yd[(size_t)(I * n + a) * nbn + J * n + bb] = tC[a * ldt + bb];
+                    }
+                    __syncthreads();
+                }
+            }
+            if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            __syncthreads();
+            // ---- forward substitution  L yy = y   (block by block; the diagonal block on wave 0, lane = entry)
+            for (int J = 0; J < nb; ++J) {
+                for (int a = tid; a < n; a += FR_THREADS) {
+                    const double* lr = Yd + (size_t)(J * n + a) * nbn;
+                    double v = y[J * n + a];
+                    for (int c = 0; c < J * n; ++c) v -= lr[c] * y[c];
+                    sv[a] = v;
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    double v = tid < n ? sv[tid] : 0.0;
+                    for (int r = 0; r < n; ++r) {
+                        const double xr = __shfl(v, r, 64) / Yd[(size_t)(J * n + r) * nbn + J * n + r];
+                        if (tid > r && tid < n) v -= Yd[(size_t)(J * n + tid) * nbn + J * n + r] * xr;
+                        else if (tid == r) v = xr;
+                    }
+                    if (tid < n) y[J * n + tid] = v;
+                }
+                __syncthreads();
+            }
+            // ---- backward substitution  L' d_nu = yy
+            for (int J = nb - 1; J >= 0; --J) {
+                for (int bb = tid; bb < n; bb += FR_THREADS) {
+                    double v = y[J * n + bb];
+                    for (int r = (J + 1) * n; r < nbn; ++r) v -= Yd[(size_t)r * nbn + J * n + bb] * dnu[r];
+                    sv[bb] = v;
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    double v = tid < n ? sv[tid] : 0.0;
+                    for (int r = n - 1; r >= 0; --r) {
+                        const double xr = __shfl(v, r, 64) / Yd[(size_t)(J * n + r) * nbn + J * n + r];
+                        if (tid < r) v -= Yd[(size_t)(J * n + r) * nbn + J * n + tid] * xr;
+                        else if (tid == r) v = xr;
+                    }
+                    if (tid < n) dnu[J * n + tid] = v;
+                }
+                __syncthreads();
+            }
+
+            // ================= P5: d_z, line-search scalars, update
+            for (int idx = tid; idx < T * m; idx += FR_THREADS) {           // rhs of Phi_u d_u = B' d_nu_j - r_d,u
+                const int j = idx / m, c = idx - j * m;
+                double dot = 0.0;
+                const double* bt = sBt + c * n;
+                const double* dj = dnu + j * n;
+                for (int r = 0; r < n; ++r) dot += bt[r] * dj[r];
+                phu[idx] = dot - rdu[idx];
+            }
+            __syncthreads();
+            for (int c = tid; c < m; c += FR_THREADS) fr_tri_solve(dg, lo, phu, T, m, c);     // phu = d_u
+            __syncthreads();
+            double be = 0.0, e2 = 0.0;
+            for (int idx = tid; idx < T * m; idx += FR_THREADS) {
+                const int j = idx / m;
+                double e = hs[idx] * phu[idx];                              // k P'DP d_z on u_j
+                if (j > 0) e -= er[idx] * phu[idx - m];
+                if (j + 1 < T) e -= er[idx + m] * phu[idx + m];
+                be += rdu[idx] * e;
+                e2 += e * e;
+            }
+            for (int idx = tid; idx < T * n; idx += FR_THREADS) {
+                const int jj = idx / n, r = idx - jj * n, j = jj + 1;
+                double v = -rdx[idx] - dnu[jj * n + r];
+                if (j < T) {
+                    const double* dj = dnu + j * n;
+                    for (int c = 0; c < n; ++c) v += M.A1[c * n + r] * dj[c];
+                }
+                if (var2 && j + 1 < T) {
+                    const double* dj = dnu + (j + 1) * n;
+                    for (int c = 0; c < n; ++c) v += M.A2[c * n + r] * dj[c];
+                }
+                if (j == T && M.has_xf) v -= dnu[T * n + r];
+                rdx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);               // reuse as d_x
+            }
+            const double beta_e = fr_block_sum(be, red);
+            const double eps2 = fr_block_sum(e2, red);
+            // closed form of backtracking_inf_newton.m:2-11 with the frozen barrier gradient:
+            // ||r(t)||^2 - ((1-al t) rho)^2 = t * gq(t)
+            double t = 1.0;
+            {
+                const double al = 1e-4;
+                int halv = 0;
+                while (true) {
+                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2 - 2.0 * (1.0 - t) * beta_e + t * eps2;
+                    if (gq <= 0.0) break;
+                    t *= 0.5;
+                    if (++halv >= FR_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                }
+            }
+            for (int idx = tid; idx < Nz; idx += FR_THREADS) {
+                const int j = idx / s, e = idx - j * s;
+                zp[idx] += t * (e < m ? phu[j * m + e] : rdx[j * n + e - m]);
+            }
+            for (int idx = tid; idx < nbn; idx += FR_THREADS) nu[idx] += t * dnu[idx];
+            if (step && tid == 0 && it < step_ld) step[(size_t)p * step_ld + it] = t;
+            ++nsteps;
+            __syncthreads();
+        }
+        if (nuout)
+            for (int idx = tid; idx < nbn; idx += FR_THREADS) nuout[(size_t)p * nbn + idx] = nu[idx];
+        if (tid == 0) {
+            if (status) status[p] = st;
+            if (iters) iters[p] = nsteps;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+size_t fmpc_ramp_lds_bytes(int n, int m) {
+    const size_t d = (size_t)m * n + 3 * (size_t)n * (n + 1) + m + 2 * (size_t)n + 8;
+    return d * sizeof(double);
+}
+size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb) { return fr_ws_layout(n, m, T, nb).total; }
+
+hipError_t fmpc_ramp_prepare(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void*)fmpc_newton_ramp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const double* dumax, int batch, int grid,
+                            const double* x0, const double* x0p, const double* w, const double* uprev,
+                            const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
+                            double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
+                            size_t ws_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(fmpc_newton_ramp, dim3(grid), dim3(FR_THREADS), fmpc_ramp_lds_bytes(M.n, M.m), stream, M, dumin,
+                       dumax, batch, x0, x0p, w, uprev, zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step,
+                       step_ld, ws, ws_stride);
+    return hipGetLastError();
+}

@@ -86,6 +86,7 @@ struct FpParams {
 };
 
 size_t fmpc_panel_lds_bytes(int nb, int mp);
+size_t fmpc_panel_lds_used(int nb, int mp, int nsteps);
 hipError_t fmpc_panel_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_panel(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
 size_t fmpc_dz_lds_bytes(int mp);

@@ -161,10 +161,13 @@ class Fast_MPC2:
         rng = self.rng if self.rng is not None else np.random.default_rng()
         return rng.random(h.nu_len)                 # nu = rand(length(b),1), inf_newton_solver.m:2
 
+    def _u_prev_for_solve(self):
+        return None                                  # VAR_2: no ramp rows (fast_mpc_ineq_const.m:61-79 commented out)
+
     def _solve(self, h, z_init, nw, k, nu0):
         z, info = h.solve(self.x0, self.x0_pre if self.var_order == 2 else None, self.w,
                           z_init=z_init, nu0=self._draw_nu0(h, nu0), n_newton=nw, k=k,
-                          return_info=True)
+                          return_info=True, u_prev=self._u_prev_for_solve())
         st = int(info["status"][0])
         if st < 0:                                   # chol() error in the reference
             raise FastMPCError(st, "inf_newton_solver")
@@ -246,9 +249,9 @@ class Fast_MPC2_VAR1(Fast_MPC2):
 
     The device path solves the *intended* VAR(1) dynamics (VAR_2 code with A2 = 0; the reference's
     misplaced row block VAR_1/fast_mpc_eq_const.m:36 is not reproduced).
-    VAR_1's ramp-rate rows (VAR_1/fast_mpc_ineq_const.m:58-76) are not on the device yet, so the
-    caller has to opt out of them explicitly with ramp=False; otherwise every driver raises
-    FMPC_E_UNSUPPORTED rather than silently solving a different problem."""
+    VAR_1's ramp-rate rows (VAR_1/fast_mpc_ineq_const.m:58-76: du_min <= u_j - u_{j-1} <= du_max with
+    u_{-1} = u_prev) are on by default, as in the reference (the ramp-rate kernel, fmpc_kernel_ramp.hip);
+    ramp=False solves with the box rows only."""
 
     var_order = 1
 
@@ -258,8 +261,21 @@ class Fast_MPC2_VAR1(Fast_MPC2):
                          u_prev, A, None, B, w, xf, x_init, device=device, rng=rng)
         self.ramp = bool(ramp)
 
-    def _handle(self):
+    def _check(self):
+        n, m, T = super()._check()
         if self.ramp:
-            raise FastMPCError(_lib.FMPC_E_UNSUPPORTED,
-                               "VAR_1 ramp-rate constraints are not on the device yet (pass ramp=False)")
-        return super()._handle()
+            E = lambda msg: FastMPCError(_lib.FMPC_E_DIM, msg)
+            if self.du_min is None or self.du_max is None or self.du_min.shape[0] != m or self.du_max.shape[0] != m:
+                raise E("Check ramp rate constraint dimension")
+            if self.u_prev is None or self.u_prev.shape[0] != m:
+                raise E("Check u_prev dimension")
+        return n, m, T
+
+    def _handle(self):
+        h = super()._handle()
+        if self.ramp:
+            h.set_ramp(self.du_min, self.du_max)     # (bounds live in the cached handle; set per call, m doubles)
+        return h
+
+    def _u_prev_for_solve(self):
+        return self.u_prev if self.ramp else None

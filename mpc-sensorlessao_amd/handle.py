@@ -85,10 +85,19 @@ class FastMPCHandle:
             pass
 
     # ------------------------------------------------------------------ host buffers
+    def set_ramp(self, du_min, du_max):
+        """Ramp-rate bounds of the VAR_1 variant (VAR_1/fast_mpc_ineq_const.m:58-76): fmpc_set_ramp.
+        Afterwards `solve(..., u_prev=...)` / `solve_device(..., u_prev=...)` add the ramp rows."""
+        du_min = _f64(du_min, (self.m,), "du_min"); du_max = _f64(du_max, (self.m,), "du_max")
+        rc = self._lib.fmpc_set_ramp(self._h, _ptr(du_min), _ptr(du_max))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_set_ramp")
+
     def solve(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
-              return_info=False, check=True):
+              return_info=False, check=True, u_prev=None):
         """One `inf_newton_solver` per problem.  x0: (batch, n) or (n,).  Returns z (batch, N_z)
-        (or (N_z,) for a single vector input); with return_info also a dict nu/status/iters/step."""
+        (or (N_z,) for a single vector input); with return_info also a dict nu/status/iters/step.
+        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`)."""
         single = np.asarray(x0).ndim == 1
         x0 = _f64(x0)
         batch = 1 if single else x0.shape[0]
@@ -104,11 +113,17 @@ class FastMPCHandle:
         status = np.zeros(batch, dtype=np.int32)
         iters = np.zeros(batch, dtype=np.int32)
         step = np.empty((batch, sld))
-        rc = self._lib.fmpc_solve(self._h, batch, _ptr(x0), _ptr(x0_pre), _ptr(w), _ptr(z_init),
-                                  _ptr(nu0), n_newton, float(k), _ptr(z), _ptr(nu), _ptr(status),
-                                  _ptr(iters), _ptr(step))
+        if u_prev is not None:
+            u_prev = _f64(u_prev, (batch, self.m), "u_prev")
+            rc = self._lib.fmpc_solve_ramp(self._h, batch, _ptr(x0), _ptr(x0_pre), _ptr(w), _ptr(u_prev),
+                                           _ptr(z_init), _ptr(nu0), n_newton, float(k), _ptr(z), _ptr(nu),
+                                           _ptr(status), _ptr(iters), _ptr(step))
+        else:
+            rc = self._lib.fmpc_solve(self._h, batch, _ptr(x0), _ptr(x0_pre), _ptr(w), _ptr(z_init),
+                                      _ptr(nu0), n_newton, float(k), _ptr(z), _ptr(nu), _ptr(status),
+                                      _ptr(iters), _ptr(step))
         if rc < 0 and check:
-            raise FastMPCError(rc, "fmpc_solve")
+            raise FastMPCError(rc, "fmpc_solve_ramp" if u_prev is not None else "fmpc_solve")
         zr = z[0] if single else z
         if return_info:
             return zr, {"nu": nu[0] if single else nu, "status": status, "iters": iters,
@@ -139,9 +154,10 @@ class FastMPCHandle:
 
     # ------------------------------------------------------------------ device tensors
     def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
-                     z_out=None, nu_out=None, status=None, iters=None, step=None):
+                     z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None):
         """Asynchronous solve on torch CUDA(HIP) tensors, on torch's current stream.
-        Returns (z_out, status, iters).  Nothing is copied through the host."""
+        Returns (z_out, status, iters).  Nothing is copied through the host.
+        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`)."""
         import torch
 
         def chk(t, cols, name, dtype=torch.float64):
@@ -156,7 +172,7 @@ class FastMPCHandle:
         batch = x0.shape[0]
         dev = x0.device
         chk(x0, self.n, "x0"); chk(x0_pre, self.n, "x0_pre"); chk(w, self.T * self.n, "w")
-        chk(z_init, self.nz, "z_init"); chk(nu0, self.nu_len, "nu0")
+        chk(z_init, self.nz, "z_init"); chk(nu0, self.nu_len, "nu0"); chk(u_prev, self.m, "u_prev")
         n_newton = 0 if n_newton is None else int(n_newton)
         if z_out is None:
             z_out = torch.empty((batch, self.nz), dtype=torch.float64, device=dev)
@@ -170,11 +186,16 @@ class FastMPCHandle:
             chk(step, self._lib.fmpc_step_ld(n_newton), "step")
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
-                                         n_newton, float(k), p(z_out), p(nu_out), p(status),
-                                         p(iters), p(step), stream)
+        if u_prev is not None:
+            rc = self._lib.fmpc_solve_ramp_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
+                                                  p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                                  p(iters), p(step), stream)
+        else:
+            rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
+                                             n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                             p(iters), p(step), stream)
         if rc != _lib.FMPC_OK:
-            raise FastMPCError(rc, "fmpc_solve_device")
+            raise FastMPCError(rc, "fmpc_solve_ramp_device" if u_prev is not None else "fmpc_solve_device")
         return z_out, status, iters
 
     def loop_inputs_device(self, a_k, x0_last, u1, u2, x0, x0_pre, w):

@@ -40,9 +40,20 @@ if nw == 1 and hasattr(lib, "fmpc_debug_panel_timing"):
             print("  %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwav, 100.0 * out[i] / tot))
         print("  total %.0f cycles/wave" % (tot / nwav))
         print("  S1 detail per wave: setup + lower bound of ||r_d|| %.0f, stages 0/1 %.0f, stages >= 2 %.0f" % tuple(out[8 + i] / nwav for i in range(3)))
-if nw == 1 and hasattr(lib, "fmpc_debug_dz_timing"):
-    lib.fmpc_debug_dz_timing(out)
-    nwv = out[7] or 1
-    print("d_z kernel, per-wave-average cycles (%d waves over 3 reps):" % nwv)
-    for nm, i in [("LDS init", 0), ("loads issued", 1), ("products, element-wise work, stores", 2)]:
-        print("  %-36s %12.0f" % (nm, out[i] / nwv))
+if nw == 1 and hasattr(lib, "fmpc_debug_dz_trace"):
+    import numpy as np
+    nwav = min(8192, 8 * ((((B + 15) // 16 + 7) // 8 * 30 + 7) // 8) * 8)
+    tr = np.zeros(4 * nwav, dtype=np.uint64)
+    lib.fmpc_debug_dz_trace(tr.ctypes.data_as(C.c_void_p), nwav)
+    tr = tr.reshape(-1, 4).astype(np.float64)
+    tr = tr[tr[:, 0] > 0]
+    t0 = tr[:, 0].min()
+    tr = (tr - t0) * 0.01                      # us (100 MHz)
+    q = lambda a: "min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max())
+    print("d_z trace of the last launch (%d waves), us since the first wave started:" % len(tr))
+    print("  wave start          ", q(tr[:, 0]))
+    print("  LDS image ready     ", q(tr[:, 1]))
+    print("  loads issued        ", q(tr[:, 2]))
+    print("  done                ", q(tr[:, 3]))
+    print("  wave life time      ", q(tr[:, 3] - tr[:, 0]))
+    print("  compute+store phase ", q(tr[:, 3] - tr[:, 2]))

@@ -93,11 +93,13 @@ def test_fast_mpc2_validation_mirrors_reference_errors(pkg):
     assert z0.shape == (130,) and np.array_equal(z0, np.zeros(130))
     with pytest.raises(NotImplementedError):
         obj.matlab_solve()
-    v1 = pkg.Fast_MPC2_VAR1(md["Q"], md["R"], [], md["Qf"], [], [], [], md["x_min"], md["x_max"], md["u_min"], md["u_max"],
-                            -np.ones(5), np.ones(5), 10, data["x0"][0], np.zeros(5), md["A1"], md["B"], data["w"][0], [], [])
-    with pytest.raises(pkg.FastMPCError) as e:
-        v1.mpc_fixed_log_newton(1, 0.01)
-    assert e.value.code == pkg.FMPC_E_UNSUPPORTED          # ramp rows are not on the device: refuse, do not approximate
+    # VAR_1: the ramp rows need du_min, du_max (m each) and u_prev (VAR_1/fast_mpc_ineq_const.m:58-76)
+    for du, up in (([], np.zeros(5)), (np.ones(4), np.zeros(5)), (np.ones(5), np.zeros(3))):
+        v1 = pkg.Fast_MPC2_VAR1(md["Q"], md["R"], [], md["Qf"], [], [], [], md["x_min"], md["x_max"], md["u_min"], md["u_max"],
+                                -np.asarray(du), du, 10, data["x0"][0], up, md["A1"], md["B"], data["w"][0], [], [])
+        with pytest.raises(pkg.FastMPCError) as e:
+            v1.mpc_fixed_log_newton(1, 0.01)
+        assert e.value.code == pkg.FMPC_E_DIM
 
 
 def test_deinterleave_and_shard_range(pkg):
