@@ -1005,7 +1005,9 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
     const int max_iter = n_newton > 0 ? n_newton : 1000;
     // one workgroup per problem in flight; the workspace holds the dense Y of each (nb n)^2 doubles
     const size_t stride = fmpc_ramp_ws_doubles(h->n, h->m, h->T, h->nb);
-    int cap = 2 * h->num_cu;
+    int wgpc = 3;                                                 // LDS (47 KB at n = 27, m = 144) and VGPRs allow 3 workgroups per CU
+    if (const char* e = getenv("FMPC_RAMP_WG_PER_CU")) { wgpc = atoi(e); if (wgpc < 1) wgpc = 1; }
+    int cap = wgpc * h->num_cu;
     const size_t budget = (size_t)2 << 30;                         // doubles (16 GB) for all workgroups together
     if ((size_t)cap * stride > budget) cap = (int)(budget / stride);
     if (cap < 1) return FMPC_E_ALLOC;

@@ -18,15 +18,21 @@
 //   P3  Y assembled block by block into the HBM workspace (lower block triangle)
 //   P4  blocked left-looking Cholesky of Y (n x n tiles through LDS), forward and backward substitution -> d_nu
 //   P5  d_z = Phi^-1(-r_d - C' d_nu) (tridiagonal solves), closed-form line search, update
-// This is the functional path for BASELINE config 0 (VAR(1), T = 10); it is written for clarity on plain VALU
-// code, not tuned like the box-only paths.
+// The two O(n^3)-class parts run on the matrix cores (v_mfma_f64_16x16x4_f64, generic 16 x 16 tiling with masked
+// edges): the B diag(g) B' products of P3 (k = actuators) and the panel updates of the Cholesky factorisation (k = the
+// columns already factored).  This is the path of BASELINE config 0 (VAR(1), T = 10); measured numbers in DESIGN.md §6.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fmpc_device.h"
 #include "../../include/fastmpc.h"
 
 #define FR_THREADS 256
+#define FR_WAVES (FR_THREADS / 64)
 #define FR_MAX_HALVINGS 64
+#define FR_MAXKS 16                     // k-steps of 4 covering n <= 64
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ double fr_wave_sum(double v) {
 #pragma unroll
@@ -45,7 +51,22 @@ __device__ __forceinline__ double fr_block_sum(double v, double* red) {
     return s;
 }
 
-struct FrWsLayout { size_t b, nu, hs, er, gr, dg, lo, rdu, rdx, phx, phu, rp, y, dnu, G, Y, total; };
+#ifdef FW_TIMING
+// per-phase time of workgroup 0 (100 MHz ticks): P1, P2, P3, P4 factor, P4 substitutions, P5
+__device__ unsigned long long fr_timing[8];
+extern "C" int fmpc_debug_ramp_timing(unsigned long long* out) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fr_timing), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fr_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#define FR_TICK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long _t = (unsigned long long)wall_clock64(); fr_timing[k] += _t - _t0; _t0 = _t; } } while (0)
+#define FR_T0() unsigned long long _t0 = (unsigned long long)wall_clock64()
+#else
+#define FR_TICK(k)
+#define FR_T0()
+#endif
+
+struct FrWsLayout { size_t b, nu, hs, er, gr, dg, lo, rdu, rdx, phx, phu, rp, y, dnu, G, Y, W, total; };
 __host__ __device__ static inline FrWsLayout fr_ws_layout(int n, int m, int T, int nb) {
     FrWsLayout L; size_t o = 0;
     const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
@@ -54,7 +75,8 @@ __host__ __device__ static inline FrWsLayout fr_ws_layout(int n, int m, int T, i
     L.rdu = o; o += Tm;  L.rdx = o; o += Tn;  L.phx = o; o += Tn;  L.phu = o; o += Tm;
     L.rp = o; o += nbn;  L.y = o; o += nbn;   L.dnu = o; o += nbn;
     L.G = o; o += (size_t)T * (T + 1) / 2 * m;
-    L.Y = o; o += nbn * nbn;
+    L.Y = o; o += (nbn + 1) * nbn;          // dense Y / its factor, row-major, plus the rhs as row nbn
+    L.W = o; o += (size_t)nb * n * n;       // L_JJ^-1 per diagonal block
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -66,7 +88,7 @@ __device__ __forceinline__ void fr_tri_solve(const double* dg, const double* lo,
     for (int j = T - 2; j >= 0; --j) f[j * m + c] = f[j * m + c] / dg[j * m + c] - lo[j * m + c] * f[(j + 1) * m + c];
 }
 
-extern "C" __global__ void __launch_bounds__(FR_THREADS)
+extern "C" __global__ void __launch_bounds__(FR_THREADS, 3)
 fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double* __restrict__ dumax, int batch,
                  const double* __restrict__ x0, const double* __restrict__ x0p, const double* __restrict__ w,
                  const double* __restrict__ uprev, const double* zinit, const double* __restrict__ nu0,
@@ -76,18 +98,18 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = M.n, m = M.m, T = M.T, nb = M.nb;
     const int s = n + m, Nz = T * s, nbn = nb * n, ldt = n + 1, tsz = n * ldt;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int ntile = (n + 15) >> 4;
     const bool var2 = M.var2 != 0;
 
     // ---- LDS carve
     double* sBt = lds;                    // m*n   Bt[c*n + r] = B[r][c]
-    double* tA = sBt + (size_t)m * n;     // tiles n*ldt
-    double* tB = tA + tsz;
-    double* tC = tB + tsz;
-    double* sg = tC + tsz;                // m     g^{IJ} of the current block pair
-    double* sv = sg + m;                  // n     vector of the triangular solves
+    double* tA = sBt + (size_t)m * n;     // n*ldt: the diagonal block being factored
+    double* tB = tA + tsz;                // n*ldt: its inverse factor
+    double* sv = tB + tsz;                // n     vector of the backward substitution
     double* srs = sv + n;                 // n     1/sqrt(pivot)
-    double* red = srs + n;                // 8
+    double* sred = srs + n;               // 4 x 64 partial sums of the backward substitution
+    double* red = sred + 4 * 64;          // 8
 
     for (int i = tid; i < m * n; i += FR_THREADS) sBt[i] = M.Bt[i];
 
@@ -97,6 +119,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
     double* gr = wsp + L.gr;   double* dg = wsp + L.dg;   double* lo = wsp + L.lo;   double* rdu = wsp + L.rdu;
     double* rdx = wsp + L.rdx; double* phx = wsp + L.phx; double* phu = wsp + L.phu; double* rp = wsp + L.rp;
     double* y = wsp + L.y;     double* dnu = wsp + L.dnu; double* G = wsp + L.G;     double* Yd = wsp + L.Y;
+    double* Wg = wsp + L.W;
 
     for (int p = blockIdx.x; p < batch; p += gridDim.x) {
         double* zp = zout + (size_t)p * Nz;
@@ -130,6 +153,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
         int st = FMPC_OK, nsteps = 0;
         for (int it = 0; it < max_iter; ++it) {
             // ================= P1: slacks and residuals
+            FR_T0();
             double acc_d = 0.0, acc_p = 0.0;
             for (int idx = tid; idx < T * m; idx += FR_THREADS) {       // ramp terms of stage j (needed by j and j-1)
                 const int j = idx / m, c = idx - j * m;
@@ -196,6 +220,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             const double rho2 = fr_block_sum(acc_d, red) + rp2;
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
+            FR_TICK(0);
 
             // ================= P2: per actuator LDL' of the tridiagonal u-part of Phi, Phi_u^-1 r_d, explicit inverse
             int bad = 0;
@@ -253,159 +278,205 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 y[idx] = rp[idx] - cv;
             }
             __syncthreads();
+            FR_TICK(1);
 
-            // ================= P3: Y (lower block triangle, dense) into the workspace
-            for (int I = 0; I < nb; ++I)
-                for (int J = 0; J <= I; ++J) {
+            // ================= P3: Y (lower block triangle, dense) into the workspace; the rhs as an extra ROW (nbn)
+            // Y_IJ = Yx_IJ + B diag(g^{JI}) B' on the matrix cores: a wave per 16 x 16 output tile, k = 4 actuators per
+            // MFMA; A operand B[a][c] g_c (row a = lane % 16, c = 4 ks + lane / 16), B operand B[b][c]; result
+            // register r of lane (lk, li) is element (4 r + lk, li) of the tile.
+            for (int idx = tid; idx < nbn; idx += FR_THREADS) Yd[(size_t)nbn * nbn + idx] = y[idx];
+            // (no workgroup barrier in this phase: every wave walks its own (block, tile) tasks)
+            {
+                const int nblk = nb * (nb + 1) / 2, tpb = ntile * ntile;
+                for (int task = wv; task < nblk * tpb; task += FR_WAVES) {
+                    const int blk = task / tpb, tp = task - blk * tpb;
+                    int I = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);          // blk = I (I + 1) / 2 + J , J <= I
+                    while (I * (I + 1) / 2 > blk) --I;
+                    while ((I + 1) * (I + 2) / 2 <= blk) ++I;
+                    const int J = blk - I * (I + 1) / 2;
+                    const int ta = tp / ntile, tb = tp - ta * ntile;
                     const bool hasu = I < T;                         // (J <= I): both stages carry u
-                    if (hasu) {
-                        const size_t pr = (size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J);
-                        for (int c = tid; c < m; c += FR_THREADS) sg[c] = G[pr * m + c];
-                    }
-                    __syncthreads();
                     const double* Yc = nullptr; bool tr = false;
                     if (I == J) Yc = M.Yblk + (size_t)M.idxD[I] * n * n;
                     else if (I == J + 1 && M.idx1[J] >= 0) { Yc = M.Yblk + (size_t)M.idx1[J] * n * n; tr = true; }
                     else if (I == J + 2 && M.idx2[J] >= 0) { Yc = M.Yblk + (size_t)M.idx2[J] * n * n; tr = true; }
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                        const int a = idx / n, bb = idx - a * n;
-                        double acc = Yc ? (tr ? Yc[bb * n + a] : Yc[idx]) : 0.0;
-                        if (hasu) {
-                            double t = 0.0;
-                            for (int c = 0; c < m; ++c) t += sBt[c * n + a] * sg[c] * sBt[c * n + bb];
-                            acc += t;
+                    d4 acc = {0, 0, 0, 0};
+                    if (hasu) {
+                        const double* gv = G + ((size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J)) * m;
+                        const int ra = 16 * ta + li < n ? 16 * ta + li : n - 1, rb = 16 * tb + li < n ? 16 * tb + li : n - 1;
+                        int c0 = 0;
+                        for (; c0 + 16 <= m; c0 += 16) {
+                            double gq[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) gq[q] = gv[c0 + 4 * q + lk];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c = c0 + 4 * q + lk;
+                                acc = MFMA64(sBt[c * n + ra] * gq[q], sBt[c * n + rb], acc);
+                            }
                         }
-                        Yd[(size_t)(I * n + a) * nbn + J * n + bb] = acc;
+                        for (; c0 < m; c0 += 4) {
+                            const int c = c0 + lk;
+                            const bool ok = c < m;
+                            const int cc = ok ? c : m - 1;
+                            const double bv = sBt[cc * n + rb];
+                            const double av = ok ? sBt[cc * n + ra] * gv[cc] : 0.0;
+                            acc = MFMA64(av, bv, acc);
+                        }
                     }
-                    __syncthreads();
+                    const int bcol = 16 * tb + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int arow = 16 * ta + 4 * r + lk;
+                        if (arow < n && bcol < n)
+                            Yd[(size_t)(I * n + arow) * nbn + J * n + bcol] =
+                                acc[r] + (Yc ? (tr ? Yc[bcol * n + arow] : Yc[arow * n + bcol]) : 0.0);
+                    }
                 }
+            }
+            __syncthreads();
+            FR_TICK(2);
 
-            // ================= P4: blocked left-looking Cholesky of Y, in place (L overwrites the lower triangle)
+            // ================= P4: blocked left-looking Cholesky of Y in place, block column J at a time:
+            //   1. M[r][:] = Y[r][J-block] - L[r][0:K] L[J-block rows][0:K]'  for every row r >= J n (K = J n): MFMA,
+            //      operands straight from the workspace (L2 / L1); the rhs row nbn rides along (forward substitution)
+            //   2. S = M of the diagonal block -> LDS; potrf with the SAME row operations applied to an identity, which
+            //      leaves W = L_JJ^-1 (no serial triangular solves)
+            //   3. L[r][J-block] = M[r][:] W'  for the rows below (and the rhs row): MFMA, K = n
             bool fail = false;
             for (int J = 0; J < nb && !fail; ++J) {
-                // ---- diagonal block: S = Y_JJ - sum_K L_JK L_JK'
-                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                    const int a = idx / n, bb = idx - a * n;
-                    tA[a * ldt + bb] = Yd[(size_t)(J * n + a) * nbn + J * n + bb];
+                const int K = J * n, r_lo = J * n, nrow = nbn + 1 - r_lo;
+                const int nrt = (nrow + 15) >> 4;
+                if (K > 0) {
+                    for (int tp = wv; tp < nrt * ntile; tp += FR_WAVES) {
+                        const int rt = tp / ntile, tb = tp - rt * ntile;
+                        const int ra = r_lo + 16 * rt + li <= nbn ? r_lo + 16 * rt + li : nbn;
+                        const int rb = 16 * tb + li < n ? r_lo + 16 * tb + li : r_lo + n - 1;
+                        const double* pa = Yd + (size_t)ra * nbn;
+                        const double* pb = Yd + (size_t)rb * nbn;
+                        d4 acc = {0, 0, 0, 0};
+                        int c0 = 0;
+                        for (; c0 + 16 <= K; c0 += 16) {
+                            double av[4], bv[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { av[q] = pa[c0 + 4 * q + lk]; bv[q] = pb[c0 + 4 * q + lk]; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc = MFMA64(av[q], bv[q], acc);
+                        }
+                        for (; c0 < K; c0 += 4) {
+                            const int c = c0 + lk;
+                            const bool ok = c < K;
+                            const double a1 = pa[ok ? c : K - 1], b1 = pb[ok ? c : K - 1];
+                            acc = MFMA64(ok ? a1 : 0.0, b1, acc);
+                        }
+                        const int bcol = 16 * tb + li;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = r_lo + 16 * rt + 4 * r + lk;
+                            if (row <= nbn && bcol < n) Yd[(size_t)row * nbn + r_lo + bcol] -= acc[r];
+                        }
+                    }
+                    __syncthreads();
                 }
-                for (int K = 0; K < J; ++K) {
-                    __syncthreads();
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                        const int a = idx / n, k2 = idx - a * n;
-                        tB[a * ldt + k2] = Yd[(size_t)(J * n + a) * nbn + K * n + k2];
-                    }
-                    __syncthreads();
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                        const int a = idx / n, bb = idx - a * n;
-                        if (bb > a) continue;
-                        double t = 0.0;
-                        for (int k2 = 0; k2 < n; ++k2) t += tB[a * ldt + k2] * tB[bb * ldt + k2];
-                        tA[a * ldt + bb] -= t;
-                    }
+                // ---- 2. diagonal block
+                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                    const int a2 = idx / n, bb = idx - a2 * n;
+                    tA[a2 * ldt + bb] = Yd[(size_t)(r_lo + a2) * nbn + r_lo + bb];
+                    tB[a2 * ldt + bb] = a2 == bb ? 1.0 : 0.0;
                 }
                 __syncthreads();
-                // ---- potrf, right-looking, one barrier per column; scaling deferred
                 for (int k2 = 0; k2 < n; ++k2) {
                     const double piv = tA[k2 * ldt + k2];
                     if (!(piv > 0.0) || isinf(piv)) { fail = true; break; }      // uniform
                     const double ip = 1.0 / piv;
                     if (tid == 0) srs[k2] = 1.0 / sqrt(piv);
                     const int rem = n - k2 - 1;
-                    for (int idx = tid; idx < rem * rem; idx += FR_THREADS) {
-                        const int r = k2 + 1 + idx / rem, c = k2 + 1 + idx % rem;
-                        if (c <= r) tA[r * ldt + c] -= tA[r * ldt + k2] * tA[c * ldt + k2] * ip;
+                    // rows r > k2:  S[r][c] -= l S[c][k2] (c = k2+1 .. r) ,  Wm[r][c] -= l Wm[k2][c] (c = 0 .. k2) ,  l = S[r][k2] / piv
+                    for (int idx = tid; idx < rem * n; idx += FR_THREADS) {
+                        const int r = k2 + 1 + idx / n, c = idx % n;
+                        const double l = tA[r * ldt + k2] * ip;
+                        if (c <= k2) tB[r * ldt + c] -= l * tB[k2 * ldt + c];
+                        else if (c <= r) tA[r * ldt + c] -= l * tA[c * ldt + k2];
                     }
                     __syncthreads();
                 }
                 if (fail) break;
-                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                    const int r = idx / n, c = idx - r * n;
-                    if (c <= r) {
-                        const double v = tA[r * ldt + c] * srs[c];               // L[r][c] = S[r][c]/sqrt(p_c)
-                        tA[r * ldt + c] = v;
-                        Yd[(size_t)(J * n + r) * nbn + J * n + c] = v;
+                {
+                    double* Wj = Wg + (size_t)J * n * n;
+                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                        const int r = idx / n, c = idx - r * n;
+                        const double v = c <= r ? tB[r * ldt + c] * srs[r] : 0.0;    // L^-1 = D^-1/2 (unit lower)^-1
+                        tB[r * ldt + c] = v;
+                        Wj[idx] = v;
                     }
                 }
                 __syncthreads();
-                // ---- blocks below: L_IJ = (Y_IJ - sum_K L_IK L_JK') L_JJ^-T
-                for (int I = J + 1; I < nb; ++I) {
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                        const int a = idx / n, bb = idx - a * n;
-                        tC[a * ldt + bb] = Yd[(size_t)(I * n + a) * nbn + J * n + bb];
-                    }
-                    for (int K = 0; K < J; ++K) {
-                        __syncthreads();
-                        for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                            const int a = idx / n, k2 = idx - a * n;
-                            tB[a * ldt + k2] = Yd[(size_t)(J * n + a) * nbn + K * n + k2];
+                // ---- 3. rows below the diagonal block (and the rhs row): X = M W'.  A wave owns whole rows: it reads a
+                //         row tile completely before it overwrites it.
+                {
+                    const int r1 = r_lo + n, nrow2 = nbn + 1 - r1;
+                    const int nrt2 = (nrow2 + 15) >> 4;
+                    for (int rt = wv; rt < nrt2; rt += FR_WAVES) {
+                        const int ra = r1 + 16 * rt + li <= nbn ? r1 + 16 * rt + li : nbn;
+                        const double* pa = Yd + (size_t)ra * nbn + r_lo;
+                        double av[FR_MAXKS];
+#pragma unroll
+                        for (int ks = 0; ks < FR_MAXKS; ++ks) {
+                            const int c = 4 * ks + lk;
+                            const double t1 = pa[c < n ? c : n - 1];
+                            av[ks] = c < n ? t1 : 0.0;
                         }
-                        __syncthreads();
-                        for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                            const int a = idx / n, bb = idx - a * n;
-                            const double* li = Yd + (size_t)(I * n + a) * nbn + K * n;       // row a of L_IK (HBM/L2)
-                            double t = 0.0;
-                            for (int k2 = 0; k2 < n; ++k2) t += li[k2] * tB[bb * ldt + k2];
-                            tC[a * ldt + bb] -= t;
+                        // (all of the row tile is in registers now: the column tiles may be overwritten one by one)
+#pragma nounroll
+                        for (int tb = 0; tb < ntile; ++tb) {
+                            d4 acc = {0, 0, 0, 0};
+                            const int rb = 16 * tb + li < n ? 16 * tb + li : n - 1;
+#pragma unroll
+                            for (int ks = 0; ks < FR_MAXKS; ++ks) {
+                                if (4 * ks < n) {
+                                    const int c = 4 * ks + lk < n ? 4 * ks + lk : n - 1;
+                                    acc = MFMA64(av[ks], tB[rb * ldt + c], acc);
+                                }
+                            }
+                            const int bcol = 16 * tb + li;
+                            if (bcol < n) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = r1 + 16 * rt + 4 * r + lk;
+                                    if (row <= nbn) Yd[(size_t)row * nbn + r_lo + bcol] = acc[r];
+                                }
+                            }
                         }
                     }
-                    __syncthreads();
-                    for (int a = tid; a < n; a += FR_THREADS) {                    // row a: x L_JJ' = tC[a, :]
-                        for (int bb = 0; bb < n; ++bb) {
-                            double v = tC[a * ldt + bb];
-                            for (int j = 0; j < bb; ++j) v -= tC[a * ldt + j] * tA[bb * ldt + j];
-                            tC[a * ldt + bb] = v / tA[bb * ldt + bb];
-                        }
-                    }
-                    __syncthreads();
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
-                        const int a = idx / n, bb = idx - a * n;
-                        Yd[(size_t)(I * n + a) * nbn + J * n + bb] = tC[a * ldt + bb];
-                    }
-                    __syncthreads();
-                }
-            }
-            if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
-            __syncthreads();
-            // ---- forward substitution  L yy = y   (block by block; the diagonal block on wave 0, lane = entry)
-            for (int J = 0; J < nb; ++J) {
-                for (int a = tid; a < n; a += FR_THREADS) {
-                    const double* lr = Yd + (size_t)(J * n + a) * nbn;
-                    double v = y[J * n + a];
-                    for (int c = 0; c < J * n; ++c) v -= lr[c] * y[c];
-                    sv[a] = v;
-                }
-                __syncthreads();
-                if (tid < 64) {
-                    double v = tid < n ? sv[tid] : 0.0;
-                    for (int r = 0; r < n; ++r) {
-                        const double xr = __shfl(v, r, 64) / Yd[(size_t)(J * n + r) * nbn + J * n + r];
-                        if (tid > r && tid < n) v -= Yd[(size_t)(J * n + tid) * nbn + J * n + r] * xr;
-                        else if (tid == r) v = xr;
-                    }
-                    if (tid < n) y[J * n + tid] = v;
                 }
                 __syncthreads();
             }
-            // ---- backward substitution  L' d_nu = yy
+            if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            FR_TICK(3);
+            // ---- backward substitution  L' d_nu = yy  (yy = the rhs row after the factorisation):
+            //      v = yy_J - sum_{r below} L[r][J-block] d_nu[r] ;  d_nu_J = W_J' v
             for (int J = nb - 1; J >= 0; --J) {
-                for (int bb = tid; bb < n; bb += FR_THREADS) {
-                    double v = y[J * n + bb];
-                    for (int r = (J + 1) * n; r < nbn; ++r) v -= Yd[(size_t)r * nbn + J * n + bb] * dnu[r];
-                    sv[bb] = v;
+                const int r_lo = J * n, r1 = r_lo + n;
+                {
+                    const int bb = tid & 63, grp = tid >> 6;
+                    double part = 0.0;
+                    if (bb < n)
+                        for (int r = r1 + grp; r < nbn; r += FR_WAVES) part += Yd[(size_t)r * nbn + r_lo + bb] * dnu[r];
+                    sred[grp * 64 + bb] = part;
                 }
                 __syncthreads();
-                if (tid < 64) {
-                    double v = tid < n ? sv[tid] : 0.0;
-                    for (int r = n - 1; r >= 0; --r) {
-                        const double xr = __shfl(v, r, 64) / Yd[(size_t)(J * n + r) * nbn + J * n + r];
-                        if (tid < r) v -= Yd[(size_t)(J * n + r) * nbn + J * n + tid] * xr;
-                        else if (tid == r) v = xr;
-                    }
-                    if (tid < n) dnu[J * n + tid] = v;
+                if (tid < n) sv[tid] = Yd[(size_t)nbn * nbn + r_lo + tid] - (sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid]);
+                __syncthreads();
+                if (tid < n) {
+                    const double* Wj = Wg + (size_t)J * n * n;
+                    double v = 0.0;
+                    for (int bb = tid; bb < n; ++bb) v += Wj[bb * n + tid] * sv[bb];
+                    dnu[r_lo + tid] = v;
                 }
                 __syncthreads();
             }
 
+            FR_TICK(4);
             // ================= P5: d_z, line-search scalars, update
             for (int idx = tid; idx < T * m; idx += FR_THREADS) {           // rhs of Phi_u d_u = B' d_nu_j - r_d,u
                 const int j = idx / m, c = idx - j * m;
@@ -464,6 +535,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             if (step && tid == 0 && it < step_ld) step[(size_t)p * step_ld + it] = t;
             ++nsteps;
             __syncthreads();
+            FR_TICK(5);
         }
         if (nuout)
             for (int idx = tid; idx < nbn; idx += FR_THREADS) nuout[(size_t)p * nbn + idx] = nu[idx];
@@ -476,7 +548,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
 
 // ---------------------------------------------------------------- host side
 size_t fmpc_ramp_lds_bytes(int n, int m) {
-    const size_t d = (size_t)m * n + 3 * (size_t)n * (n + 1) + m + 2 * (size_t)n + 8;
+    const size_t d = (size_t)m * n + 2 * (size_t)n * (n + 1) + 2 * (size_t)n + 4 * 64 + 8;
     return d * sizeof(double);
 }
 size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb) { return fr_ws_layout(n, m, T, nb).total; }

@@ -66,8 +66,7 @@ def test_ramp_matches_dense_oracle(pkg, gpu, n, m, T, var_order, xf, nw):
 
 def test_ramp_config0_size(pkg, gpu):
     """BASELINE configs[0]: VAR(1), n = 27, m = 144, T = 10, ramp rows on (README.md:355-356: du = +-0.2121)."""
-    md = pkg.synthetic.make_model(27, 144, 10)
-    md = dict(md); md["var_order"] = 1; md["A2"] = np.zeros((27, 27))
+    md = pkg.synthetic.make_model(27, 144, 10, var_order=1)
     data = pkg.synthetic.make_replay_batch(md, r=2, steps=3)
     du = 0.2121 * np.ones(144)
     rng = np.random.default_rng(8)
