@@ -78,8 +78,8 @@ def cpu_baseline(pkg, model, data, n_newton):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--n-newton", type=int, default=N_NEWTON)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,6 +273,39 @@ def main():
                                           "sequential_steps": nsteps_}
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
                                          "depends on the previous first move, so only realisations batch", **cl)
+        # BASELINE configs[0] on the device: VAR(1), T = 10, ramp-rate rows on (VAR_1/fast_mpc_ineq_const.m:58-76;
+        # README.md:355-356 du = +-0.2121): dense Schur complement per problem and Newton step (fmpc_kernel_ramp.hip)
+        T0 = 10
+        m0 = pkg.synthetic.make_model(n, m, T0, var_order=1)
+        h0 = pkg.FastMPCHandle(m0["A1"], None, m0["B"], m0["Q"], m0["R"], m0["Qf"], m0["u_min"], m0["u_max"], m0["x_min"],
+                               m0["x_max"], T0, var_order=1, device=local_rank)
+        h0.set_ramp(-0.2121 * np.ones(m), 0.2121 * np.ones(m))
+        fl0 = T0 * (T0 + 1) / 2 * 2.0 * n * n * m + (T0 * n) ** 3 / 3.0 + 2.0 * (T0 * n) ** 2 + T0 * (6.0 * (2 * n * n + n * m) + 60.0 * (n + m))
+        rc0 = {"what": "configs[0] on the device: VAR(1), n=27, m=144, T=10, ramp-rate rows on; 200 timesteps of one realisation as a "
+                       "replay batch, and one problem at a time (latency)",
+               "flops_per_newton_iteration": fl0}
+        for B0, tag in ((200, "replay_200"), (1, "single")):
+            d0 = pkg.synthetic.make_replay_batch(m0, r=0, steps=B0)
+            tx0 = torch.from_numpy(d0["x0"]).to(dev); tn0 = torch.from_numpy(np.ascontiguousarray(d0["nu0"][:, :T0 * n])).to(dev)
+            tup = torch.from_numpy(0.05 * np.random.default_rng(7).standard_normal((B0, m))).to(dev)
+            z0 = torch.empty((B0, h0.nz), dtype=torch.float64, device=dev)
+            s0 = torch.empty(B0, dtype=torch.int32, device=dev); i0 = torch.empty(B0, dtype=torch.int32, device=dev)
+            for nw0 in (1, 5):
+                for _ in range(2):
+                    h0.solve_device(tx0, None, None, None, tn0, nw0, K_BAR, z_out=z0, status=s0, iters=i0, u_prev=tup)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    h0.solve_device(tx0, None, None, None, tn0, nw0, K_BAR, z_out=z0, status=s0, iters=i0, u_prev=tup)
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t0) / 10
+                assert int((s0 < 0).sum()) == 0
+                its = float(i0.sum().item())
+                rc0["%s_budget%d" % (tag, nw0)] = {"value": B0 / dt, "unit": "MPC steps/s", "ms_per_solve": dt * 1e3,
+                                                    "newton_iters_per_problem": its / B0,
+                                                    "tflops": fl0 * its / dt / 1e12, "frac_of_fp64_peak": fl0 * its / dt / 1e12 / FP64_PEAK_TFLOPS}
+        h0.close()
+        extra["config0_var1_ramp"] = rc0
         e5, k5, i5 = run(one_lane, 5, ksteps, 2)
         extra["budget5"] = {"what": "Newton budget 5 with the reference's exit test (test_fast_mpc.m:53,59)",
                             "value": B * ksteps / e5, "unit": "MPC steps/s", "kernel_ms": k5,

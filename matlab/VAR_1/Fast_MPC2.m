@@ -1,0 +1,47 @@
+classdef Fast_MPC2
+    % Drop-in replacement for Fast_MPC/VAR_1/Fast_MPC2.m (the VAR(1) variant WITH ramp-rate rows,
+    % VAR_1/fast_mpc_ineq_const.m:58-76) on the MI355X library (include/fastmpc.h, libfastmpc.so).
+    % Same 21-argument constructor (VAR_1/Fast_MPC2.m:26-27) and driver methods.  var_order = 1 makes
+    % fmpc_solve_once build the ramp rows du_min <= u_j - u_{j-1} <= du_max (u_{-1} = u_prev) from dumin, dumax,
+    % u_prev; pass [] for any of the three to solve with the box rows only.  The device solves the intended VAR(1)
+    % dynamics (the reference's misplaced row block VAR_1/fast_mpc_eq_const.m:36 is not reproduced).
+    % Cannot be executed in the build image (no MATLAB); mpc-sensorlessao_amd/fast_mpc2.py (Fast_MPC2_VAR1) is the
+    % tested twin.  One-time setup:  loadlibrary('libfastmpc', 'fastmpc.h')
+    properties
+        Q; R; S; q; r; Qf; qf; x_min; x_max; u_min; u_max; du_min; du_max
+        T; x0; u_prev; A; B; w; x_final; x_init
+        device = 0
+    end
+    methods
+        function cs = Fast_MPC2(Q,R,S,Qf,q,r,qf,xmin,xmax,umin,umax,dumin,dumax,T,x0,u_prev,A,B,w,xf,x_init)
+            if nargin > 1
+                cs.Q = Q; cs.R = R; cs.S = S; cs.Qf = Qf; cs.q = q; cs.r = r; cs.qf = qf;
+                cs.x_min = xmin; cs.x_max = xmax; cs.u_min = umin; cs.u_max = umax;
+                cs.du_min = dumin; cs.du_max = dumax; cs.T = T; cs.x0 = x0; cs.u_prev = u_prev;
+                cs.A = A; cs.B = B; cs.w = w; cs.x_final = xf; cs.x_init = x_init;
+            end
+        end
+        function x_opt = mpc_fixed_log_newton(obj,nw,k)
+            x_opt = obj.solve_once(obj.x_init, nw, k);
+        end
+        function x_opt = mpc_fixed_log(obj,k)
+            x_opt = obj.solve_once(obj.x_init, 0, k);
+        end
+    end
+    methods (Access = private)
+        function x_opt = solve_once(obj, z_init, nw, k)
+            n = size(obj.Q,1); m = size(obj.R,1); Nz = obj.T*(n+m);
+            nu0 = rand(obj.T*n + n*(~isempty(obj.x_final)), 1);  % inf_newton_solver.m:2, drawn here
+            z = zeros(Nz,1); iters = int32(0);
+            P = @(a) libpointer('doublePtr', a);                 % [] -> NULL
+            [rc, ~, ~] = calllib('libfastmpc','fmpc_solve_once', n, m, obj.T, 1, ...
+                P(obj.Q),P(obj.R),P(obj.S),P(obj.Qf),P(obj.q),P(obj.r),P(obj.qf), ...
+                P(obj.x_min),P(obj.x_max),P(obj.u_min),P(obj.u_max),P(obj.du_min),P(obj.du_max), ...
+                P(obj.x0),P([]),P(obj.u_prev),P(obj.A),P([]),P(obj.B), ...
+                P(obj.w),P(obj.x_final),P(z_init),P(nu0), int32(nw), k, int32(obj.device), ...
+                libpointer('doublePtr', z), libpointer('int32Ptr', iters));
+            if rc < 0, error('fastmpc:%d %s', rc, calllib('libfastmpc','fmpc_strerror',rc)); end
+            x_opt = z;
+        end
+    end
+end

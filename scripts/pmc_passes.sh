@@ -11,7 +11,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C -d "$OUT/p$i" -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 2 > "$OUT/p$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d "$OUT/p$i" -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 2 --in-flight 1 > "$OUT/p$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

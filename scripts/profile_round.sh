@@ -9,7 +9,7 @@ TAG=${1:-r01_panel}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-extra --steps 10 --warmup 3"
+ARGS="--no-cpu-baseline --no-extra --steps 10 --warmup 3 --in-flight 1"   # one step at a time: per-kernel durations without overlap
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -o kt --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > "$OUT/${TAG}_kt.log" 2>&1
 cp "$OUT/${TAG}_kt/kt_kernel_stats.csv" "$OUT/${TAG}_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
