@@ -304,7 +304,30 @@ def main():
                 rc0["%s_budget%d" % (tag, nw0)] = {"value": B0 / dt, "unit": "MPC steps/s", "ms_per_solve": dt * 1e3,
                                                     "newton_iters_per_problem": its / B0,
                                                     "tflops": fl0 * its / dt / 1e12, "frac_of_fp64_peak": fl0 * its / dt / 1e12 / FP64_PEAK_TFLOPS}
+        # ... and as the reference runs it: 200 SEQUENTIAL timesteps of one realisation, u_prev = the last first move
+        a0 = pkg.synthetic.make_realisation(m0, r=0, steps=201)[1:201]
+        ta0 = torch.from_numpy(np.ascontiguousarray(a0[:, None, :])).to(dev)
+        for _ in range(2):
+            loop0 = pkg.ClosedLoop(h0, 1, n_newton=1, k=K_BAR, ramp=True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for s_ in range(200):
+                loop0.step(ta0[s_])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        assert int((loop0.status < 0).sum()) == 0
+        rc0["closed_loop_200_sequential_steps"] = {"value": 200 / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / 200 * 1e3, "n_newton": 1}
         h0.close()
+        if not args.no_cpu_baseline:
+            # the reference's dense algebra for this config on the host (oracle/dense_ref.py, checker code, timed only)
+            from oracle.dense_ref import DenseFastMPC
+            dref = DenseFastMPC.var1(m0["Q"], m0["R"], None, m0["Qf"], None, None, None, m0["x_min"], m0["x_max"], m0["u_min"],
+                                     m0["u_max"], -0.2121 * np.ones(m), 0.2121 * np.ones(m), T0, a0[0], np.zeros(m), m0["A1"],
+                                     m0["B"], np.zeros(T0 * n), None, None, ramp=True)
+            t0 = time.perf_counter()
+            dref.mpc_fixed_log_newton(1, K_BAR, nu0=np.zeros(T0 * n))
+            rc0["cpu_port"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "MPC steps/s", "cores": os.cpu_count(),
+                               "sample": "1 problem, 1 Newton step, dense H, P (4Tm x Tz), C as the reference"}
         extra["config0_var1_ramp"] = rc0
         e5, k5, i5 = run(one_lane, 5, ksteps, 2)
         extra["budget5"] = {"what": "Newton budget 5 with the reference's exit test (test_fast_mpc.m:53,59)",

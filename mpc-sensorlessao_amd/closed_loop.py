@@ -17,7 +17,10 @@ from __future__ import annotations
 
 
 class ClosedLoop:
-    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None):
+    """ramp=True (after `handle.set_ramp`): every solve carries the VAR_1 variant's ramp-rate rows against the
+    previous first move, u_prev = U(1:nu) (README.md:589; VAR_1/fast_mpc_ineq_const.m:58-76), zeros at the first step."""
+
+    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None, ramp=False):
         import torch
         self.h, self.batch, self.n_newton, self.k = handle, int(batch), int(n_newton), float(k)
         dev = torch.device("cuda", handle.device) if device is None else device
@@ -31,6 +34,7 @@ class ClosedLoop:
         self.status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.steps_done = 0
+        self.ramp = bool(ramp)
 
     def step(self, a_k, nu0=None):
         """One closed-loop step for all realisations.  a_k: (batch, n) device tensor.  Returns u[k] (batch, m),
@@ -40,7 +44,7 @@ class ClosedLoop:
         self.h.loop_inputs_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
                                   self.x0, self.x0_pre, self.w)
         self.h.solve_device(self.x0, self.x0_pre, self.w, None, nu0, self.n_newton, self.k, z_out=self.z,
-                            status=self.status, iters=self.iters)
+                            status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None)
         self.h.unpack_device(self.z, None, None, u_new)
         self.steps_done = s + 1
         return u_new

@@ -39,13 +39,34 @@ def design_matrices(A1, A2, T):
     return M1, M2
 
 
-def closed_loop(model, a, n_newton=1, k=1e-2, nu0=None):
+def closed_loop(model, a, n_newton=1, k=1e-2, nu0=None, ramp=None):
     """a: (steps, n) turbulence coefficients of ONE realisation.  Returns dict of per-step x0, u (first moves),
-    w, status.  nu0: (steps, nb*n) or None (zeros)."""
+    w, status.  nu0: (steps, nb*n) or None (zeros).  ramp = (du_min, du_max): the VAR_1 variant's ramp-rate rows
+    against the previous first move (u_prev = U(1:nu), README.md:589; zeros at the first step), solved by the DENSE
+    oracle (the structured one has no ramp rows)."""
     A1, A2, B, T = model["A1"], model["A2"], model["B"], model["T"]
     n, m = B.shape
     solver = BandedFastMPC(A1, A2, B, model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"],
                            model["x_min"], model["x_max"], T)
+    if ramp is not None:
+        from .dense_ref import DenseFastMPC
+        var1 = model.get("var_order", 2) == 1
+
+        class _Dense:
+            def solve(self, x0, x0_pre, w, nw, kk, nu0=None):
+                info = {}
+                nu = np.zeros(T * n) if nu0 is None else nu0
+                if var1:
+                    d = DenseFastMPC.var1(model["Q"], model["R"], None, model["Qf"], None, None, None, model["x_min"],
+                                          model["x_max"], model["u_min"], model["u_max"], ramp[0], ramp[1], T, x0, self.u_prev,
+                                          A1, B, w, None, None, ramp=True)
+                else:
+                    d = DenseFastMPC(model["Q"], model["R"], None, model["Qf"], None, None, None, model["x_min"],
+                                     model["x_max"], model["u_min"], model["u_max"], ramp[0], ramp[1], T, x0, x0_pre,
+                                     self.u_prev, A1, A2, B, w, None, None, ramp=True)
+                z = d.mpc_fixed_log_newton(nw, kk, nu0=nu, info=info)
+                return z, info["nu"], info["iters"], 0
+        solver = _Dense()
     M1, M2 = design_matrices(A1, A2, T)
     steps = a.shape[0]
     X0 = np.zeros((steps, n)); U0 = np.zeros((steps, m)); W = np.zeros((steps, T * n)); ST = np.zeros(steps, dtype=int)
@@ -58,6 +79,8 @@ def closed_loop(model, a, n_newton=1, k=1e-2, nu0=None):
             w -= M1 @ (B @ u1)
         if s >= 2:
             w -= M2 @ (B @ u2)
+        if ramp is not None:
+            solver.u_prev = u1.copy()
         z, _, _, st = solver.solve(x0, x0_pre, w, n_newton, k, nu0=None if nu0 is None else nu0[s])
         u0 = z[:m].copy()
         X0[s], U0[s], W[s], ST[s] = x0, u0, w, st

@@ -35,3 +35,27 @@ def test_closed_loop_matches_oracle(pkg, gpu, n, m, T, nw):
         w_ref = -M1 @ (md["B"] @ U0[steps - 2, r]) - M2 @ (md["B"] @ U0[steps - 3, r])
         assert rel_err(w_dev[r], w_ref) <= 1e-12
     h.close()
+
+
+@pytest.mark.parametrize("n,m,T,nw,var_order", [(8, 5, 6, 2, 1), (27, 144, 10, 1, 1)])
+def test_closed_loop_with_ramp_rows(pkg, gpu, n, m, T, nw, var_order):
+    """BASELINE configs[0] as a loop: VAR(1), ramp-rate rows against the previous first move (README.md:355-356, 589;
+    VAR_1/fast_mpc_ineq_const.m:58-76).  Oracle: the dense restatement with the ramp rows, step by step."""
+    import torch
+    md = pkg.synthetic.make_model(n, m, T, var_order=var_order)
+    R, steps = 2, 4
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    du = 0.2121 * np.ones(m)
+    h = handle_from_model(pkg, md)
+    h.set_ramp(-du, du)
+    loop = pkg.ClosedLoop(h, R, n_newton=nw, k=1e-2, ramp=True)
+    U0, X0 = loop.run(torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    U0, X0 = U0.cpu().numpy(), X0.cpu().numpy()
+    assert int((loop.status < 0).sum()) == 0 and h.last_dispatch()[0] == pkg.FMPC_PATH_RAMP
+    # (no feasibility assertion: like the reference, a fixed Newton budget without a slack-positivity test may leave
+    #  the ramp rows violated; parity with the oracle is the bar)
+    for r in range(R if n < 20 else 1):
+        ref = closed_loop(md, a[:, r], nw, 1e-2, ramp=(-du, du))
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    h.close()
