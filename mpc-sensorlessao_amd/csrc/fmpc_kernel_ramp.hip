@@ -26,8 +26,6 @@
 #include "fmpc_device.h"
 #include "../../include/fastmpc.h"
 
-#define FR_THREADS 256
-#define FR_WAVES (FR_THREADS / 64)
 #define FR_MAX_HALVINGS 64
 #define FR_MAXKS 16                     // k-steps of 4 covering n <= 64
 
@@ -40,6 +38,7 @@ __device__ __forceinline__ double fr_wave_sum(double v) {
     return v;
 }
 // Sum over the workgroup, result to every thread; fixed order -> bitwise reproducible.
+template <int NT>
 __device__ __forceinline__ double fr_block_sum(double v, double* red) {
     v = fr_wave_sum(v);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -47,7 +46,7 @@ __device__ __forceinline__ double fr_block_sum(double v, double* red) {
     if (lane == 0) red[wv] = v;
     __syncthreads();
     double s = 0.0;
-    for (int i = 0; i < (FR_THREADS >> 6); ++i) s += red[i];
+    for (int i = 0; i < (NT >> 6); ++i) s += red[i];
     return s;
 }
 
@@ -88,7 +87,9 @@ __device__ __forceinline__ void fr_tri_solve(const double* dg, const double* lo,
     for (int j = T - 2; j >= 0; --j) f[j * m + c] = f[j * m + c] / dg[j * m + c] - lo[j * m + c] * f[(j + 1) * m + c];
 }
 
-extern "C" __global__ void __launch_bounds__(FR_THREADS, 3)
+// NT threads per workgroup: 256 (3 workgroups per CU, throughput) or 512 (one problem spread over twice the waves, latency)
+template <int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 2)
 fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double* __restrict__ dumax, int batch,
                  const double* __restrict__ x0, const double* __restrict__ x0p, const double* __restrict__ w,
                  const double* __restrict__ uprev, const double* zinit, const double* __restrict__ nu0,
@@ -96,6 +97,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                  int* __restrict__ iters, double* __restrict__ step, int step_ld, double* __restrict__ ws,
                  size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NW = NT / 64;
     const int n = M.n, m = M.m, T = M.T, nb = M.nb;
     const int s = n + m, Nz = T * s, nbn = nb * n, ldt = n + 1, tsz = n * ldt;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -108,10 +110,10 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
     double* tB = tA + tsz;                // n*ldt: its inverse factor
     double* sv = tB + tsz;                // n     vector of the backward substitution
     double* srs = sv + n;                 // n     1/sqrt(pivot)
-    double* sred = srs + n;               // 4 x 64 partial sums of the backward substitution
-    double* red = sred + 4 * 64;          // 8
+    double* sred = srs + n;               // NW x 64 partial sums of the backward substitution
+    double* red = sred + NW * 64;   // NW
 
-    for (int i = tid; i < m * n; i += FR_THREADS) sBt[i] = M.Bt[i];
+    for (int i = tid; i < m * n; i += NT) sBt[i] = M.Bt[i];
 
     const FrWsLayout L = fr_ws_layout(n, m, T, nb);
     double* wsp = ws + (size_t)blockIdx.x * ws_stride;
@@ -128,11 +130,11 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
         const double* upv = uprev + (size_t)p * m;
         __syncthreads();
         // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m)
-        for (int idx = tid; idx < Nz; idx += FR_THREADS) {
+        for (int idx = tid; idx < Nz; idx += NT) {
             const int e = idx % s;
             zp[idx] = zinit ? zinit[(size_t)p * Nz + idx] : (e < m ? M.umid[e] : M.xmid[e - m]);
         }
-        for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+        for (int idx = tid; idx < nbn; idx += NT) {
             nu[idx] = nu0 ? nu0[(size_t)p * nbn + idx] : 0.0;
             const int i = idx / n, r = idx - i * n;
             double v = (i < T && w) ? w[(size_t)p * T * n + idx] : 0.0;
@@ -147,7 +149,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             b[idx] = v;
         }
         if (step)
-            for (int idx = tid; idx < step_ld; idx += FR_THREADS) step[(size_t)p * step_ld + idx] = -1.0;
+            for (int idx = tid; idx < step_ld; idx += NT) step[(size_t)p * step_ld + idx] = -1.0;
         __syncthreads();
 
         int st = FMPC_OK, nsteps = 0;
@@ -155,7 +157,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             // ================= P1: slacks and residuals
             FR_T0();
             double acc_d = 0.0, acc_p = 0.0;
-            for (int idx = tid; idx < T * m; idx += FR_THREADS) {       // ramp terms of stage j (needed by j and j-1)
+            for (int idx = tid; idx < T * m; idx += NT) {       // ramp terms of stage j (needed by j and j-1)
                 const int j = idx / m, c = idx - j * m;
                 const double dl = zp[j * s + c] - (j == 0 ? upv[c] : zp[(j - 1) * s + c]);
                 const double rpv = 1.0 / (dumax[c] - dl), rmv = 1.0 / (dl - dumin[c]);
@@ -163,7 +165,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 gr[idx] = kbar * (rpv - rmv);
             }
             __syncthreads();
-            for (int idx = tid; idx < T * m; idx += FR_THREADS) {
+            for (int idx = tid; idx < T * m; idx += NT) {
                 const int j = idx / m, c = idx - j * m;
                 const double u = zp[j * s + c];
                 const double dp = 1.0 / (M.umax[c] - u), dm = 1.0 / (u - M.umin[c]);
@@ -178,7 +180,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 rdu[idx] = rd;
                 acc_d += rd * rd;
             }
-            for (int idx = tid; idx < T * n; idx += FR_THREADS) {
+            for (int idx = tid; idx < T * n; idx += NT) {
                 const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
                 const double x = zp[jj * s + m + r];
                 double v = (j == T ? M.Qf2[r] * x + M.qfl[r] : M.Q2[r] * x + M.ql[r]) + nu[jj * n + r];
@@ -195,7 +197,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 phx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);           // Phi^-1 r_d on x_j
                 acc_d += v * v;
             }
-            for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+            for (int idx = tid; idx < nbn; idx += NT) {
                 const int i = idx / n, r = idx - i * n;
                 double v;
                 if (i < T) {
@@ -216,15 +218,15 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 rp[idx] = v;
                 acc_p += v * v;
             }
-            const double rp2 = fr_block_sum(acc_p, red);
-            const double rho2 = fr_block_sum(acc_d, red) + rp2;
+            const double rp2 = fr_block_sum<NT>(acc_p, red);
+            const double rho2 = fr_block_sum<NT>(acc_d, red) + rp2;
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
             FR_TICK(0);
 
             // ================= P2: per actuator LDL' of the tridiagonal u-part of Phi, Phi_u^-1 r_d, explicit inverse
             int bad = 0;
-            for (int c = tid; c < m; c += FR_THREADS) {
+            for (int c = tid; c < m; c += NT) {
                 double lprev = 0.0, oprev = 0.0;
                 for (int j = 0; j < T; ++j) {
                     double d = M.R2[c] + hs[j * m + c];
@@ -254,10 +256,10 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     }
                 }
             }
-            const double badsum = fr_block_sum((double)bad, red);
+            const double badsum = fr_block_sum<NT>((double)bad, red);
             if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
             // rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into y)
-            for (int idx = tid; idx < nbn; idx += FR_THREADS) {
+            for (int idx = tid; idx < nbn; idx += NT) {
                 const int i = idx / n, r = idx - i * n;
                 double cv;
                 if (i < T) {
@@ -284,11 +286,11 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             // Y_IJ = Yx_IJ + B diag(g^{JI}) B' on the matrix cores: a wave per 16 x 16 output tile, k = 4 actuators per
             // MFMA; A operand B[a][c] g_c (row a = lane % 16, c = 4 ks + lane / 16), B operand B[b][c]; result
             // register r of lane (lk, li) is element (4 r + lk, li) of the tile.
-            for (int idx = tid; idx < nbn; idx += FR_THREADS) Yd[(size_t)nbn * nbn + idx] = y[idx];
+            for (int idx = tid; idx < nbn; idx += NT) Yd[(size_t)nbn * nbn + idx] = y[idx];
             // (no workgroup barrier in this phase: every wave walks its own (block, tile) tasks)
             {
                 const int nblk = nb * (nb + 1) / 2, tpb = ntile * ntile;
-                for (int task = wv; task < nblk * tpb; task += FR_WAVES) {
+                for (int task = wv; task < nblk * tpb; task += NW) {
                     const int blk = task / tpb, tp = task - blk * tpb;
                     int I = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);          // blk = I (I + 1) / 2 + J , J <= I
                     while (I * (I + 1) / 2 > blk) --I;
@@ -348,7 +350,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 const int K = J * n, r_lo = J * n, nrow = nbn + 1 - r_lo;
                 const int nrt = (nrow + 15) >> 4;
                 if (K > 0) {
-                    for (int tp = wv; tp < nrt * ntile; tp += FR_WAVES) {
+                    for (int tp = wv; tp < nrt * ntile; tp += NW) {
                         const int rt = tp / ntile, tb = tp - rt * ntile;
                         const int ra = r_lo + 16 * rt + li <= nbn ? r_lo + 16 * rt + li : nbn;
                         const int rb = 16 * tb + li < n ? r_lo + 16 * tb + li : r_lo + n - 1;
@@ -379,7 +381,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     __syncthreads();
                 }
                 // ---- 2. diagonal block
-                for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                for (int idx = tid; idx < n * n; idx += NT) {
                     const int a2 = idx / n, bb = idx - a2 * n;
                     tA[a2 * ldt + bb] = Yd[(size_t)(r_lo + a2) * nbn + r_lo + bb];
                     tB[a2 * ldt + bb] = a2 == bb ? 1.0 : 0.0;
@@ -392,7 +394,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     if (tid == 0) srs[k2] = 1.0 / sqrt(piv);
                     const int rem = n - k2 - 1;
                     // rows r > k2:  S[r][c] -= l S[c][k2] (c = k2+1 .. r) ,  Wm[r][c] -= l Wm[k2][c] (c = 0 .. k2) ,  l = S[r][k2] / piv
-                    for (int idx = tid; idx < rem * n; idx += FR_THREADS) {
+                    for (int idx = tid; idx < rem * n; idx += NT) {
                         const int r = k2 + 1 + idx / n, c = idx % n;
                         const double l = tA[r * ldt + k2] * ip;
                         if (c <= k2) tB[r * ldt + c] -= l * tB[k2 * ldt + c];
@@ -403,7 +405,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 if (fail) break;
                 {
                     double* Wj = Wg + (size_t)J * n * n;
-                    for (int idx = tid; idx < n * n; idx += FR_THREADS) {
+                    for (int idx = tid; idx < n * n; idx += NT) {
                         const int r = idx / n, c = idx - r * n;
                         const double v = c <= r ? tB[r * ldt + c] * srs[r] : 0.0;    // L^-1 = D^-1/2 (unit lower)^-1
                         tB[r * ldt + c] = v;
@@ -416,7 +418,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 {
                     const int r1 = r_lo + n, nrow2 = nbn + 1 - r1;
                     const int nrt2 = (nrow2 + 15) >> 4;
-                    for (int rt = wv; rt < nrt2; rt += FR_WAVES) {
+                    for (int rt = wv; rt < nrt2; rt += NW) {
                         const int ra = r1 + 16 * rt + li <= nbn ? r1 + 16 * rt + li : nbn;
                         const double* pa = Yd + (size_t)ra * nbn + r_lo;
                         double av[FR_MAXKS];
@@ -461,11 +463,15 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     const int bb = tid & 63, grp = tid >> 6;
                     double part = 0.0;
                     if (bb < n)
-                        for (int r = r1 + grp; r < nbn; r += FR_WAVES) part += Yd[(size_t)r * nbn + r_lo + bb] * dnu[r];
+                        for (int r = r1 + grp; r < nbn; r += NW) part += Yd[(size_t)r * nbn + r_lo + bb] * dnu[r];
                     sred[grp * 64 + bb] = part;
                 }
                 __syncthreads();
-                if (tid < n) sv[tid] = Yd[(size_t)nbn * nbn + r_lo + tid] - (sred[tid] + sred[64 + tid] + sred[128 + tid] + sred[192 + tid]);
+                if (tid < n) {
+                    double acc2 = 0.0;
+                    for (int q = 0; q < NW; ++q) acc2 += sred[q * 64 + tid];
+                    sv[tid] = Yd[(size_t)nbn * nbn + r_lo + tid] - acc2;
+                }
                 __syncthreads();
                 if (tid < n) {
                     const double* Wj = Wg + (size_t)J * n * n;
@@ -478,7 +484,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
 
             FR_TICK(4);
             // ================= P5: d_z, line-search scalars, update
-            for (int idx = tid; idx < T * m; idx += FR_THREADS) {           // rhs of Phi_u d_u = B' d_nu_j - r_d,u
+            for (int idx = tid; idx < T * m; idx += NT) {           // rhs of Phi_u d_u = B' d_nu_j - r_d,u
                 const int j = idx / m, c = idx - j * m;
                 double dot = 0.0;
                 const double* bt = sBt + c * n;
@@ -487,10 +493,10 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 phu[idx] = dot - rdu[idx];
             }
             __syncthreads();
-            for (int c = tid; c < m; c += FR_THREADS) fr_tri_solve(dg, lo, phu, T, m, c);     // phu = d_u
+            for (int c = tid; c < m; c += NT) fr_tri_solve(dg, lo, phu, T, m, c);     // phu = d_u
             __syncthreads();
             double be = 0.0, e2 = 0.0;
-            for (int idx = tid; idx < T * m; idx += FR_THREADS) {
+            for (int idx = tid; idx < T * m; idx += NT) {
                 const int j = idx / m;
                 double e = hs[idx] * phu[idx];                              // k P'DP d_z on u_j
                 if (j > 0) e -= er[idx] * phu[idx - m];
@@ -498,7 +504,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 be += rdu[idx] * e;
                 e2 += e * e;
             }
-            for (int idx = tid; idx < T * n; idx += FR_THREADS) {
+            for (int idx = tid; idx < T * n; idx += NT) {
                 const int jj = idx / n, r = idx - jj * n, j = jj + 1;
                 double v = -rdx[idx] - dnu[jj * n + r];
                 if (j < T) {
@@ -512,8 +518,8 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 if (j == T && M.has_xf) v -= dnu[T * n + r];
                 rdx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);               // reuse as d_x
             }
-            const double beta_e = fr_block_sum(be, red);
-            const double eps2 = fr_block_sum(e2, red);
+            const double beta_e = fr_block_sum<NT>(be, red);
+            const double eps2 = fr_block_sum<NT>(e2, red);
             // closed form of backtracking_inf_newton.m:2-11 with the frozen barrier gradient:
             // ||r(t)||^2 - ((1-al t) rho)^2 = t * gq(t)
             double t = 1.0;
@@ -527,18 +533,18 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     if (++halv >= FR_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
             }
-            for (int idx = tid; idx < Nz; idx += FR_THREADS) {
+            for (int idx = tid; idx < Nz; idx += NT) {
                 const int j = idx / s, e = idx - j * s;
                 zp[idx] += t * (e < m ? phu[j * m + e] : rdx[j * n + e - m]);
             }
-            for (int idx = tid; idx < nbn; idx += FR_THREADS) nu[idx] += t * dnu[idx];
+            for (int idx = tid; idx < nbn; idx += NT) nu[idx] += t * dnu[idx];
             if (step && tid == 0 && it < step_ld) step[(size_t)p * step_ld + it] = t;
             ++nsteps;
             __syncthreads();
             FR_TICK(5);
         }
         if (nuout)
-            for (int idx = tid; idx < nbn; idx += FR_THREADS) nuout[(size_t)p * nbn + idx] = nu[idx];
+            for (int idx = tid; idx < nbn; idx += NT) nuout[(size_t)p * nbn + idx] = nu[idx];
         if (tid == 0) {
             if (status) status[p] = st;
             if (iters) iters[p] = nsteps;
@@ -547,23 +553,29 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
 }
 
 // ---------------------------------------------------------------- host side
-size_t fmpc_ramp_lds_bytes(int n, int m) {
-    const size_t d = (size_t)m * n + 2 * (size_t)n * (n + 1) + 2 * (size_t)n + 4 * 64 + 8;
+size_t fmpc_ramp_lds_bytes(int n, int m) {      // sized for the 512-thread variant (8 waves)
+    const size_t d = (size_t)m * n + 2 * (size_t)n * (n + 1) + 2 * (size_t)n + 8 * 64 + 8;
     return d * sizeof(double);
 }
 size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb) { return fr_ws_layout(n, m, T, nb).total; }
 
 hipError_t fmpc_ramp_prepare(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void*)fmpc_newton_ramp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)fmpc_newton_ramp<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)fmpc_newton_ramp<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const double* dumax, int batch, int grid,
                             const double* x0, const double* x0p, const double* w, const double* uprev,
                             const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
                             double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
-                            size_t ws_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(fmpc_newton_ramp, dim3(grid), dim3(FR_THREADS), fmpc_ramp_lds_bytes(M.n, M.m), stream, M, dumin,
-                       dumax, batch, x0, x0p, w, uprev, zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step,
-                       step_ld, ws, ws_stride);
+                            size_t ws_stride, int threads, hipStream_t stream) {
+    const size_t lds = fmpc_ramp_lds_bytes(M.n, M.m);
+    if (threads == 512)
+        hipLaunchKernelGGL(fmpc_newton_ramp<512>, dim3(grid), dim3(512), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+    else
+        hipLaunchKernelGGL(fmpc_newton_ramp<256>, dim3(grid), dim3(256), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
     return hipGetLastError();
 }
