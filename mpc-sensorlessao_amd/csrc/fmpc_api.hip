@@ -928,7 +928,7 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             const int ntasks = npanels * h->T;
             // one task per wave, 8 per workgroup; workgroups b, b + 8, ... take the panels b % 8, b % 8 + 8, ...
             const int ppx = (npanels + 7) / 8;                       // panels of the fullest XCD share
-            const int dgrid = 8 * ((ppx * h->T + 7) / 8);
+            const int dgrid = 8 * ((ppx * h->T + FD_WAVES - 1) / FD_WAVES);
             (void)ntasks;
             e = fmpc_launch_dz(Q, dgrid, h->pn_dz_lds, (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;

@@ -21,7 +21,6 @@
 #include "fmpc_panel.h"
 #include "../../include/fastmpc.h"
 
-#define FD_WAVES 8
 #define FD_THREADS (FD_WAVES * 64)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -54,7 +53,7 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     {   // the LDS image is packed by the host in LDS order: all loads first, then the stores
         const double* src = P->dzimg;
         const int len = P->dzimg_len;
-        constexpr int NB = 14;                          // 14 x 512 doubles = 56 KB >= the image for m <= 160
+        constexpr int NB = 7168 / FD_THREADS;           // NB x FD_THREADS doubles = 56 KB >= the image for m <= 160
         double t[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) { const int i = k * FD_THREADS + tid; t[k] = src[i < len ? i : 0]; }
@@ -84,9 +83,12 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     const double* nuws = P->nuws;
     const size_t nus = (size_t)nb * FP_N;
 
-    // ---- everything this task reads from HBM / L2
+    // ---- everything this task reads from HBM / L2.  The instruction arbiter serves the oldest wave of a SIMD first:
+    // without help the stores of the older waves (already computing) starve the loads of the younger ones (measured:
+    // the 4th wave of a SIMD had its operands 8 us after the 1st).  Loading waves therefore run at raised priority.
+    __builtin_amdgcn_s_setprio(3);
     double v0[FP_KS], v1[FP_KS], v2[FP_KS];        // nu+_j, nu+_{j+1}, nu+_{j+2} in B-operand layout (problem = lane % 16)
-    double nj[2][4], nx[2][4];                      // nu+_j, nu+_T at (problem 4 r + g, row 16 I + lane % 16)
+    double nx[2][4];                                // nu+_T at (problem 4 r + g, row 16 I + lane % 16): last stage with xf only
     {
         // nu+ arrives in panel layout, [stage row][16 problems]: the B-operand loads are 512 contiguous bytes
         const double* pnl = nuws + (size_t)panel * nus * FP_NP;
@@ -103,14 +105,37 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int I = 0; I < 2; ++I) {
-                const int row = 16 * I + c16;
-                const int rc = row < FP_N ? row : 0;
-                nj[I][r] = pnl[(j * FP_N + rc) * FP_NP + 4 * r + g];
-                const double t_ = pnl[((xfl ? T : j) * FP_N + rc) * FP_NP + 4 * r + g];
-                nx[I][r] = xfl ? t_ : 0.0;
-            }
+            for (int I = 0; I < 2; ++I) nx[I][r] = 0.0;
+        if (xfl) {                                  // (wave-uniform; a strided load: 16 cache lines per instruction)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < 2; ++I) {
+                    const int row = 16 * I + c16;
+                    nx[I][r] = pnl[(T * FP_N + (row < FP_N ? row : 0)) * FP_NP + 4 * r + g];
+                }
+        }
     }
+    // nu+_j is also needed TRANSPOSED, at (problem 4 r + g, row 16 I + lane % 16).  Loading it that way costs 16 cache
+    // lines per instruction; the values are already here in B-operand layout, so they go through this wave's LDS
+    // scratch instead: element (row, problem) at row * 16 + (problem ^ (row & 15)) -- conflict-free both ways.
+    const fd_lds_t scr = (fd_lds_t)lds + L.SCR + wv * FD_SCR;
+#pragma unroll
+    for (int ks = 0; ks < FP_KS; ++ks) {
+        const int row = 4 * ks + g;
+        if (row < FP_N) scr[row * FP_NP + (c16 ^ (row & 15))] = v0[ks];
+    }
+    double nj[2][4];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * I + c16 < FP_N ? 16 * I + c16 : 0;
+            nj[I][r] = scr[row * FP_NP + ((4 * r + g) ^ (row & 15))];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);                     // operands are here (the LDS round trip above needed v0): compute and store
+    __builtin_amdgcn_sched_barrier(0);
     FD_TICK(1);
     double* zq[4]; double* nq[4];
 #pragma unroll
@@ -204,7 +229,7 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
 }
 
 // ---------------------------------------------------------------- host side
-size_t fmpc_dz_lds_bytes(int mp) { return (size_t)fd_lds_layout(mp).total * sizeof(double); }
+size_t fmpc_dz_lds_bytes(int mp) { return (size_t)fd_lds_layout(mp).lds_total * sizeof(double); }
 
 hipError_t fmpc_dz_prepare(size_t lds_bytes) {
     return hipFuncSetAttribute((const void*)fmpc_cold_dz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -48,7 +48,9 @@ __host__ __device__ static inline FpVec fp_vec_layout(int nb, int T) {
 }
 
 // LDS map of the d_z kernel (doubles); the host packs FpParams::dzimg in exactly this order
-struct FdLds { int BT, A1T, A2T, UC, XQ, total; };
+struct FdLds { int BT, A1T, A2T, UC, XQ, total, SCR, lds_total; };
+#define FD_WAVES 8                      // wavefronts (tasks) per d_z workgroup
+#define FD_SCR (FP_N * FP_NP)           // per wave: nu+_j as [row][problem] (swizzled) for the transposed read-back
 __host__ __device__ static inline FdLds fd_lds_layout(int mp) {
     FdLds L; int o = 0;
     L.BT = o;  o += (mp / 16) * FP_KS * 64;         // B' images
@@ -56,7 +58,9 @@ __host__ __device__ static inline FdLds fd_lds_layout(int mp) {
     L.A2T = o; o += FP_IMG;
     L.UC = o;  o += 4 * mp;                         // [c1 | wc | hc | ubar], c1 = -wc cu
     L.XQ = o;  o += 4 * 32;                         // [xc | xc(last stage) | iq | iq(last stage)]
-    L.total = o;
+    L.total = o;                                    // what the host packs (FpParams::dzimg)
+    L.SCR = o; o += FD_WAVES * FD_SCR;
+    L.lds_total = o;
     return L;
 }
 

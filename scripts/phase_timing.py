@@ -57,3 +57,21 @@ if nw == 1 and hasattr(lib, "fmpc_debug_dz_trace"):
     print("  done                ", q(tr[:, 3]))
     print("  wave life time      ", q(tr[:, 3] - tr[:, 0]))
     print("  compute+store phase ", q(tr[:, 3] - tr[:, 2]))
+    if os.environ.get("FMPC_TRACE_DETAIL"):
+        raw = np.zeros(4 * nwav, dtype=np.uint64)
+        lib.fmpc_debug_dz_trace(raw.ctypes.data_as(C.c_void_p), nwav)
+        raw = raw.reshape(-1, 4).astype(np.float64)
+        ok = raw[:, 0] > 0
+        wid = np.arange(len(raw))[ok]; rr = (raw[ok] - t0) * 0.01
+        blk = wid // 8
+        for x in range(8):
+            sel = (blk & 7) == x
+            print("   XCD %d: loads done median %.1f p90 %.1f max %.1f | done median %.1f max %.1f" % (x, np.median(rr[sel, 2]), np.percentile(rr[sel, 2], 90), rr[sel, 2].max(), np.median(rr[sel, 3]), rr[sel, 3].max()))
+        nwpw = 8
+        for x in range(nwpw):
+            sel = (wid % nwpw) == x
+            print("   wave %2d of its workgroup: loads done median %.1f p90 %.1f | done median %.1f" % (x, np.median(rr[sel, 2]), np.percentile(rr[sel, 2], 90), np.median(rr[sel, 3])))
+        late = rr[:, 2] > 9.0
+        print("   late waves (loads done > 9 us): %d; their block ids (first 40):" % late.sum(), np.unique(blk[late])[:40])
+        print("   their stage j = task %% 30 histogram:", np.bincount((((blk[late] >> 3) * 8 + (wid[late] & 7)) % 30), minlength=30))
+
