@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the general-path / budget-5 variants")
     ap.add_argument("--in-flight", type=int, default=2, help="independent steps in flight per GPU (SolveLanes: one handle + HIP "
                                                              "stream each); 1 = strictly one step after the other")
+    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: a lane all-gathers the first moves of this many of its "
+                                                                "steps in one RCCL call (every first move is gathered once)")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of one step instead of launching from Python "
                                                           "(measured slower here: the step is GPU-bound, not launch-bound)")
     args = ap.parse_args()
@@ -108,8 +110,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FMPC_BENCH_FORCE_DIST=1 (1-GPU boxes): initialise RCCL with a single rank and run the N > 1 code path (the gather
+    # of the first moves, its overlap with the next step) on it
+    dist_on = world > 1 or os.environ.get("FMPC_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -128,11 +134,11 @@ def main():
     x0 = torch.from_numpy(data["x0"]).to(dev)
     x0p = torch.from_numpy(data["x0_pre"]).to(dev)
     nu0 = torch.from_numpy(data["nu0"]).to(dev)
-    overlap = {"gather": world > 1 and not rehearse}
+    overlap = {"gather": dist_on and not rehearse}
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -141,37 +147,54 @@ def main():
         the first moves for N > 1) of one batch, submitted to the next of `lanes` (SolveLanes): consecutive steps are
         independent batches and overlap when there is more than one lane.  Per-launch kernel time: HIP events
         recorded on the lane's stream around the solve, one step at a time (no overlap), outside the timed region."""
-        u0_all = {id(l): torch.empty((world * B, m), dtype=torch.float64, device=dev) for l in lanes.lanes} if world > 1 else None
+        G = lanes.lanes[0].u0_ring.shape[0]
+        u0_all = {id(l): torch.empty((world * G * B, m), dtype=torch.float64, device=dev) for l in lanes.lanes} if dist_on else None
         pending = {id(l): None for l in lanes.lanes}
+        ungathered = {id(l): 0 for l in lanes.lanes}
+
+        def gather(lane, cnt):
+            """all-gather the first `cnt` ring slots of the lane (the one collective of the job: RCCL), on its stream"""
+            with torch.cuda.stream(lane.stream):
+                src = lane.u0_ring[:cnt].reshape(cnt * B, m)
+                dst = u0_all[id(lane)][:world * cnt * B]
+                if rehearse:
+                    parts = [torch.empty((cnt * B, m), dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(parts, src.cpu())
+                elif overlap["gather"]:
+                    try:
+                        pending[id(lane)] = dist.all_gather_into_tensor(dst, src, async_op=True)
+                    except Exception:                            # no async support: gather in line
+                        overlap["gather"] = False
+                        dist.all_gather_into_tensor(dst, src)
+                else:
+                    dist.all_gather_into_tensor(dst, src)
+            ungathered[id(lane)] = 0
 
         def step(ev=None):
             lane = lanes.lanes[0] if ev else lanes.next_lane()   # the evented steps run back to back on ONE lane
-            with torch.cuda.stream(lane.stream):
-                if pending[id(lane)] is not None:                # the gather that last read this lane's u0
+            if pending[id(lane)] is not None and (lane.slot + 1) % G == 0:
+                with torch.cuda.stream(lane.stream):             # the ring is about to be rewritten: its gather must be done
                     pending[id(lane)].wait()
-                    pending[id(lane)] = None
-                if ev:
-                    ev[0].record(lane.stream)
+                pending[id(lane)] = None
+            if ev:
+                ev[0].record(lane.stream)
             lanes.submit(x0, x0p, None, None, nu0, n_newton, K_BAR, after_current=False,
                          lane=lane if ev else None)                      # solve + first move u0 (README.md:589)
             if ev:
                 ev[1].record(lane.stream)
-            if world > 1:
-                with torch.cuda.stream(lane.stream):
-                    if rehearse:
-                        parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
-                        dist.all_gather(parts, lane.u0.cpu())
-                    elif overlap["gather"]:
-                        try:                                     # the one collective: final gather of the first moves (RCCL)
-                            pending[id(lane)] = dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0, async_op=True)
-                        except Exception:                        # no async support: gather in line
-                            overlap["gather"] = False
-                            dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0)
-                    else:
-                        dist.all_gather_into_tensor(u0_all[id(lane)], lane.u0)
+            if dist_on:
+                ungathered[id(lane)] += 1
+                if lane.slot == G - 1:
+                    gather(lane, G)
 
         def drain():
             for lane in lanes.lanes:
+                if dist_on and ungathered[id(lane)] > 0 and lane.slot != G - 1:
+                    if pending[id(lane)] is not None:
+                        with torch.cuda.stream(lane.stream):
+                            pending[id(lane)].wait()
+                        pending[id(lane)] = None
+                    gather(lane, lane.slot + 1)                  # the last, partial group
                 if pending[id(lane)] is not None:
                     with torch.cuda.stream(lane.stream):
                         pending[id(lane)].wait()
@@ -200,10 +223,12 @@ def main():
                 graph.replay()
             else:
                 step()
+        host_s = time.perf_counter() - t0                       # host time to enqueue the K steps (diagnostic)
         drain()
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        run.host_enqueue_ms = host_s / steps * 1e3
+        if dist_on:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -213,10 +238,11 @@ def main():
         return elapsed, kern_ms, iters_cpu
 
     depth = max(1, args.in_flight)
-    main_lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev)
+    main_lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev, u0_slots=max(1, args.gather_every) if dist_on else 1)
     h = main_lanes.lanes[0].handle
     u0 = main_lanes.lanes[0].u0
     elapsed, kern_ms, iters_cpu = run(main_lanes, args.n_newton, args.steps, args.warmup, use_graph=args.graph)
+    host_ms_main = run.host_enqueue_ms
     path, handed = h.last_dispatch()
     shared = os.environ.get("FMPC_NO_SHARED", "0") != "1" and os.environ.get("FMPC_FORCE_GENERIC", "0") != "1"
     units_first = float((iters_cpu >= 1).sum())           # first Newton steps (shared factor when enabled)
@@ -375,8 +401,10 @@ def main():
                        "in_flight_note": "consecutive steps are independent batches (other realisations / horizon windows) and are "
                                          "dealt round-robin to `in_flight` solver lanes, one handle + HIP stream each "
                                          "(mpc-sensorlessao_amd/lanes.py); extra.one_step_at_a_time has the strictly sequential figure",
-                       "gather": ("u0 all-gather (RCCL), overlapped with the next step's solve" if overlap["gather"] else "u0 all-gather")
-                                 if world > 1 else "none (1 GPU)",
+                       "gather": ("u0 all-gather (RCCL) of every %d steps of a lane, overlapped with the following solves" % max(1, args.gather_every)
+                                  if overlap["gather"] else "u0 all-gather")
+                                 if dist_on else "none (1 GPU)",
+                       "host_enqueue_ms_per_step": host_ms_main,
                        "launch": "hipGraph replay of one step (solve + first-move unpack)" if (world == 1 and args.graph)
                                  else "one Python call per step"},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -399,7 +427,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, model, data, args.n_newton)
         print(json.dumps(out), flush=True)
     main_lanes.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 
 class Lane:
-    def __init__(self, handle, batch, device, want_u0=True):
+    def __init__(self, handle, batch, device, u0_slots=1):
         import torch
         f64 = dict(dtype=torch.float64, device=device)
         self.handle = handle
@@ -22,12 +22,18 @@ class Lane:
         self.z = torch.empty((batch, handle.nz), **f64)
         self.status = torch.zeros(batch, dtype=torch.int32, device=device)
         self.iters = torch.zeros(batch, dtype=torch.int32, device=device)
-        self.u0 = torch.empty((batch, handle.m), **f64) if want_u0 else None
+        # first moves: a ring of `u0_slots` buffers, one per submit in turn (so that several steps' first moves can be
+        # collected, e.g. gathered across GPUs, in one go); `u0` is the slot of the last submit
+        self.u0_ring = torch.empty((u0_slots, batch, handle.m), **f64)
+        self.slot = u0_slots - 1
+        self.u0 = self.u0_ring[self.slot]
         self.done = torch.cuda.Event()
+        self._bound_key = None                      # argument set of the last submit and its prebuilt C calls
+        self._bound = None
 
 
 class SolveLanes:
-    def __init__(self, make_handle, batch, depth=2, device=None):
+    def __init__(self, make_handle, batch, depth=2, device=None, u0_slots=1):
         """make_handle: () -> FastMPCHandle (called `depth` times: every lane needs its own workspaces)."""
         import torch
         if depth < 1:
@@ -36,7 +42,7 @@ class SolveLanes:
         dev = torch.device("cuda", handles[0].device) if device is None else device
         self.device = dev
         self.batch = int(batch)
-        self.lanes = [Lane(h, self.batch, dev) for h in handles]
+        self.lanes = [Lane(h, self.batch, dev, u0_slots) for h in handles]
         self.submitted = 0
 
     @property
@@ -59,11 +65,39 @@ class SolveLanes:
             self.submitted += 1
         if after_current:
             lane.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(lane.stream):
-            lane.handle.solve_device(x0, x0_pre, w, z_init, nu0, n_newton, k, z_out=lane.z, status=lane.status,
-                                     iters=lane.iters)
-            lane.handle.unpack_device(lane.z, None, None, lane.u0)
-            lane.done.record()
+        # Steady state (the same device buffers as in this lane's last submit): the two C calls are replayed from
+        # prebuilt ctypes arguments on the lane's stream -- no tensor checks, no stream context (host time per
+        # submit 41 -> ~15 us, which matters once a step takes 50 us on the device).
+        key = (x0.data_ptr(), 0 if x0_pre is None else x0_pre.data_ptr(), 0 if w is None else w.data_ptr(),
+               0 if z_init is None else z_init.data_ptr(), 0 if nu0 is None else nu0.data_ptr(), int(n_newton), float(k),
+               x0.shape[0])
+        lane.slot = (lane.slot + 1) % lane.u0_ring.shape[0]
+        lane.u0 = lane.u0_ring[lane.slot]
+        if key != lane._bound_key:
+            with torch.cuda.stream(lane.stream):    # first time: the checked path
+                lane.handle.solve_device(x0, x0_pre, w, z_init, nu0, n_newton, k, z_out=lane.z, status=lane.status,
+                                         iters=lane.iters)
+                lane.handle.unpack_device(lane.z, None, None, lane.u0)
+            import ctypes as C
+            h = lane.handle
+            vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            st = C.c_void_p(lane.stream.cuda_stream)
+            solve_args = (h._h, int(x0.shape[0]), vp(x0), vp(x0_pre), vp(w), vp(z_init), vp(nu0), int(n_newton), float(k),
+                          vp(lane.z), None, vp(lane.status), vp(lane.iters), None, st)
+            unpack_args = [(h._h, int(x0.shape[0]), vp(lane.z), None, None, vp(lane.u0_ring[q]), st)
+                           for q in range(lane.u0_ring.shape[0])]
+            lane._bound = (h._lib.fmpc_solve_device, solve_args, h._lib.fmpc_unpack_device, unpack_args,
+                           (x0, x0_pre, w, z_init, nu0))          # keeps the inputs alive
+            lane._bound_key = key
+        else:
+            f1, a1, f2, a2, _ = lane._bound
+            rc = f1(*a1)
+            if rc == 0:
+                rc = f2(*a2[lane.slot])
+            if rc != 0:
+                from ._lib import FastMPCError
+                raise FastMPCError(rc, "SolveLanes.submit")
+        lane.done.record(lane.stream)
         return lane
 
     def wait(self, lane=None):

@@ -63,3 +63,33 @@ def test_lanes_overlap_without_waiting(pkg, gpu):
         torch.cuda.synchronize()
         assert torch.equal(z, used[i].z) and torch.equal(it, used[i].iters)
     h.close(); lanes.close()
+
+
+def test_lanes_first_move_ring_and_bound_calls(pkg, gpu):
+    """u0_slots > 1: the first moves of consecutive submits of a lane land in consecutive ring slots; repeated submits
+    with the same buffers take the prebuilt-call path and must give the same results as the checked one."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10)
+    B = 48
+    dev = torch.device("cuda:0")
+    sets = [pkg.synthetic.make_replay_batch(md, r=r, steps=B) for r in range(2)]
+    dv = [{k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items() if k in ("x0", "x0_pre", "nu0")} for d in sets]
+    torch.cuda.synchronize()
+    lanes = pkg.SolveLanes(lambda: handle_from_model(pkg, md), B, depth=1, device=dev, u0_slots=3)
+    lane = lanes.lanes[0]
+    seq = [0, 0, 0, 1, 1, 0, 0]                      # same buffers repeatedly (bound path), then a change, then back
+    for i, q in enumerate(seq):
+        d = dv[q]
+        lanes.submit(d["x0"], d["x0_pre"], None, None, d["nu0"], 1, 1e-2, after_current=False)
+        assert lane.slot == i % 3
+    lanes.synchronize()
+    h = handle_from_model(pkg, md)
+    ref = []
+    for q in range(2):
+        z, _, _ = h.solve_device(dv[q]["x0"], dv[q]["x0_pre"], None, None, dv[q]["nu0"], 1, 1e-2)
+        ref.append(h.unpack_device(z)[2].clone())
+    torch.cuda.synchronize()
+    # the ring after 7 submits: slot 0 <- submit 6 (set 0), slot 1 <- submit 4 (set 1), slot 2 <- submit 5 (set 0)
+    assert torch.equal(lane.u0_ring[0], ref[0]) and torch.equal(lane.u0_ring[1], ref[1]) and torch.equal(lane.u0_ring[2], ref[0])
+    assert torch.equal(lane.u0, lane.u0_ring[0]) and int(lane.status.abs().sum()) == 0
+    h.close(); lanes.close()
