@@ -42,6 +42,10 @@ def _exact_handle(pkg, md):
     (10, 33, True, False, False),       # short horizon with xf
     (3, 20, False, False, True),        # horizon too short for the twisted order (natural elimination order)
     (1, 4, True, True, True),           # one stage + terminal row
+    (2, 17, False, False, True),        # the horizon the README itself runs (README.md:338)
+    (8, 16, False, True, True),         # nb = 8: the shortest horizon with the twisted order
+    (7, 9, True, False, True),          # nb = 8 through the terminal row
+    (9, 16, False, False, False),       # odd number of block rows
 ])
 def test_panel_step_matches_oracle_and_exact_path(pkg, gpu, T, batch, xf, use_w, use_nu):
     md, data = _case(pkg, T, batch, xf, use_w, use_nu, seed=11)
