@@ -123,6 +123,17 @@ int fmpc_solve_device(fmpc_handle h, int batch,
                       void* stream);
 
 /*
+ * fmpc_solve_device that also leaves the first move u0 = z(1:m) of every problem (u_prev = U(1:nu), README.md:589)
+ * in u0_out (m x batch): the solve and the one output a closed loop needs in ONE call.  On the n = 27 paths the last
+ * kernel of the solve writes it (no extra launch); otherwise it is fmpc_solve_device + fmpc_unpack_device.
+ */
+int fmpc_solve_u0_device(fmpc_handle h, int batch,
+                         const double* x0, const double* x0_pre, const double* w,
+                         const double* z_init, const double* nu0, int n_newton, double k,
+                         double* z_out, double* nu_out, int* status, int* iters, double* step,
+                         double* u0_out, void* stream);
+
+/*
  * Caller-side unpack of x_opt (README.md:558-570) and u_prev = U(1:nu) (README.md:589):
  * z (N_z x batch) -> U (T*m x batch), X (T*n x batch), u0 (m x batch); any output may be NULL.
  */

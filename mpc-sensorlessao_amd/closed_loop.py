@@ -10,8 +10,8 @@ the caller's residual-free turbulence coefficients a[k]:
     z = Fast_MPC2(..., w, [], []).mpc_fixed_log_newton(n_fix, k_fix)      README.md:547-555
     u[k] = U(1:nu)                            README.md:589
 
-Everything stays in HBM between the steps: three launches per step on torch's current stream
-(`fmpc_loop_inputs_device`, `fmpc_solve_device`, `fmpc_unpack_device`), no host round trip.
+Everything stays in HBM between the steps: two calls per step on torch's current stream
+(`fmpc_loop_inputs_device`, `fmpc_solve_u0_device`), no host round trip.
 """
 from __future__ import annotations
 
@@ -44,8 +44,7 @@ class ClosedLoop:
         self.h.loop_inputs_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
                                   self.x0, self.x0_pre, self.w)
         self.h.solve_device(self.x0, self.x0_pre, self.w, None, nu0, self.n_newton, self.k, z_out=self.z,
-                            status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None)
-        self.h.unpack_device(self.z, None, None, u_new)
+                            status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new)
         self.steps_done = s + 1
         return u_new
 

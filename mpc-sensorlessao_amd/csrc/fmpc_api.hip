@@ -52,7 +52,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
-                            const double* nuws = nullptr);
+                            const double* nuws = nullptr, double* u0out = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -852,12 +852,14 @@ static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
     return FMPC_OK;
 }
 
-extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
-                                 const double* x0, const double* x0_pre, const double* w,
-                                 const double* z_init, const double* nu0,
-                                 int n_newton, double k,
-                                 double* z_out, double* nu_out, int* status, int* iters, double* step,
-                                 void* stream) {
+// fmpc_solve_device (u0_out == NULL) / fmpc_solve_u0_device: the first moves are written by the solve's last kernel
+// where that kernel visits every problem anyway (the wave kernel), by the unpack kernel otherwise
+static int fmpc_solve_device_impl(fmpc_handle h, int batch,
+                                  const double* x0, const double* x0_pre, const double* w,
+                                  const double* z_init, const double* nu0,
+                                  int n_newton, double k,
+                                  double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                  double* u0_out, void* stream) {
     if (!h || !x0 || !z_out) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
@@ -936,13 +938,14 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
             e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                  z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                                  h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
-                                 h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws);
+                                 h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws, u0_out);
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
-                             h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
+                             h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                             nullptr, nullptr, nullptr, nullptr, u0_out);
         h->last_path = mode == 1 ? FMPC_PATH_SHARED : FMPC_PATH_WAVE;
     } else {
         h->last_path = FMPC_PATH_GENERIC;
@@ -953,8 +956,31 @@ extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
         e = fmpc_launch_generic(h->dev, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                 z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
                                 h->ws, stride, (hipStream_t)stream);
+        if (e == hipSuccess && u0_out)
+            e = fmpc_launch_unpack(h->n, h->m, h->T, batch, z_out, nullptr, nullptr, u0_out, (hipStream_t)stream);
     }
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
+                                 const double* x0, const double* x0_pre, const double* w,
+                                 const double* z_init, const double* nu0,
+                                 int n_newton, double k,
+                                 double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                 void* stream) {
+    return fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                  nullptr, stream);
+}
+
+extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
+                                    const double* x0, const double* x0_pre, const double* w,
+                                    const double* z_init, const double* nu0,
+                                    int n_newton, double k,
+                                    double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                    double* u0_out, void* stream) {
+    if (!u0_out) return FMPC_E_NULL;
+    return fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                  u0_out, stream);
 }
 
 extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {

@@ -132,6 +132,7 @@ struct FwParams {
     // step length of every problem first and solve only those whose decision is not clear-cut.
     const double* gate; const double* epsp; int* handed;
     const double* nuws;             // nu+ of the panel kernels, panel layout [panel][stage row][16]
+    double* u0out;                  // optional: the first move u0 = z(1:m) of every problem (README.md:589), written here too
 };
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
@@ -1412,6 +1413,11 @@ __device__ __forceinline__ bool fw_panel_decide(FwKP P, int p, bool write) {
         if (P->iters) P->iters[p] = 1;
         if (P->step) for (int q = 0; q < P->step_ld; ++q) P->step[(size_t)p * P->step_ld + q] = q == 0 ? 1.0 : -1.0;
     }
+    if (clear && write && P->u0out) {               // z is what the d_z kernel wrote (an earlier launch)
+        const int m = P->M.m;
+        const double* zp = P->zout + (size_t)p * T * (P->M.n + m);
+        for (int idx = lane; idx < m; idx += 64) P->u0out[(size_t)p * m + idx] = zp[idx];
+    }
     return clear;
 }
 
@@ -1600,6 +1606,12 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             if (P->status) P->status[p] = st;
             if (P->iters) P->iters[p] = nsteps;
         }
+        if (P->u0out) {                              // z of this problem was written by this wave's own lanes
+            fw_mem_fence();
+            const int m = P->M.m;
+            const double* zp = P->zout + (size_t)p * P->M.T * (N + m);
+            for (int idx = lane; idx < m; idx += 64) P->u0out[(size_t)p * m + idx] = zp[idx];
+        }
     }
 #ifdef FW_TIMING
     if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&fw_timing[4 + q], _ka[q]);
@@ -1658,10 +1670,10 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const double* gate, const double* epsp, int* handed, const double* nuws) {
+                            const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
-    P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws;
+    P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;

@@ -154,10 +154,11 @@ class FastMPCHandle:
 
     # ------------------------------------------------------------------ device tensors
     def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
-                     z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None):
+                     z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None, u0_out=None):
         """Asynchronous solve on torch CUDA(HIP) tensors, on torch's current stream.
         Returns (z_out, status, iters).  Nothing is copied through the host.
-        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`)."""
+        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`).
+        u0_out (batch, m): also receives the first moves z[:, :m] (fmpc_solve_u0_device: no separate unpack)."""
         import torch
 
         def chk(t, cols, name, dtype=torch.float64):
@@ -180,7 +181,7 @@ class FastMPCHandle:
             status = torch.empty(batch, dtype=torch.int32, device=dev)
         if iters is None:
             iters = torch.empty(batch, dtype=torch.int32, device=dev)
-        chk(z_out, self.nz, "z_out"); chk(nu_out, self.nu_len, "nu_out")
+        chk(z_out, self.nz, "z_out"); chk(nu_out, self.nu_len, "nu_out"); chk(u0_out, self.m, "u0_out")
         chk(status, 1, "status", torch.int32); chk(iters, 1, "iters", torch.int32)
         if step is not None:
             chk(step, self._lib.fmpc_step_ld(n_newton), "step")
@@ -190,6 +191,12 @@ class FastMPCHandle:
             rc = self._lib.fmpc_solve_ramp_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
                                                   p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
                                                   p(iters), p(step), stream)
+            if rc == _lib.FMPC_OK and u0_out is not None:
+                rc = self._lib.fmpc_unpack_device(self._h, batch, p(z_out), None, None, p(u0_out), stream)
+        elif u0_out is not None:
+            rc = self._lib.fmpc_solve_u0_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
+                                                n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                                p(iters), p(step), p(u0_out), stream)
         else:
             rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
                                              n_newton, float(k), p(z_out), p(nu_out), p(status),

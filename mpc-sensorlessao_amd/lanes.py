@@ -54,7 +54,7 @@ class SolveLanes:
         return self.lanes[self.submitted % len(self.lanes)]
 
     def submit(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2, after_current=True, lane=None):
-        """Enqueue one batch on the next lane: solve + first-move unpack into the lane's buffers.  Returns the lane.
+        """Enqueue one batch on the next lane: solve + first moves (fmpc_solve_u0_device) into the lane's buffers.  Returns the lane.
         The inputs must stay untouched until the lane is waited for.  after_current: the lane's stream first waits
         for what torch's current stream has enqueued so far (the producer of the inputs); pass False when the inputs
         are already complete, so that lanes never serialise through the caller's stream.  lane: use this lane
@@ -65,7 +65,7 @@ class SolveLanes:
             self.submitted += 1
         if after_current:
             lane.stream.wait_stream(torch.cuda.current_stream(self.device))
-        # Steady state (the same device buffers as in this lane's last submit): the two C calls are replayed from
+        # Steady state (the same device buffers as in this lane's last submit): the C call is replayed from
         # prebuilt ctypes arguments on the lane's stream -- no tensor checks, no stream context (host time per
         # submit 41 -> ~15 us, which matters once a step takes 50 us on the device).
         key = (x0.data_ptr(), 0 if x0_pre is None else x0_pre.data_ptr(), 0 if w is None else w.data_ptr(),
@@ -76,24 +76,19 @@ class SolveLanes:
         if key != lane._bound_key:
             with torch.cuda.stream(lane.stream):    # first time: the checked path
                 lane.handle.solve_device(x0, x0_pre, w, z_init, nu0, n_newton, k, z_out=lane.z, status=lane.status,
-                                         iters=lane.iters)
-                lane.handle.unpack_device(lane.z, None, None, lane.u0)
+                                         iters=lane.iters, u0_out=lane.u0)
             import ctypes as C
             h = lane.handle
             vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             st = C.c_void_p(lane.stream.cuda_stream)
-            solve_args = (h._h, int(x0.shape[0]), vp(x0), vp(x0_pre), vp(w), vp(z_init), vp(nu0), int(n_newton), float(k),
-                          vp(lane.z), None, vp(lane.status), vp(lane.iters), None, st)
-            unpack_args = [(h._h, int(x0.shape[0]), vp(lane.z), None, None, vp(lane.u0_ring[q]), st)
-                           for q in range(lane.u0_ring.shape[0])]
-            lane._bound = (h._lib.fmpc_solve_device, solve_args, h._lib.fmpc_unpack_device, unpack_args,
-                           (x0, x0_pre, w, z_init, nu0))          # keeps the inputs alive
+            args = [(h._h, int(x0.shape[0]), vp(x0), vp(x0_pre), vp(w), vp(z_init), vp(nu0), int(n_newton), float(k),
+                     vp(lane.z), None, vp(lane.status), vp(lane.iters), None, vp(lane.u0_ring[q]), st)
+                    for q in range(lane.u0_ring.shape[0])]           # one per ring slot
+            lane._bound = (h._lib.fmpc_solve_u0_device, args, (x0, x0_pre, w, z_init, nu0))   # (keeps the inputs alive)
             lane._bound_key = key
         else:
-            f1, a1, f2, a2, _ = lane._bound
-            rc = f1(*a1)
-            if rc == 0:
-                rc = f2(*a2[lane.slot])
+            f1, a1, _ = lane._bound
+            rc = f1(*a1[lane.slot])
             if rc != 0:
                 from ._lib import FastMPCError
                 raise FastMPCError(rc, "SolveLanes.submit")

@@ -228,3 +228,43 @@ def test_shared_cold_start_factor_equals_per_problem_factor(pkg, gpu):
     zo, _, ito, _, _ = oracle_batch(md, data, 4, 1e-2)
     assert np.array_equal(i_s["iters"], ito) and max(rel_err(zs[p], zo[p]) for p in range(40)) <= TOL
     hs.close(); hp.close()
+
+
+@pytest.mark.parametrize("case", ["panel", "panel_budget3", "handed_over", "warm_start", "no_shared", "generic_n8"])
+def test_solve_with_first_move_output(pkg, gpu, case):
+    """fmpc_solve_u0_device: u0_out == z[:, :m] on every device path (the fused write of the n = 27 kernels, the
+    unpack launch elsewhere), and z itself is what fmpc_solve_device gives."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, m, T = (8, 5, 6) if case == "generic_n8" else (27, 144, 10)
+    if case == "generic_n8":
+        md, data = pkg.synthetic.make_test_problem(n, m, T, seed=3, batch=40)
+    else:
+        md = pkg.synthetic.make_model(n, m, T)
+        if case == "handed_over":
+            md["u_min"] = -0.05 * np.ones(m); md["u_max"] = 0.05 * np.ones(m)
+        data = pkg.synthetic.make_replay_batch(md, r=4, steps=40)
+    if case == "no_shared":
+        os.environ["FMPC_NO_SHARED"] = "1"
+    try:
+        h = handle_from_model(pkg, md)
+    finally:
+        os.environ.pop("FMPC_NO_SHARED", None)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x0, x0p, w, nu0 = t(data["x0"]), t(data["x0_pre"]), t(data.get("w")), t(data["nu0"])
+    nw = 3 if case == "panel_budget3" else 1
+    z_init = None
+    if case == "warm_start":
+        z_init = h.solve_device(x0, x0p, w, None, nu0, 1, 1e-2)[0].clone()
+    z_ref, st_ref, it_ref = h.solve_device(x0, x0p, w, z_init, nu0, nw, 1e-2)
+    z_ref, st_ref, it_ref = z_ref.clone(), st_ref.clone(), it_ref.clone()
+    u0 = torch.full((40, m), float("nan"), dtype=torch.float64, device=dev)
+    z, st, it = h.solve_device(x0, x0p, w, z_init, nu0, nw, 1e-2, u0_out=u0)
+    torch.cuda.synchronize()
+    path, handed = h.last_dispatch()
+    want = {"panel": pkg.FMPC_PATH_PANEL, "panel_budget3": pkg.FMPC_PATH_PANEL, "handed_over": pkg.FMPC_PATH_PANEL,
+            "warm_start": pkg.FMPC_PATH_WAVE, "no_shared": pkg.FMPC_PATH_WAVE, "generic_n8": pkg.FMPC_PATH_GENERIC}[case]
+    assert path == want and (handed > 0) == (case == "handed_over")
+    assert torch.equal(z, z_ref) and torch.equal(st, st_ref) and torch.equal(it, it_ref)
+    assert torch.equal(u0, z[:, :m])
+    h.close()
