@@ -411,8 +411,9 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
     const int nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
     if (blockIdx.x == 0 && tid == 0 && P->handed) *P->handed = 0;
-    // a finite panel: pad rows are read (and multiplied by zero image columns)
-    for (int i = tid; i < (nb * FP_N + 1) * FP_NP; i += FP_THREADS) lds[L.Y + i] = 0.0;
+    // S1 writes every row of every stage; only the pad row behind the last stage (read by the k-step that holds row 26,
+    // multiplied by a zero image column) has to be made finite here
+    if (tid < FP_NP) lds[L.Y + nb * FP_N * FP_NP + tid] = 0.0;
     {   // both sweep schedules, packed: forward rows 0 .. nsf-1, backward rows nsf .. nsf+nsb-1
         int* sch = (int*)(lds + L.SCH);
         for (int i = tid; i < P->nsf * FP_STEP_INTS; i += FP_THREADS) sch[i] = P->sched_f[i];
