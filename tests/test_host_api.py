@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load()
     hdr = open(os.path.join(ROOT, "include", "fastmpc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(fmpc_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(fmpc_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(pkg._lib.SIGNATURES), (declared ^ set(pkg._lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
