@@ -1025,11 +1025,17 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
         if (i < T) {
             const double* wi = W.winv + (size_t)i * mp + g;
             const fw_clds_t bp = sBt + g * FW_LDB + c16;
+            // winv comes from HBM/L2 (a global load per k-step group): the next chunk's values are requested before
+            // this chunk's products (one chunk = 18 MFMAs = 1.2 k cycles, about one L2 round trip)
+            double wk[FW_KCH], wn[FW_KCH];
+#pragma unroll
+            for (int q = 0; q < FW_KCH; ++q) wk[q] = wi[4 * q];
             for (int kc = 0; kc < mp; kc += 4 * FW_KCH) {
-                double wk[FW_KCH], b0[FW_KCH], b1[FW_KCH];
+                double b0[FW_KCH], b1[FW_KCH];
+                const int kn = kc + 4 * FW_KCH < mp ? kc + 4 * FW_KCH : kc;
 #pragma unroll
                 for (int q = 0; q < FW_KCH; ++q) {
-                    wk[q] = wi[kc + 4 * q];
+                    wn[q] = wi[kn + 4 * q];
                     b0[q] = bp[(kc + 4 * q) * FW_LDB];
                     b1[q] = bp[(kc + 4 * q) * FW_LDB + 16];
                 }
@@ -1040,6 +1046,8 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
                     S01 = MFMA64(a0, b1[q], S01);
                     S11 = MFMA64(a1, b1[q], S11);
                 }
+#pragma unroll
+                for (int q = 0; q < FW_KCH; ++q) wk[q] = wn[q];
             }
         }
         // ---- S -= Ua'Ua + Uc'Uc ;  M1 = Y_{i,i+1} - Ua'Ub
