@@ -52,7 +52,8 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
-                            const double* nuws = nullptr, double* u0out = nullptr);
+                            const double* nuws = nullptr, double* u0out = nullptr,
+                            int pphase = 0, const double* rnp = nullptr, int* list = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -88,6 +89,8 @@ struct fmpc_handle_s {
     int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
     size_t pn_cap;                       // per-batch buffers of the panel path, grown together
     double* pn_gate; double* pn_epsp; double* pn_nuws;
+    double* pn_rnp; int* pn_list;        // budgets > 1: next-exit-test partials, compacted list of the problems that go on
+    int* pn_cnt_host;                    // pinned copy of pn_cnt of an EARLIER call (never waited for): sizes the continuation grid
     size_t pn_o_dz; int pn_dz_len;
     size_t pn_dz_lds;
     double pn_rd2_0, pn_rp2c;
@@ -190,7 +193,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
+    h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -409,16 +412,18 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                 h->pn_o_aimg = o; o += 5 * FP_IMG;
                 h->pn_o_vec = o;  o += V.total;
                 h->pn_o_ucon = o; o += 4 * (size_t)pmp;
-                h->pn_dz_len = fd_lds_layout(pmp).total;
+                h->pn_dz_len = fd_lds_layout(pmp).total_next;
                 h->pn_o_dz = o;   o += (size_t)h->pn_dz_len;
                 h->pn_doubles = o;
                 h->pn_o_dump = o; o += (size_t)T * (n + m) + (size_t)h->nb * n;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_cnt, sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_sched, (size_t)2 * FP_MAX_STEPS(h->nb) * FP_STEP_INTS * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
-                (void)hipMemset(h->pn_cnt, 0, sizeof(int));
-                h->pn_dz_lds = fmpc_dz_lds_bytes(pmp);
-                if (fmpc_panel_prepare(plds) != hipSuccess || fmpc_dz_prepare(h->pn_dz_lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+                (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));     // [handed over, length of the continuation list]
+                if (hipHostMalloc((void**)&h->pn_cnt_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                h->pn_cnt_host[0] = -1; h->pn_cnt_host[1] = -1;   // nothing known yet
+                h->pn_dz_lds = fmpc_dz_lds_bytes(pmp, 1);
+                if (fmpc_panel_prepare(plds) != hipSuccess || fmpc_dz_prepare(pmp) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
                 h->hm_Q2 = Q2; h->hm_Qf2 = Qf2; h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2;
                 h->hm_ql.assign(n, 0.0); if (q) h->hm_ql.assign(q, q + n);
                 h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
@@ -449,6 +454,9 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->pn_gate) (void)hipFree(h->pn_gate);
     if (h->pn_epsp) (void)hipFree(h->pn_epsp);
     if (h->pn_nuws) (void)hipFree(h->pn_nuws);
+    if (h->pn_rnp) (void)hipFree(h->pn_rnp);
+    if (h->pn_list) (void)hipFree(h->pn_list);
+    if (h->pn_cnt_host) (void)hipHostFree(h->pn_cnt_host);
     if (h->ramp_du) (void)hipFree(h->ramp_du);
     if (h->ramp_ws) (void)hipFree(h->ramp_ws);
     if (h->ws) (void)hipFree(h->ws);
@@ -824,6 +832,13 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
             dz[D.UC + j] = -uc[mp + j] * uc[j];
             dz[D.UC + mp + j] = uc[mp + j]; dz[D.UC + 2 * mp + j] = uc[2 * mp + j]; dz[D.UC + 3 * mp + j] = uc[3 * mp + j];
         }
+        for (int j = 0; j < mp; ++j) {                               // [c2 | 2R | hp | hm] for the next-exit-test variant
+            const bool in = j < m;
+            dz[D.UX + j] = in ? h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] : 0.0;
+            dz[D.UX + mp + j] = in ? h->hm_R2[j] : 0.0;
+            dz[D.UX + 2 * mp + j] = in ? h->hm_umax[j] - h->hm_umid[j] : 1.0;
+            dz[D.UX + 3 * mp + j] = in ? h->hm_umid[j] - h->hm_umin[j] : 1.0;
+        }
         for (int r = 0; r < 32; ++r) {
             dz[D.XQ + r] = vec[V.xc + r]; dz[D.XQ + 32 + r] = vec[V.xc + (T - 1) * 32 + r];
             dz[D.XQ + 64 + r] = vec[V.iq + r]; dz[D.XQ + 96 + r] = vec[V.iq + (T - 1) * 32 + r];
@@ -904,9 +919,13 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
                 if (h->pn_gate) (void)hipFree(h->pn_gate);
                 if (h->pn_epsp) (void)hipFree(h->pn_epsp);
                 if (h->pn_nuws) (void)hipFree(h->pn_nuws);
-                h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_cap = 0;
+                if (h->pn_rnp) (void)hipFree(h->pn_rnp);
+                if (h->pn_list) (void)hipFree(h->pn_list);
+                h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cap = 0;
                 if (hipMalloc((void**)&h->pn_gate, (size_t)batch * 2 * sizeof(double)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_epsp, (size_t)npanels * h->T * FP_NP * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_rnp, (size_t)npanels * h->T * FP_NP * sizeof(double)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_list, (size_t)batch * sizeof(int)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_nuws, (size_t)npanels * FP_NP * h->nb * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
                 h->pn_cap = batch;
             }
@@ -923,6 +942,8 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
             Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
             Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;
             Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
+            Q.kbar = k; Q.rnp = h->pn_rnp;
+            const int split = max_iter > 1;                           // budgets > 1: decide, compact, continue (two launches)
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
             e = fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), (hipStream_t)stream);
@@ -932,13 +953,35 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
             const int ppx = (npanels + 7) / 8;                       // panels of the fullest XCD share
             const int dgrid = 8 * ((ppx * h->T + FD_WAVES - 1) / FD_WAVES);
             (void)ntasks;
-            e = fmpc_launch_dz(Q, dgrid, h->pn_dz_lds, (hipStream_t)stream);
+            e = fmpc_launch_dz(Q, dgrid, split, (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;
-            // decides the step length of every problem; solves exactly those whose decision is not clear-cut
-            e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
-                                 z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
-                                 h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
-                                 h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws, u0_out);
+            // decides the step length of every problem; solves exactly those whose decision is not clear-cut.  Budget 1:
+            // one launch.  Budgets > 1: a decide-only launch that also evaluates the next exit test and COMPACTS the
+            // problems that go on (typically a few per cent), then the continuation over that list on as few
+            // workgroups as it needs -- the rest of the chip stays free for other streams.
+            for (int ph = split ? 1 : 0; ph <= (split ? 2 : 0); ++ph) {
+                int g2 = grid;
+                if (ph == 2) {
+                    // Every workgroup of the continuation needs a CU with its whole LDS free, also those that find the
+                    // list empty -- behind other streams' long-running continuations they would wait for a slot.  Size
+                    // the grid from the list length an EARLIER call of this handle reported (never waited for); the
+                    // kernel loops over the list, so any grid is correct.
+                    const int last = ((volatile int*)h->pn_cnt_host)[1];
+                    if (last >= 0) {
+                        const int wpw2 = fmpc_wave_waves_per_wg();
+                        int want = (last + last / 2 + wpw2 - 1) / wpw2 + 4;
+                        if (want < 8) want = 8;
+                        if (want < g2) g2 = want;
+                    }
+                }
+                e = fmpc_launch_wave(h->dev, h->wave, batch, g2, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                                     z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
+                                     h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                                     h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws, u0_out, ph, h->pn_rnp, h->pn_list);
+                if (e != hipSuccess) return FMPC_E_HIP;
+            }
+            if (split && hipMemcpyAsync(h->pn_cnt_host, h->pn_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+                return FMPC_E_HIP;
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }

@@ -40,6 +40,10 @@ extern "C" int fmpc_debug_dz_trace(unsigned long long* out, int n) {
 #define FD_TICK(k)
 #endif
 
+// NEXT: also leave, per task, the partial ||r_d||^2 of the NEW point (z+, nu+) with the barrier terms re-evaluated there,
+// i.e. what the exit test of the following Newton iteration (inf_newton_solver.m:19-22) needs; its x entries and r_p
+// vanish for a full step (the x part of Phi is constant), so only the u entries are summed.  Used for budgets > 1.
+template <bool NEXT>
 __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const FpParams Q = Pv;
@@ -52,7 +56,7 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
 #endif
     {   // the LDS image is packed by the host in LDS order: all loads first, then the stores
         const double* src = P->dzimg;
-        const int len = P->dzimg_len;
+        const int len = NEXT ? L.total_next : L.total;
         constexpr int NB = 7168 / FD_THREADS;           // NB x FD_THREADS doubles = 56 KB >= the image for m <= 160
         double t[NB];
 #pragma unroll
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     // nu+_j is also needed TRANSPOSED, at (problem 4 r + g, row 16 I + lane % 16).  Loading it that way costs 16 cache
     // lines per instruction; the values are already here in B-operand layout, so they go through this wave's LDS
     // scratch instead: element (row, problem) at row * 16 + (problem ^ (row & 15)) -- conflict-free both ways.
-    const fd_lds_t scr = (fd_lds_t)lds + L.SCR + wv * FD_SCR;
+    const fd_lds_t scr = (fd_lds_t)lds + (NEXT ? L.total_next : L.total) + wv * FD_SCR;
 #pragma unroll
     for (int ks = 0; ks < FP_KS; ++ks) {
         const int row = 4 * ks + g;
@@ -144,7 +148,9 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
         zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + (size_t)j * s + c16;
         nq[r] = P->nuout ? (p < batch ? P->nuout + (size_t)p * nus : P->dump + (size_t)T * s) + c16 : nullptr;
     }
-    double eps2[4] = {0.0, 0.0, 0.0, 0.0};
+    double eps2[4] = {0.0, 0.0, 0.0, 0.0}, rn2[4] = {0.0, 0.0, 0.0, 0.0};
+    const fd_clds_t UX = (fd_clds_t)lds + L.UX + c16;
+    const double kbar = P->kbar;
     // ---- x entries first (they free 30 of the 37 loaded values): d_x = (2Q)^-1 (-dx0 - nu+_j + A1' nu+_{j+1} + A2' nu+_{j+2} [- nu+_T])
     const bool last = j + 1 == T;
     const fd_clds_t xcv = XQ + (last ? 32 : 0), iqv = XQ + 64 + (last ? 32 : 0);
@@ -184,6 +190,8 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
         const fd_clds_t uc = UC + 16 * J;
         const double c1 = uc[0], wc = uc[mp], hc = uc[2 * mp], ub = uc[3 * mp];
         const bool cok = J < NJF || 16 * J + c16 < m;    // partial last column block when m % 16 != 0
+        double c2 = 0.0, r2 = 0.0, hp = 1.0, hm = 1.0;
+        if (NEXT) { const fd_clds_t ux = UX + 16 * J; c2 = ux[0]; r2 = ux[mp]; hp = ux[2 * mp]; hm = ux[3 * mp]; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double du = fma(wc, acc[r], c1);
@@ -191,6 +199,11 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
             if (cok) {
                 eps2[r] = fma(e, e, eps2[r]);
                 zq[r][16 * J] = ub + du;
+            }
+            if (NEXT) {
+                // r_d[u] at the new point: 2R u+ + r + k (1/(umax - u+) - 1/(u+ - umin)) - B' nu+ ,  u+ = ubar + du
+                const double rn = fma(r2, du, c2) + kbar * (1.0 / (hp - du) - 1.0 / (hm + du)) - acc[r];
+                if (cok) rn2[r] = fma(rn, rn, rn2[r]);
             }
         }
     };
@@ -219,6 +232,15 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
         if (c16 == 0) ep[4 * r + g] = v;
     }
+    if (NEXT) {
+        double* rq = P->rnp + ((size_t)panel * T + j) * FP_NP;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = rn2[r];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (c16 == 0) rq[4 * r + g] = v;
+        }
+    }
     FD_TICK(2);
 #ifdef FW_TIMING
     if (lane == 0) {       // (no atomics here: thousands of waves adding to one address take longer than the kernel)
@@ -229,13 +251,21 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
 }
 
 // ---------------------------------------------------------------- host side
-size_t fmpc_dz_lds_bytes(int mp) { return (size_t)fd_lds_layout(mp).lds_total * sizeof(double); }
-
-hipError_t fmpc_dz_prepare(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void*)fmpc_cold_dz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+size_t fmpc_dz_lds_bytes(int mp, int next) {
+    const FdLds L = fd_lds_layout(mp);
+    return ((size_t)(next ? L.total_next : L.total) + FD_WAVES * FD_SCR) * sizeof(double);
 }
 
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(fmpc_cold_dz, dim3(grid), dim3(FD_THREADS), lds_bytes, stream, P);
+hipError_t fmpc_dz_prepare(int mp) {
+    hipError_t e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)fmpc_dz_lds_bytes(mp, 0));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)fmpc_cold_dz<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)fmpc_dz_lds_bytes(mp, 1));
+}
+
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream) {
+    if (next) hipLaunchKernelGGL(fmpc_cold_dz<true>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 1), stream, P);
+    else hipLaunchKernelGGL(fmpc_cold_dz<false>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
     return hipGetLastError();
 }

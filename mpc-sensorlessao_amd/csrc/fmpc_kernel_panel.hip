@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(FP_THREADS, 2) fmpc_cold_panel(FpParams Pv) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
     const int nb = P->nb, batch = P->batch;
     const FpLds L = fp_lds_layout(nb, P->mp);
-    if (blockIdx.x == 0 && tid == 0 && P->handed) *P->handed = 0;
+    if (blockIdx.x == 0 && tid == 0 && P->handed) { P->handed[0] = 0; P->handed[1] = 0; }   // counters of the exact-path launches
     // S1 writes every row of every stage; only the pad row behind the last stage (read by the k-step that holds row 26,
     // multiplied by a zero image column) has to be made finite here
     if (tid < FP_NP) lds[L.Y + nb * FP_N * FP_NP + tid] = 0.0;

@@ -133,7 +133,15 @@ struct FwParams {
     const double* gate; const double* epsp; int* handed;
     const double* nuws;             // nu+ of the panel kernels, panel layout [panel][stage row][16]
     double* u0out;                  // optional: the first move u0 = z(1:m) of every problem (README.md:589), written here too
+    // Newton budgets > 1 on the panel path run in two launches so that the few problems that go on are COMPACTED:
+    // pphase 1 decides every problem (step length of the panel step, then the exit test of the next iteration from
+    // rnp) and appends those that need this kernel to `list`; pphase 2 works through the list.  pphase 0: one launch
+    // (budget 1: decide, and redo the handed-over problems right away).
+    int pphase;
+    const double* rnp;              // per (panel, stage, problem): partial ||r_d||^2 at the new point (fmpc_cold_dz<true>)
+    int* list;                      // problem index, bit 30 set = handed over (to be redone from scratch)
 };
+#define FW_LIST_HANDED (1 << 30)
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
 __device__ __forceinline__ FwKP fw_params() {
@@ -1429,6 +1437,21 @@ __device__ __forceinline__ bool fw_panel_decide(FwKP P, int p, bool write) {
     return clear;
 }
 
+// Panel path, budgets > 1: is the exit test of the NEXT iteration (inf_newton_solver.m:19-22: ||r|| <= 1e-6 and
+// ||r_p|| <= 1e-8 at the new point) clearly met?  After a full step r_p and the x entries of r_d vanish up to
+// rounding (measured: <= 1e-19 against the threshold of 1e-12 on the squared norm); the u entries of r_d were summed by
+// fmpc_cold_dz<true> with the same formula as the exact path, so the two agree to rounding as well.  "Clearly met" =
+// 0.4 % below the threshold on the squared norm; everything else is evaluated exactly by the continuation.
+// Wave-uniform; fixed summation order.
+__device__ __forceinline__ bool fw_panel_converged(FwKP P, int p) {
+    const int lane = threadIdx.x & 63, T = P->M.T;
+    const double* r0 = P->rnp + ((size_t)(p >> 4) * T) * 16 + (p & 15);
+    double a = 0.0;
+    for (int j = lane; j < T; j += 64) a += r0[(size_t)j * 16];
+    const double rn2 = fw_wave_sum(a);
+    return rn2 <= 0.996e-12;                         // false for NaN
+}
+
 template <int N>
 __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     using C = FwCfg<N>;
@@ -1439,19 +1462,28 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const int batch = P->batch;
     const bool panel_mode = P->gate != nullptr;
     const int wave_g = blockIdx.x * FW_WAVES + wv, nwaves = gridDim.x * FW_WAVES;
-    const int rounds = (batch + nwaves - 1) / nwaves;
-    if (panel_mode) {
+    const int pphase = panel_mode ? P->pphase : 0;
+    const int nlist = pphase == 2 ? P->handed[1] : 0;          // written by the pphase-1 launch
+    const int rounds = pphase == 2 ? (nlist + nwaves - 1) / nwaves : (batch + nwaves - 1) / nwaves;
+    if (panel_mode && pphase != 2) {
         // decisions of all problems of this workgroup; leave if none of them needs the exact path
         int need = 0;
         for (int rnd = 0; rnd < rounds; ++rnd) {
             const int q = wave_g + rnd * nwaves;
             if (q < batch) {
-                if (!fw_panel_decide(P, q, true)) { need = 1; if (lane == 0 && P->handed) atomicAdd(P->handed, 1); }
-                else if (P->max_iter > 1) need = 1;          // accepted first step, further iterations follow here
+                int entry = -1;
+                if (!fw_panel_decide(P, q, true)) { entry = q | FW_LIST_HANDED; if (lane == 0 && P->handed) atomicAdd(P->handed, 1); }
+                else if (P->max_iter > 1 && !fw_panel_converged(P, q)) entry = q;   // accepted first step, more iterations follow
+                if (entry >= 0) {
+                    need = 1;
+                    if (pphase == 1 && lane == 0) P->list[atomicAdd(P->handed + 1, 1)] = entry;
+                }
             }
         }
+        if (pphase == 1) return;
         if (!__syncthreads_or(need)) return;
     }
+    if (pphase == 2 && nlist == 0) return;
     for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
     {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
         double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
@@ -1476,10 +1508,18 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     // All waves of a workgroup run the same number of rounds (the shared sweeps are collective).
     const bool cold_mode = P->mode == FW_MODE_SHARED && *P->sh_ok != 0;
     for (int rnd = 0; rnd < rounds; ++rnd) {
-        const int p = wave_g + rnd * nwaves;
         // panel mode: `accepted` = the panel kernels' first Newton step stands (z, nu+ are in place)
-        const bool accepted = p < batch && panel_mode && fw_panel_decide(P, p, false);
-        const bool active = p < batch && !(accepted && max_iter <= 1);
+        int p = wave_g + rnd * nwaves;
+        bool accepted, active;
+        if (pphase == 2) {                               // the compacted list of the problems that go on
+            const int entry = p < nlist ? P->list[p] : -1;
+            accepted = entry >= 0 && !(entry & FW_LIST_HANDED);
+            active = entry >= 0;
+            p = entry >= 0 ? (entry & (FW_LIST_HANDED - 1)) : batch;
+        } else {
+            accepted = p < batch && panel_mode && fw_panel_decide(P, p, false);
+            active = p < batch && !(accepted && (max_iter <= 1 || fw_panel_converged(P, p)));
+        }
         if (cold_mode) {
             // [cu | hc | wc | ubar] into LDS for the cold step's epilogue.  The region overlaps the per-wave
             // tiles of the general path, so wait until every wave has left the previous round.
@@ -1678,10 +1718,13 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
-                            const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out) {
+                            const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out,
+                            int pphase, const double* rnp, int* list) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
     P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
+    P.pphase = pphase; P.rnp = rnp; P.list = list;
+    if (pphase == 1) lds_bytes = 0;                  // the decide-only launch touches no LDS: cheap to place
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;

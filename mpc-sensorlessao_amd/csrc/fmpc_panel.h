@@ -48,7 +48,7 @@ __host__ __device__ static inline FpVec fp_vec_layout(int nb, int T) {
 }
 
 // LDS map of the d_z kernel (doubles); the host packs FpParams::dzimg in exactly this order
-struct FdLds { int BT, A1T, A2T, UC, XQ, total, SCR, lds_total; };
+struct FdLds { int BT, A1T, A2T, UC, XQ, total, UX, total_next; };
 #define FD_WAVES 8                      // wavefronts (tasks) per d_z workgroup
 #define FD_SCR (FP_N * FP_NP)           // per wave: nu+_j as [row][problem] (swizzled) for the transposed read-back
 __host__ __device__ static inline FdLds fd_lds_layout(int mp) {
@@ -58,10 +58,10 @@ __host__ __device__ static inline FdLds fd_lds_layout(int mp) {
     L.A2T = o; o += FP_IMG;
     L.UC = o;  o += 4 * mp;                         // [c1 | wc | hc | ubar], c1 = -wc cu
     L.XQ = o;  o += 4 * 32;                         // [xc | xc(last stage) | iq | iq(last stage)]
-    L.total = o;                                    // what the host packs (FpParams::dzimg)
-    L.SCR = o; o += FD_WAVES * FD_SCR;
-    L.lds_total = o;
-    return L;
+    L.total = o;                                    // what the plain kernel copies of FpParams::dzimg
+    L.UX = o;  o += 4 * mp;                         // [c2 | 2R | hp | hm]: only the variant that also evaluates the NEXT
+    L.total_next = o;                               //   exit test (Newton budgets > 1) copies and uses these
+    return L;                                       // (behind it: FD_WAVES x FD_SCR doubles of per-wave scratch)
 }
 
 // One parameter block for both kernels of the panel path.
@@ -83,8 +83,10 @@ struct FpParams {
     double rp2c;                        // sum_{i>=2} |cp_i|^2: ||r_p||^2 of the stages >= 2 when w = NULL
     double* gate;                       // per problem: ||r_p||^2, lower bound of rho^2   (read by fmpc_newton_wave)
     double* epsp;                       // per (panel, stage, problem): partial ||e||^2   (read by fmpc_newton_wave)
-    const double* dzimg;                // LDS image of the d_z kernel: [B' | A1' | A2' | c1 wc hc ubar | xc xc' iq iq']
+    const double* dzimg;                // LDS image of the d_z kernel: [B' | A1' | A2' | c1 wc hc ubar | xc xc' iq iq' | c2 2R hp hm]
     int dzimg_len;
+    double kbar;                        // barrier weight (the d_z variant that evaluates the next exit test needs it)
+    double* rnp;                        // per (panel, stage, problem): partial ||r_d(z+, nu+)||^2, barrier terms re-evaluated
     int* handed;                        // number of problems the exact path had to solve (diagnostic), zeroed here
     double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
 };
@@ -93,6 +95,6 @@ size_t fmpc_panel_lds_bytes(int nb, int mp);
 size_t fmpc_panel_lds_used(int nb, int mp, int nsteps);
 hipError_t fmpc_panel_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_panel(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
-size_t fmpc_dz_lds_bytes(int mp);
-hipError_t fmpc_dz_prepare(size_t lds_bytes);
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
+size_t fmpc_dz_lds_bytes(int mp, int next);
+hipError_t fmpc_dz_prepare(int mp);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream);
