@@ -187,3 +187,34 @@ def test_panel_path_on_device_tensors_full_size(pkg, gpu):
     zo, _, _, _, _ = oracle_batch(md, {k: (None if v is None else v[:6]) for k, v in data.items()}, 1, 1e-2)
     assert max(rel_err(zz[p], zo[p]) for p in range(6)) <= TOL_Z
     h.close()
+
+
+@pytest.mark.parametrize("tight,bad", [(False, False), (True, False), (False, True)])
+def test_budget_over_one_decide_compact_continue(pkg, gpu, tight, bad):
+    """Newton budgets > 1 on the panel path run as decide + compacted continuation (two launches): iteration counts,
+    step lengths and results against the oracle for problems that stop after one step, problems that go on, problems
+    handed to the exact path (tight bounds), a NaN problem among healthy ones, and a ragged batch."""
+    md, data = _case(pkg, 10, 53, False, False, True, seed=21)
+    if tight:
+        md = dict(md); md["u_min"] = -0.05 * np.ones(144); md["u_max"] = 0.05 * np.ones(144)
+    x0 = data["x0"].copy()
+    if bad:
+        x0[17, 3] = np.nan
+    hp = handle_from_model(pkg, md)
+    for nw in (2, 5):
+        z, info = hp.solve(x0, data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=1e-2, return_info=True, check=False)
+        path, handed = hp.last_dispatch()
+        assert path == pkg.FMPC_PATH_PANEL and (handed == 53 if tight else handed == (1 if bad else 0))
+        sub = {k: (None if v is None else v[:53]) for k, v in data.items()}
+        sub["x0"] = x0
+        zo, nuo, ito, sto, steps = oracle_batch(md, sub, nw, 1e-2)
+        for p in range(53):
+            if bad and p == 17:
+                assert info["status"][p] != 0
+                continue
+            assert info["status"][p] == sto[p] and info["iters"][p] == ito[p], (p, info["iters"][p], ito[p])
+            assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p][:ito[p]]))
+            assert rel_err(z[p], zo[p]) <= TOL_Z and rel_err(info["nu"][p], nuo[p]) <= TOL_NU
+        if not tight and not bad:
+            assert 1 <= info["iters"].min() and info["iters"].max() <= nw
+    hp.close()
