@@ -218,3 +218,22 @@ def test_budget_over_one_decide_compact_continue(pkg, gpu, tight, bad):
         if not tight and not bad:
             assert 1 <= info["iters"].min() and info["iters"].max() <= nw
     hp.close()
+
+
+def test_budget5_bench_workload_every_problem_against_the_oracle(pkg, gpu):
+    """BASELINE configs[1] at the reference test's Newton budget of 5 (test_fast_mpc.m:53,59): every problem's iteration
+    count, status, step lengths and z against the structured oracle (most stop after one step: the exit test of
+    iteration 2 is decided from the d_z kernel's residual sums; the rest goes through the compacted continuation)."""
+    md = pkg.synthetic.make_model(27, 144, 30)
+    B = 640
+    data = pkg.synthetic.make_replay_batch(md, r=0, steps=B)
+    h = handle_from_model(pkg, md)
+    z, info = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=5, k=1e-2, return_info=True)
+    assert h.last_dispatch() == (pkg.FMPC_PATH_PANEL, 0)
+    zo, nuo, ito, sto, steps = oracle_batch(md, data, 5, 1e-2)
+    assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
+    assert (ito == 1).sum() > B // 2 and (ito >= 2).sum() > 0            # both kinds are present
+    for p in range(B):
+        assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p][:ito[p]]))
+        assert rel_err(z[p], zo[p]) <= TOL_Z and rel_err(info["nu"][p], nuo[p]) <= TOL_NU
+    h.close()
