@@ -220,20 +220,22 @@ def test_budget_over_one_decide_compact_continue(pkg, gpu, tight, bad):
     hp.close()
 
 
-def test_budget5_bench_workload_every_problem_against_the_oracle(pkg, gpu):
+def test_budget5_bench_workload_against_the_oracle(pkg, gpu):
     """BASELINE configs[1] at the reference test's Newton budget of 5 (test_fast_mpc.m:53,59): every problem's iteration
     count, status, step lengths and z against the structured oracle (most stop after one step: the exit test of
     iteration 2 is decided from the d_z kernel's residual sums; the rest goes through the compacted continuation)."""
     md = pkg.synthetic.make_model(27, 144, 30)
-    B = 640
-    data = pkg.synthetic.make_replay_batch(md, r=0, steps=B)
+    data = pkg.synthetic.make_replay_batch(md, r=0, steps=2000)          # the bench's batch
     h = handle_from_model(pkg, md)
     z, info = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=5, k=1e-2, return_info=True)
     assert h.last_dispatch() == (pkg.FMPC_PATH_PANEL, 0)
-    zo, nuo, ito, sto, steps = oracle_batch(md, data, 5, 1e-2)
-    assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
-    assert (ito == 1).sum() > B // 2 and (ito >= 2).sum() > 0            # both kinds are present
-    for p in range(B):
-        assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p][:ito[p]]))
-        assert rel_err(z[p], zo[p]) <= TOL_Z and rel_err(info["nu"][p], nuo[p]) <= TOL_NU
+    # checked against the oracle: every problem that took more than one step, and every 5th of the others
+    idx = np.array(sorted(set(np.nonzero(info["iters"] >= 2)[0]) | set(range(0, 2000, 5))))
+    assert (info["iters"] >= 2).sum() > 20 and (info["iters"] == 1).sum() > 1000          # both kinds are present
+    sub = {k: (None if v is None else v[idx]) for k, v in data.items()}
+    zo, nuo, ito, sto, steps = oracle_batch(md, sub, 5, 1e-2)
+    assert np.array_equal(info["iters"][idx], ito) and np.array_equal(info["status"][idx], sto)
+    for q, p in enumerate(idx):
+        assert np.array_equal(canon_steps(info["step"][p][:ito[q]]), canon_steps(steps[q][:ito[q]]))
+        assert rel_err(z[p], zo[q]) <= TOL_Z and rel_err(info["nu"][p], nuo[q]) <= TOL_NU
     h.close()
