@@ -70,6 +70,15 @@ def test_create_argument_checks(pkg):
     assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NOT_PD_PHI
     assert lib.fmpc_destroy(None) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve(None, 1, *([None] * 5), 1, 0.01, *([None] * 5)) == pkg.FMPC_E_NULL
+    # the later entry points refuse a NULL handle / NULL mandatory buffers the same way (no device needed to find out)
+    assert lib.fmpc_solve_device(None, 1, *([None] * 5), 1, 0.01, *([None] * 5), None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_solve_u0_device(None, 1, *([None] * 5), 1, 0.01, *([None] * 6), None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_set_ramp(None, one, one) == pkg.FMPC_E_NULL
+    assert lib.fmpc_solve_ramp(None, 1, *([None] * 6), 1, 0.01, *([None] * 5)) == pkg.FMPC_E_NULL
+    assert lib.fmpc_solve_ramp_device(None, 1, *([None] * 6), 1, 0.01, *([None] * 5), None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_unpack_device(None, 1, None, None, None, None, None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_loop_inputs_device(None, 1, *([None] * 7), None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_last_dispatch(None, None, None) == pkg.FMPC_E_NULL
 
 
 def test_fast_mpc2_validation_mirrors_reference_errors(pkg):
