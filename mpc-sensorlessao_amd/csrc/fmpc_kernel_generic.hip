@@ -478,43 +478,294 @@ fmpc_unpack_kernel(int n, int m, int T, int batch, const double* __restrict__ z,
     }
 }
 
-// Closed-loop inputs (fmpc_loop_inputs_device in include/fastmpc.h; README.md:482-497): one workgroup per problem.
+// Closed-loop inputs (fmpc_loop_inputs_device in include/fastmpc.h; README.md:482-497):
 //   x0 = a + B u1 ,  x0_pre = x0_last ,  w = -M1 (B u1) - M2 (B u2)      M1, M2: (T n) x n row-major
-extern "C" __global__ void __launch_bounds__(256)
-fmpc_loop_inputs_kernel(int n, int m, int T, const double* __restrict__ Bt, const double* __restrict__ M1,
+// A workgroup takes a tile of LI_PT problems and one of LI_RS row slices of w: B u1, B u2 of its problems go to LDS, then
+// every thread keeps one row of M1 and of M2 in registers and applies it to all problems of the tile (a row of M is
+// read once per LI_PT problems, not once per problem: the first version, one workgroup per problem, spent 61 us per
+// step at 512 problems re-reading the 350 KB of M1, M2).
+#define LI_PT 16
+#define LI_RS 8
+#define LI_NMAX 64
+#ifdef FW_TIMING
+__device__ unsigned long long li_timing[8];
+extern "C" int fmpc_debug_loop_inputs_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(li_timing), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#define LI_TICK(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) li_timing[k] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define LI_TICK(k)
+#endif
+// NC: n at compile time (27: the AO configuration), or 0 = any n <= LI_NMAX (arrays sized LI_NMAX, predicated loops)
+template <int NC>
+__global__ void __launch_bounds__(256)
+fmpc_loop_inputs_kernel(int n_rt, int m, int T, int batch, const double* __restrict__ Bt, const double* __restrict__ M1,
                         const double* __restrict__ M2, const double* __restrict__ a, const double* x0_last,
                         const double* __restrict__ u1, const double* __restrict__ u2,
                         double* x0, double* __restrict__ x0_pre, double* __restrict__ w) {
-    extern __shared__ double sh[];                      // bu1[n], bu2[n]
-    double* bu1 = sh; double* bu2 = sh + n;
-    const size_t p = blockIdx.x;
+    extern __shared__ double sh[];      // bu1[LI_PT][n], bu2[LI_PT][n], this row slice of M1 and M2, B' (m x n), u1 and u2 of the tile
+    const int n = NC ? NC : n_rt;
+    constexpr int NQ = NC ? NC : LI_NMAX;
+    double* bu1 = sh; double* bu2 = sh + LI_PT * n;
+    const int rows_ = (T * n + LI_RS - 1) / LI_RS;
+    double* sBt = sh + 2 * LI_PT * n + 2 * (size_t)rows_ * (n + 1);
+    double* su = sBt + (size_t)m * n;
+    const int p0 = blockIdx.x * LI_PT, np = batch - p0 < LI_PT ? batch - p0 : LI_PT;
     const int tid = threadIdx.x;
-    for (int r = tid; r < 2 * n; r += blockDim.x) {
-        const int rr = r < n ? r : r - n;
-        const double* u = r < n ? u1 : u2;
-        double acc = 0.0;
-        if (u) for (int c = 0; c < m; ++c) acc += Bt[(size_t)c * n + rr] * u[p * m + c];
-        sh[r] = acc;
+    // everything the products B u need goes to LDS first with independent, coalesced loads (a dependent chain of global
+    // loads per output cost 40 us here)
+    LI_TICK(0);
+    // (copy loops in batches of 8 loads before the 8 LDS stores: left to itself the compiler waits for every load)
+    for (int base = 0; base < m * n; base += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = Bt[idx < m * n ? idx : 0]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; if (idx < m * n) sBt[idx] = t[k]; }
+    }
+    for (int which = 0; which < 2; ++which) {
+        const double* u = which ? u2 : u1;
+        const int len = np * m;                          // the tile's rows of u are contiguous
+        for (int base = 0; base < LI_PT * m; base += 8 * 256) {
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = (u && idx < len) ? u[(size_t)p0 * m + idx] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; if (idx < LI_PT * m) su[which * LI_PT * m + idx] = t[k]; }
+        }
     }
     __syncthreads();
-    for (int r = tid; r < n; r += blockDim.x) {
-        const double xl = x0_last ? x0_last[p * n + r] : 0.0;
-        x0_pre[p * n + r] = xl;
-        x0[p * n + r] = a[p * n + r] + bu1[r];
+    LI_TICK(1);
+    // B u1, B u2: 2 x LI_PT x n outputs, each a sum over the m actuators.  A thread works on its (up to 4) outputs
+    // INTERLEAVED -- four independent accumulation chains instead of one dependent chain after the other
+    {
+        const int nout = 2 * LI_PT * n;
+        const double* bp[4]; const double* upp[4]; double acc4[4]; bool act[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + k * 256;
+            const int ic = idx < nout ? idx : 0;
+            const int which = ic / (LI_PT * n), rem = ic - which * LI_PT * n, pp = rem / n, r = rem - pp * n;
+            act[k] = idx < nout && pp < np;
+            bp[k] = sBt + r; upp[k] = su + (size_t)(which * LI_PT + pp) * m; acc4[k] = 0.0;
+        }
+        if (act[0] || act[1] || act[2] || act[3]) {
+#pragma unroll 4
+            for (int c = 0; c < m; ++c) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc4[k] += bp[k][(size_t)c * n] * upp[k][c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = tid + k * 256; if (idx < nout) sh[idx] = act[k] ? acc4[k] : 0.0; }
     }
-    for (int e = tid; e < T * n; e += blockDim.x) {
+    __syncthreads();
+    LI_TICK(2);
+    if (blockIdx.y == 0)
+        for (int idx = tid; idx < np * n; idx += blockDim.x) {
+            const int pp = idx / n, r = idx - pp * n;
+            const size_t g = (size_t)(p0 + pp) * n + r;
+            const double xl = x0_last ? x0_last[g] : 0.0;        // (x0 may alias x0_last: read before the write below)
+            x0_pre[g] = xl;
+            x0[g] = a[g] + bu1[pp * n + r];
+        }
+    // thread = (row lane er = tid & 15, problem pp = tid >> 4): B u1, B u2 of its problem in registers; rows of M1, M2 staged
+    // through LDS 16 at a time (coalesced reads), every staged row used by the 16 problems of the tile
+    const int Tn = T * n;
+    const int rows = (Tn + LI_RS - 1) / LI_RS, e0 = blockIdx.y * rows, e1 = e0 + rows < Tn ? e0 + rows : Tn;
+    const int er = tid & 15, pp = tid >> 4;
+    double b1[NQ], b2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        b1[q] = q < n ? bu1[pp * n + q] : 0.0;
+        b2[q] = q < n ? bu2[pp * n + q] : 0.0;
+    }
+    // this workgroup's rows of M1 and M2 into LDS in one go (one memory latency), leading dimension n + 1
+    double* t1 = sh + 2 * LI_PT * n;
+    double* t2 = t1 + (size_t)rows * (n + 1);
+    {
+        const int len = (e1 - e0) * n;                   // the slice's rows are contiguous in M1, M2
+        for (int base = 0; base < rows * n; base += 4 * 256) {
+            double ta[4], tb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * 256 + tid;
+                const bool ok = idx < len;
+                ta[k] = ok ? M1[(size_t)e0 * n + idx] : 0.0;
+                tb[k] = ok ? M2[(size_t)e0 * n + idx] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = base + k * 256 + tid;
+                if (idx < rows * n) { const int rr = idx / n, q = idx - rr * n; t1[rr * (n + 1) + q] = ta[k]; t2[rr * (n + 1) + q] = tb[k]; }
+            }
+        }
+    }
+    __syncthreads();
+    LI_TICK(3);
+    for (int eb = 0; e0 + eb < e1; eb += 16) {
+        const int rr = eb + er < rows ? eb + er : 0;
         double acc = 0.0;
-        const double* r1 = M1 + (size_t)e * n; const double* r2 = M2 + (size_t)e * n;
-        for (int q = 0; q < n; ++q) acc -= r1[q] * bu1[q] + r2[q] * bu2[q];
-        w[p * (size_t)T * n + e] = acc;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q < n) acc -= t1[rr * (n + 1) + q] * b1[q] + t2[rr * (n + 1) + q] * b2[q];
+        if (e0 + eb + er < e1 && pp < np) w[(size_t)(p0 + pp) * Tn + e0 + eb + er] = acc;
     }
+    LI_TICK(4);
+}
+
+// The same for n = 27 on the matrix cores (v_mfma_f64_16x16x4_f64), 16 problems = the N dimension:
+//   B u1, B u2 :  rows q of B (2 row tiles) x actuators (k) x problems: result tile register r of lane (lk, li) = (B u)[16 I + 4 r + lk]
+//                 of problem li -- which is directly the B operand (k-step 4 I + r) of
+//   w          :  rows e of M1 | M2 (A operand straight from L2) x q (7 k-steps each) x problems.
+// Every wave computes B u itself (144 MFMAs, all four SIMDs in parallel) and then its own 16-row tiles of the slice.
+typedef double li_d4 __attribute__((ext_vector_type(4)));
+#define LI_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// (the second launch bound keeps the register budget at 256: with 512 the compiler puts the MFMA results into AGPRs and
+//  copies all accumulators AGPR <-> VGPR around every k-step)
+__global__ void __launch_bounds__(256, 2)
+fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restrict__ Bt, const double* __restrict__ M1,
+                        const double* __restrict__ M2, const double* __restrict__ a, const double* x0_last,
+                        const double* __restrict__ u1, const double* __restrict__ u2,
+                        double* x0, double* __restrict__ x0_pre, double* __restrict__ w) {
+    constexpr int n = 27;
+    extern __shared__ double sh[];                      // B' (m x n), u1 and u2 of the tile (LI_PT x (m + 1) each)
+    double* sBt = sh; double* su = sh + (size_t)m * n;
+    const int ldu = m + 1;                              // padded rows of u: the 16 problems of a k-step read different banks
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int p0 = blockIdx.x * LI_PT, np = batch - p0 < LI_PT ? batch - p0 : LI_PT;
+    const int Tn = T * n, e0 = blockIdx.y * rows, e1 = e0 + rows < Tn ? e0 + rows : Tn;
+    LI_TICK(0);
+    // ---- this wave's first row tile of M1, M2 as A operands: requested now, used last
+    double am1[7], am2[7];
+    {
+        const int e = e0 + 16 * wv + li;
+        const bool eok = e < e1;
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int q = 4 * ks + lk;
+            const bool ok = eok && q < n;
+            const size_t off = (size_t)(eok ? e : e0) * n + (q < n ? q : 0);
+            const double t1 = M1[off], t2 = M2[off];
+            am1[ks] = ok ? t1 : 0.0; am2[ks] = ok ? t2 : 0.0;
+        }
+    }
+    for (int base = 0; base < m * n; base += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = Bt[idx < m * n ? idx : 0]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; if (idx < m * n) sBt[idx] = t[k]; }
+    }
+    for (int which = 0; which < 2; ++which) {
+        const double* u = which ? u2 : u1;
+        const int len = np * m;
+        for (int base = 0; base < LI_PT * m; base += 8 * 256) {
+            double t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = (u && idx < len) ? u[(size_t)p0 * m + idx] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = base + k * 256 + tid;
+                if (idx < LI_PT * m) { const int pp = idx / m; su[(which * LI_PT + pp) * ldu + idx - pp * m] = t[k]; }
+            }
+        }
+    }
+    __syncthreads();
+    LI_TICK(1);
+    // ---- B u1, B u2
+    li_d4 bu[2][2];
+#pragma unroll
+    for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+        for (int I = 0; I < 2; ++I) bu[wh][I] = li_d4{0, 0, 0, 0};
+    {
+        const int q0 = li, q1 = 16 + li < n ? 16 + li : n - 1;
+        const bool q1ok = 16 + li < n;
+        const double* ua = su + (size_t)li * ldu;
+        const double* ub = su + (size_t)(LI_PT + li) * ldu;
+#pragma unroll 4
+        for (int c0 = 0; c0 < m; c0 += 4) {
+            const int c = c0 + lk;
+            const bool cok = c < m;
+            const int cc = cok ? c : m - 1;
+            const double r0 = sBt[(size_t)cc * n + q0], r1 = sBt[(size_t)cc * n + q1];   // unconditional loads, then selects:
+            const double b0 = cok ? r0 : 0.0;                                            // (a conditional load becomes a branch
+            const double b1 = (cok && q1ok) ? r1 : 0.0;                                  //  and the accumulators bounce AGPR <-> VGPR)
+            const double v1 = ua[cc], v2 = ub[cc];
+            bu[0][0] = LI_MFMA(b0, v1, bu[0][0]); bu[0][1] = LI_MFMA(b1, v1, bu[0][1]);
+            bu[1][0] = LI_MFMA(b0, v2, bu[1][0]); bu[1][1] = LI_MFMA(b1, v2, bu[1][1]);
+        }
+    }
+    LI_TICK(2);
+    // ---- x0 = a + B u1 ,  x0_pre = x0_last    (one wave of the first row slice)
+    if (blockIdx.y == 0 && wv == 0 && li < np) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * I + 4 * r + lk;
+                if (q < n) {
+                    const size_t g = (size_t)(p0 + li) * n + q;
+                    const double xl = x0_last ? x0_last[g] : 0.0;    // (x0 may alias x0_last: read before the write below)
+                    x0_pre[g] = xl;
+                    x0[g] = a[g] + bu[0][I][r];
+                }
+            }
+    }
+    LI_TICK(3);
+    // ---- w = -M1 (B u1) - M2 (B u2): this wave's row tiles of the slice
+    for (int t = wv; 16 * t < e1 - e0; t += 4) {
+        if (t != wv) {                                   // (slices longer than 64 rows: further tiles, loaded here)
+            const int e = e0 + 16 * t + li;
+            const bool eok = e < e1;
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int q = 4 * ks + lk;
+                const bool ok = eok && q < n;
+                const size_t off = (size_t)(eok ? e : e0) * n + (q < n ? q : 0);
+                const double t1 = M1[off], t2 = M2[off];
+                am1[ks] = ok ? t1 : 0.0; am2[ks] = ok ? t2 : 0.0;
+            }
+        }
+        li_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            acc = LI_MFMA(am1[ks], bu[0][ks >> 2][ks & 3], acc);
+            acc = LI_MFMA(am2[ks], bu[1][ks >> 2][ks & 3], acc);
+        }
+        if (li < np) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = e0 + 16 * t + 4 * r + lk;
+                if (e < e1) w[(size_t)(p0 + li) * Tn + e] = -acc[r];
+            }
+        }
+    }
+    LI_TICK(4);
 }
 
 hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
                                    const double* a, const double* x0_last, const double* u1, const double* u2,
                                    double* x0, double* x0_pre, double* w, hipStream_t stream) {
-    hipLaunchKernelGGL(fmpc_loop_inputs_kernel, dim3(batch), dim3(256), 2 * n * sizeof(double), stream,
-                       n, m, T, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w);
+    if (n > LI_NMAX) return hipErrorInvalidValue;
+    if (n == 27) {
+        const int Tn = T * n, rs = (Tn + 63) / 64, rows = (Tn + rs - 1) / rs;      // <= 64 rows = 4 tiles per workgroup
+        const size_t lds = ((size_t)m * n + 2 * LI_PT * (m + 1)) * sizeof(double);
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t ea = hipFuncSetAttribute((const void*)fmpc_loop_inputs_mfma27, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+        hipLaunchKernelGGL(fmpc_loop_inputs_mfma27, dim3((batch + LI_PT - 1) / LI_PT, rs), dim3(256), lds, stream,
+                           m, T, batch, rows, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w);
+        return hipGetLastError();
+    }
+    const auto kern = fmpc_loop_inputs_kernel<0>;
+    const size_t lds = (2 * LI_PT * n + 2 * (size_t)((T * n + LI_RS - 1) / LI_RS) * (n + 1) + (size_t)m * n + 2 * LI_PT * m) * sizeof(double);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t ea = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL(kern, dim3((batch + LI_PT - 1) / LI_PT, LI_RS), dim3(256), lds, stream,
+                       n, m, T, batch, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w);
     return hipGetLastError();
 }
 
