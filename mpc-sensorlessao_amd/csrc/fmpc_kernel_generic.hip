@@ -684,7 +684,6 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
         const bool q1ok = 16 + li < n;
         const double* ua = su + (size_t)li * ldu;
         const double* ub = su + (size_t)(LI_PT + li) * ldu;
-#pragma unroll 4
         for (int c0 = 0; c0 < m; c0 += 4) {
             const int c = c0 + lk;
             const bool cok = c < m;

@@ -271,32 +271,54 @@ FP_FN double fp_s1(FpKP P, double* lds_g, int panel, double* rdlb, unsigned long
             }
         }
     } else {
-        // ---- stages >= 2 with w: tasks (stage, row block) dealt to the waves
-        for (int task = 4 + wv; task < 2 * nb; task += FP_WAVES) {
-            const int i = task >> 1, I = task & 1;
-            d4 acc;
+        // ---- stages >= 2 with w: tasks (stage, row block) dealt to the waves.  Everything a task reads from memory (rt,
+        // w, the image of Linv_i) is requested one task ahead: a wave has ~7 tasks and a load costs 1-2 k cycles here.
+        struct Tk { double rtv[4], wv[FP_KS], im[FP_KS], cpv[FP_KS]; };
+        auto tload = [&](int task, Tk& t) {
+            const int tc = task < 2 * nb ? task : 2 * nb - 1;            // (past the end: a valid task, loaded and dropped)
+            const int i = tc >> 1, I = tc & 1;
+            const int iw = i < T ? i : T - 1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * I + 4 * r + g;
-                acc[r] = rt[i * 32 + (row < FP_N ? row : 0)];
+                t.rtv[r] = rt[i * 32 + (row < FP_N ? row : 0)];
             }
+            const double* img = P->simg + (size_t)iw * FP_IMG + (size_t)(I * FP_KS) * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < FP_KS; ++e) {
+                t.wv[e] = w[iw * FP_N + (4 * e + g < FP_N ? 4 * e + g : 0)];
+                t.cpv[e] = cp[i * 32 + (4 * e + g < FP_N ? 4 * e + g : 0)];
+                t.im[e] = img[e * 64];
+            }
+        };
+        auto tdo = [&](int task, const Tk& t) {
+            if (task >= 2 * nb) return;
+            const int i = task >> 1, I = task & 1;
+            d4 acc = {t.rtv[0], t.rtv[1], t.rtv[2], t.rtv[3]};
             if (i < T) {
                 double v[FP_KS];
 #pragma unroll
                 for (int e = 0; e < FP_KS; ++e) {
                     const bool rok = 4 * e + g < FP_N;
-                    const int rc = rok ? 4 * e + g : 0;
-                    const double wi = w[i * FP_N + rc];
-                    if (rok && I == 0) { const double rp = cp[i * 32 + rc] - wi; rp2 = fma(rp, rp, rp2); }
-                    v[e] = rok ? -wi : 0.0;
+                    if (rok && I == 0) { const double rp = t.cpv[e] - t.wv[e]; rp2 = fma(rp, rp, rp2); }
+                    v[e] = rok ? -t.wv[e] : 0.0;
                 }
-                acc = fp_mm_g(P->simg + (size_t)i * FP_IMG, I, lane, v, acc);
+#pragma unroll
+                for (int ks = 0; ks < FP_KS; ++ks) acc = MFMA64(t.im[ks], v[ks], acc);
             } else if (I == 0) {                             // the xf row: b_T = 0
 #pragma unroll
                 for (int e = 0; e < FP_KS; ++e)
-                    if (4 * e + g < FP_N) { const double cc = cp[i * 32 + 4 * e + g]; rp2 = fma(cc, cc, rp2); }
+                    if (4 * e + g < FP_N) rp2 = fma(t.cpv[e], t.cpv[e], rp2);
             }
             fp_store_d(Y, i, I, g, c16, acc);
+        };
+        Tk ta, tb;
+        tload(4 + wv, ta);
+        for (int task = 4 + wv; task < 2 * nb; task += 2 * FP_WAVES) {
+            tload(task + FP_WAVES, tb);
+            tdo(task, ta);
+            tload(task + 2 * FP_WAVES, ta);
+            tdo(task + FP_WAVES, tb);
         }
     }
     FP_STICK(2);
