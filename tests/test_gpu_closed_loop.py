@@ -11,7 +11,7 @@ from tests.util import handle_from_model, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,m,T,nw", [(27, 144, 30, 1), (27, 144, 10, 3), (8, 5, 6, 2)])
+@pytest.mark.parametrize("n,m,T,nw", [(27, 144, 30, 1), (27, 144, 10, 3), (8, 5, 6, 2), (27, 97, 6, 1)])   # last: m not a multiple of 4
 def test_closed_loop_matches_oracle(pkg, gpu, n, m, T, nw):
     import torch
     md = pkg.synthetic.make_model(n, m, T)
