@@ -59,3 +59,30 @@ def test_closed_loop_with_ramp_rows(pkg, gpu, n, m, T, nw, var_order):
         ref = closed_loop(md, a[:, r], nw, 1e-2, ramp=(-du, du))
         assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
     h.close()
+
+
+@pytest.mark.parametrize("n,m,T", [(27, 144, 30), (27, 97, 7), (8, 5, 6)])
+def test_loop_inputs_kernel_against_numpy(pkg, gpu, n, m, T):
+    """fmpc_loop_inputs_device alone (several 16-problem tiles, a ragged last one; matrix-core kernel for n = 27, the
+    plain one otherwise): x0 = a + B u1, x0_pre = x0_last, w = -M1 B u1 - M2 B u2, and the NULL variants of the first steps."""
+    import torch
+    md = pkg.synthetic.make_model(n, m, T)
+    R = 37
+    rng = np.random.default_rng(4)
+    a, xl, u1, u2 = rng.standard_normal((R, n)), rng.standard_normal((R, n)), rng.standard_normal((R, m)), rng.standard_normal((R, m))
+    M1, M2 = design_matrices(md["A1"], md["A2"], T)
+    h = handle_from_model(pkg, md)
+    dev = torch.device("cuda:0")
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    f = dict(dtype=torch.float64, device=dev)
+    for use1, use2, usel in ((True, True, True), (True, False, True), (False, False, False)):
+        x0, x0p, w = torch.full((R, n), np.nan, **f), torch.full((R, n), np.nan, **f), torch.full((R, T * n), np.nan, **f)
+        h.loop_inputs_device(t(a), t(xl) if usel else None, t(u1) if use1 else None, t(u2) if use2 else None, x0, x0p, w)
+        torch.cuda.synchronize()
+        bu1 = (md["B"] @ u1.T).T if use1 else np.zeros((R, n))
+        bu2 = (md["B"] @ u2.T).T if use2 else np.zeros((R, n))
+        assert rel_err(x0.cpu().numpy(), a + bu1) <= 1e-13
+        assert np.array_equal(x0p.cpu().numpy(), xl if usel else np.zeros((R, n)))
+        w_ref = -(M1 @ bu1.T).T - (M2 @ bu2.T).T
+        assert np.abs(w.cpu().numpy() - w_ref).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
+    h.close()
