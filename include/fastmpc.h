@@ -18,8 +18,12 @@
  *     (fast_mpc_init.m:22-25), N_z = T*(n+m).
  *   - nu has `fmpc_nu_len()` = n*(T + (xf given ? 1 : 0)) entries (length(b),
  *     inf_newton_solver.m:2).
- *   - Caller owns every buffer.  The handle copies the shared model to the device once and is
+ *   - Caller owns every buffer.  The handle copies the shared model to the device once; the model is
  *     immutable afterwards.  No pointer passed to a solve call is retained.
+ *   - A handle may be used from several threads and streams: its device workspaces serve one solve at
+ *     a time, so the library orders the solves of ONE handle on the device (a solve enqueued on
+ *     another stream than the handle's previous one first waits for that one).  Solves that should
+ *     overlap need a handle each (mpc-sensorlessao_amd/lanes.py).
  *   - Functions return FMPC_OK (0), a negative error, or a positive warning; nothing throws.
  *   - There is NO CPU fallback: without a usable HIP device fmpc_create fails with
  *     FMPC_E_NO_DEVICE / FMPC_E_HIP.
@@ -63,6 +67,7 @@ const char* fmpc_strerror(int code);
  * fast_mpc_ineq_const.m:46-56).
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
+ *   n          <= 79 (n <= 64: fp64 kernels; 64 < n <= 79: fp32 factor + fp64 residuals, see fmpc_set_precision).
  *   Q,R,Qf     n x n, m x m, n x n.  Must be diagonal for now (else FMPC_E_UNSUPPORTED);
  *              diagonal entries must be > 0 (else FMPC_E_NOT_PD_PHI).
  *   q,r,qf     NULL = zeros (fast_mpc_objective.m:26-47).
@@ -161,6 +166,12 @@ int fmpc_solve_once(int n, int m, int T, int var_order,
                     const double* w, const double* xf, const double* x_init,
                     const double* nu0, int nw, double k, int device,
                     double* x_opt, int* iters);
+/*
+ * The reference rebuilds its object at every timestep with an unchanged model (README.md:548).  fmpc_solve_once keeps
+ * the device handles of the last 4 distinct models (compared byte for byte over every model argument), so only the
+ * first call with a model allocates, uploads and factors; fmpc_solve_once_cache_clear releases them.
+ */
+int fmpc_solve_once_cache_clear(void);
 
 /*
  * Coefficient-space closed loop: the steps either side of the solver in the reference's simulation loop
@@ -199,6 +210,20 @@ int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                            void* stream);
 
 /*
+ * Arithmetic of the per-problem-factor path (no counterpart in the reference, which is fp64 throughout).
+ *   FMPC_PREC_F64        everything in fp64 (default wherever an fp64 kernel exists: n <= 64)
+ *   FMPC_PREC_F32_MIXED  "fp32 mixed precision" (BASELINE configs[4]): Y = C Phi^-1 C', its block Cholesky factor
+ *                        (inf_newton_solver.m:27,30) and the two triangular sweeps (:31-32) in fp32 on the matrix
+ *                        cores; the residuals r_d, r_p (:12-17), the right-hand side (:28-29), d_z, the line search
+ *                        and the iterate z, nu stay fp64, so every Newton step refines the fp32 KKT solve of the
+ *                        previous one against fp64 residuals.  Default for 64 < n <= 79 (only path there).
+ * FMPC_E_UNSUPPORTED when the handle's size has no kernel of that type.
+ */
+#define FMPC_PREC_F64        0
+#define FMPC_PREC_F32_MIXED  1
+int fmpc_set_precision(fmpc_handle h, int mode);
+
+/*
  * Diagnostic (no counterpart in the reference): which device path the last fmpc_solve[_device] call of
  * this handle took, and how many problems the panel kernel handed to the exact per-problem path because
  * their step-length / exit decision was not clear-cut.  Synchronises the device.
@@ -210,6 +235,8 @@ int fmpc_solve_ramp_device(fmpc_handle h, int batch,
 #define FMPC_PATH_SHARED  2
 #define FMPC_PATH_PANEL   3
 #define FMPC_PATH_RAMP    4
+#define FMPC_PATH_TILED   5   /* tiled kernel, fp64 factor */
+#define FMPC_PATH_TILED_F32 6 /* tiled kernel, fp32 factor + fp64 residuals */
 int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
 
 #ifdef __cplusplus

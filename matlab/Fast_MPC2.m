@@ -56,16 +56,19 @@ classdef Fast_MPC2
         function x_opt = solve_once(obj, z_init, nw, k)
             n = size(obj.Q,1); m = size(obj.R,1); Nz = obj.T*(n+m);
             nu0 = rand(obj.T*n + n*(~isempty(obj.x_final)), 1);  % inf_newton_solver.m:2, drawn here
-            z = zeros(Nz,1); iters = int32(0);
             P = @(a) libpointer('doublePtr', a);                 % [] -> NULL
-            [rc, ~, ~] = calllib('libfastmpc','fmpc_solve_once', n, m, obj.T, 2, ...
+            % calllib copies INTO a libpointer's own buffer: the outputs must be read back from pointers that
+            % are kept in variables (a temporary libpointer, or a plain array argument, would be lost)
+            pz = libpointer('doublePtr', zeros(Nz,1));
+            pit = libpointer('int32Ptr', int32(0));
+            rc = calllib('libfastmpc','fmpc_solve_once', n, m, obj.T, 2, ...
                 P(obj.Q),P(obj.R),P(obj.S),P(obj.Qf),P(obj.q),P(obj.r),P(obj.qf), ...
                 P(obj.x_min),P(obj.x_max),P(obj.u_min),P(obj.u_max),P(obj.du_min),P(obj.du_max), ...
                 P(obj.x0),P(obj.x0_pre),P(obj.u_prev),P(obj.A1),P(obj.A2),P(obj.B), ...
                 P(obj.w),P(obj.x_final),P(z_init),P(nu0), int32(nw), k, int32(obj.device), ...
-                libpointer('doublePtr', z), libpointer('int32Ptr', iters));
+                pz, pit);
             if rc < 0, error('fastmpc:%d %s', rc, calllib('libfastmpc','fmpc_strerror',rc)); end
-            x_opt = z;
+            x_opt = pz.Value;                                    % N_z x 1, interleaved [u0;x1;u1;x2;...]
         end
     end
 end

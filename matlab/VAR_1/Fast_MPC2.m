@@ -25,23 +25,48 @@ classdef Fast_MPC2
             x_opt = obj.solve_once(obj.x_init, nw, k);
         end
         function x_opt = mpc_fixed_log(obj,k)
-            x_opt = obj.solve_once(obj.x_init, 0, k);
+            x_opt = obj.solve_once(obj.x_init, 0, k);          % nw = []: <= 1000 iterations + tolerance
+        end
+        function x_opt = mpc_fixed_newton(obj,nw)                % VAR_1/Fast_MPC2.m, same body as VAR_2 :131-144
+            x_opt = obj.k_schedule(nw);
+        end
+        function x_opt = mpc_solve_full(obj)                     % same body as VAR_2 :100-115
+            x_opt = obj.k_schedule(0);
+        end
+        function x_opt = mpc_solve_check(obj,k_min,k_max)        % same body as VAR_2 :88-99
+            ks = linspace(k_max,k_min,5); z = obj.initialize();
+            for i = 1:numel(ks), z = obj.solve_once(z, 0, ks(i)); end
+            x_opt = z;
+        end
+        function z_init = initialize(obj)                        % fast_mpc_init.m:12-27
+            n = size(obj.Q,1); m = size(obj.R,1);
+            if ~isempty(obj.x_init), z_init = obj.x_init; return; end
+            z_init = repmat([(obj.u_min+obj.u_max)/2; (obj.x_min+obj.x_max)/2], obj.T, 1);
+            assert(numel(z_init) == obj.T*(n+m));
         end
     end
     methods (Access = private)
+        function x_opt = k_schedule(obj,nw)                      % k = 1, x0.1 while k*length(z) >= 10e-3, warm starts
+            k = 1; mu = 1/10; z = obj.initialize(); x_opt = z;
+            while k*length(z) >= 10e-3
+                x_opt = obj.solve_once(z, nw, k); k = mu*k; z = x_opt;
+            end
+        end
         function x_opt = solve_once(obj, z_init, nw, k)
             n = size(obj.Q,1); m = size(obj.R,1); Nz = obj.T*(n+m);
             nu0 = rand(obj.T*n + n*(~isempty(obj.x_final)), 1);  % inf_newton_solver.m:2, drawn here
-            z = zeros(Nz,1); iters = int32(0);
             P = @(a) libpointer('doublePtr', a);                 % [] -> NULL
-            [rc, ~, ~] = calllib('libfastmpc','fmpc_solve_once', n, m, obj.T, 1, ...
+            % outputs are read back from libpointers kept in variables (calllib writes into the pointer's own buffer)
+            pz = libpointer('doublePtr', zeros(Nz,1));
+            pit = libpointer('int32Ptr', int32(0));
+            rc = calllib('libfastmpc','fmpc_solve_once', n, m, obj.T, 1, ...
                 P(obj.Q),P(obj.R),P(obj.S),P(obj.Qf),P(obj.q),P(obj.r),P(obj.qf), ...
                 P(obj.x_min),P(obj.x_max),P(obj.u_min),P(obj.u_max),P(obj.du_min),P(obj.du_max), ...
                 P(obj.x0),P([]),P(obj.u_prev),P(obj.A),P([]),P(obj.B), ...
                 P(obj.w),P(obj.x_final),P(z_init),P(nu0), int32(nw), k, int32(obj.device), ...
-                libpointer('doublePtr', z), libpointer('int32Ptr', iters));
+                pz, pit);
             if rc < 0, error('fastmpc:%d %s', rc, calllib('libfastmpc','fmpc_strerror',rc)); end
-            x_opt = z;
+            x_opt = pz.Value;
         end
     end
 end

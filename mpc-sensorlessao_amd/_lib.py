@@ -27,6 +27,10 @@ FMPC_PATH_WAVE = 1
 FMPC_PATH_SHARED = 2
 FMPC_PATH_PANEL = 3
 FMPC_PATH_RAMP = 4
+FMPC_PATH_TILED = 5
+FMPC_PATH_TILED_F32 = 6
+FMPC_PREC_F64 = 0
+FMPC_PREC_F32_MIXED = 1
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -45,10 +49,12 @@ SIGNATURES = {
     "fmpc_unpack": (C.c_int, [_vp, C.c_int] + [_vp] * 4),
     "fmpc_unpack_device": (C.c_int, [_vp, C.c_int] + [_vp] * 4 + [_vp]),
     "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
+    "fmpc_solve_once_cache_clear": (C.c_int, []),
     "fmpc_last_dispatch": (C.c_int, [_vp, _ip, _ip]),
     "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
     "fmpc_solve_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),
+    "fmpc_set_precision": (C.c_int, [_vp, C.c_int]),
     "fmpc_solve_ramp": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5),
     "fmpc_solve_ramp_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5 + [_vp]),
 }

@@ -12,6 +12,7 @@
 #include "../../include/fastmpc.h"
 #include "fmpc_device.h"
 #include "fmpc_panel.h"
+#include "fmpc_tiled.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
 size_t fmpc_generic_lds_bytes(int n, int m);
@@ -98,10 +99,20 @@ struct fmpc_handle_s {
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
+    // tiled kernel (fmpc_kernel_tiled.hip): workgroup per problem, any n <= 79; images per arithmetic type, built on first use
+    int generic_ok;                      // the generic kernel's LDS tiles fit (n <= 64)
+    int prec;                            // FMPC_PREC_F64 / FMPC_PREC_F32_MIXED of the per-problem-factor path
+    int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
+    struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // [0] fp64, [1] fp32
+    double* tl_ws; size_t tl_ws_doubles;
+    std::vector<double> hm_b;            // B row-major n x m
     // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
     double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
     double* ramp_ws; size_t ramp_ws_doubles;
-    // workspace, grown on demand; guarded because a handle may be shared between threads
+    // A handle's device workspaces serve ONE solve at a time.  Solves enqueued on different streams are ordered on
+    // the device: every solve records `ev`, and a solve on another stream than the last one waits for it first.
+    hipEvent_t ev; int ev_valid; hipStream_t last_stream;
+    // workspace, grown on demand; `mu` serialises the host-side enqueue (a handle may be shared between threads)
     std::mutex mu;
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
     double* ws;
@@ -174,9 +185,13 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         if (!(cm(Q, n, i, i) > 0.0) || !(cm(Qf, n, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
     for (int i = 0; i < m; ++i)
         if (!(cm(R, m, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
-    if (n > 64) return FMPC_E_UNSUPPORTED;
-    const size_t lds = fmpc_generic_lds_bytes(n, m);
-    if (lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+    // per-problem-factor paths: the generic kernel (n <= 64 and its tiles fit the LDS), else the tiled kernel in fp64
+    // (n <= 47), else the tiled kernel with an fp32 factor (n <= 79: "fp32 mixed precision", BASELINE configs[4])
+    size_t lds = fmpc_generic_lds_bytes(n, m);
+    const bool generic_ok = n <= 64 && lds <= FMPC_LDS_LIMIT;
+    const bool tiled64 = fmpc_tiled_supports(n, m, 0, nullptr, nullptr), tiled32 = fmpc_tiled_supports(n, m, 1, nullptr, nullptr);
+    if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
+    if (!generic_ok) lds = 0;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FMPC_E_NO_DEVICE;
@@ -190,6 +205,11 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
+    h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
+    h->generic_ok = generic_ok ? 1 : 0;
+    h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
+    { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
+    memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0;
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
@@ -197,7 +217,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    h->wg_per_cu = (int)(FMPC_LDS_LIMIT / lds);
+    h->wg_per_cu = lds ? (int)(FMPC_LDS_LIMIT / lds) : 1;
     if (h->wg_per_cu < 1) h->wg_per_cu = 1;
     if (h->wg_per_cu > 8) h->wg_per_cu = 8;
 
@@ -340,7 +360,12 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
     h->loop_M1 = h->pool_d + oM1; h->loop_M2 = h->pool_d + oM2;
 
-    if (fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+    if (generic_ok && fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+    // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
+    h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
+    h->hm_b.resize((size_t)n * m);
+    for (int rr = 0; rr < n; ++rr)
+        for (int c = 0; c < m; ++c) h->hm_b[(size_t)rr * m + c] = cm(B, n, rr, c);
 
     // ---- wave kernel: MFMA-layout images of the constant blocks (+ a zero block), padded B'
     const char* force = getenv("FMPC_FORCE_GENERIC");
@@ -457,6 +482,13 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->pn_rnp) (void)hipFree(h->pn_rnp);
     if (h->pn_list) (void)hipFree(h->pn_list);
     if (h->pn_cnt_host) (void)hipHostFree(h->pn_cnt_host);
+    for (int t = 0; t < 2; ++t) {
+        if (h->tl[t].pool) (void)hipFree(h->tl[t].pool);
+        if (h->tl[t].ipool) (void)hipFree(h->tl[t].ipool);
+        if (h->tl[t].bm) (void)hipFree(h->tl[t].bm);
+    }
+    if (h->tl_ws) (void)hipFree(h->tl_ws);
+    if (h->ev) (void)hipEventDestroy(h->ev);
     if (h->ramp_du) (void)hipFree(h->ramp_du);
     if (h->ramp_ws) (void)hipFree(h->ramp_ws);
     if (h->ws) (void)hipFree(h->ws);
@@ -849,6 +881,87 @@ static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
     return FMPC_OK;
 }
 
+// Images of the tiled kernel for one arithmetic type (0: fp64, 1: fp32): the unique constant Y blocks and B' as
+// zero-padded 16 x 16 tiles, block ids with the zero block substituted for "none".  Built on first use.
+template <typename R>
+static int fmpc_tiled_build(fmpc_handle h, int t) {
+    fmpc_handle_s::Tiled& X = h->tl[t];
+    const int n = h->n, m = h->m, nb = h->nb, nn = n * n;
+    int NB = 0, NW = 0;
+    if (!fmpc_tiled_supports(n, m, t, &NB, &NW)) return FMPC_E_UNSUPPORTED;
+    const int mb = (m + 15) / 16, NQ = NB * NB;
+    const int nblk = (int)(h->hm_blocks.size() / nn);
+    std::vector<R> img((size_t)(nblk + 1) * NQ * FT_TILE + (size_t)mb * NB * FT_TILE, (R)0);
+    for (int k = 0; k < nblk; ++k)
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b)
+                img[((size_t)k * NQ + (a / 16) * NB + b / 16) * FT_TILE + (a % 16) * 16 + b % 16] = (R)h->hm_blocks[(size_t)k * nn + a * n + b];
+    const size_t obt = (size_t)(nblk + 1) * NQ * FT_TILE;
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < n; ++r)
+            img[obt + ((size_t)(c / 16) * NB + r / 16) * FT_TILE + (c % 16) * 16 + r % 16] = (R)h->hm_bt[(size_t)c * n + r];
+    std::vector<int> ids;
+    for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idxD[i]);
+    for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idx1[i] >= 0 ? h->hm_idx1[i] : nblk);
+    for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idx2[i] >= 0 ? h->hm_idx2[i] : nblk);
+    if (hipMalloc(&X.pool, img.size() * sizeof(R)) != hipSuccess ||
+        hipMalloc((void**)&X.ipool, ids.size() * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&X.bm, h->hm_b.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+    if (hipMemcpy(X.pool, img.data(), img.size() * sizeof(R), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(X.ipool, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(X.bm, h->hm_b.data(), h->hm_b.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    X.NB = NB; X.NW = NW;
+    X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t);
+    if (fmpc_tiled_prepare(NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
+    X.V.NB = NB; X.V.mb = mb; X.V.cn = n / 16; X.V.nl = n % 16; X.V.nblk = nblk;
+    X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
+    X.V.iD = X.ipool; X.V.i1 = X.ipool + nb; X.V.i2 = X.ipool + 2 * nb;
+    X.V.Bm = X.bm;
+    X.ready = 1;
+    return FMPC_OK;
+}
+
+// launches the tiled kernel; caller holds h->mu
+static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, const double* x0_pre, const double* w,
+                            const double* z_init, const double* nu0, int n_newton, double k, double* z_out,
+                            double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+    fmpc_handle_s::Tiled& X = h->tl[t];
+    if (!X.ready) {
+        const int rc = t ? fmpc_tiled_build<float>(h, 1) : fmpc_tiled_build<double>(h, 0);
+        if (rc != FMPC_OK) return rc;
+    }
+    int wgs = (int)(FMPC_LDS_LIMIT / X.lds);
+    if (wgs < 1) wgs = 1;
+    if (wgs * X.NW > 8) wgs = 8 / X.NW > 0 ? 8 / X.NW : 1;             // two waves per SIMD (launch bound)
+    const int cap = h->num_cu * wgs;
+    const int grid = batch < cap ? batch : cap;
+    const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8);
+    const size_t need = L.total * (size_t)cap;
+    if (need > h->tl_ws_doubles) {
+        if (h->tl_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->tl_ws); h->tl_ws = nullptr; h->tl_ws_doubles = 0; }
+        if (hipMalloc((void**)&h->tl_ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->tl_ws_doubles = need;
+    }
+    FtParams P;
+    P.M = h->dev; P.V = X.V; P.batch = batch;
+    P.x0 = x0; P.x0p = x0_pre; P.w = w; P.zinit = z_init; P.nu0 = nu0;
+    P.max_iter = n_newton > 0 ? n_newton : 1000; P.kbar = k;
+    P.zout = z_out; P.nuout = nu_out; P.status = status; P.iters = iters; P.step = step; P.step_ld = fmpc_step_ld(n_newton);
+    P.ws = h->tl_ws; P.ws_stride = L.total; P.u0out = u0_out;
+    h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
+    return fmpc_launch_tiled(P, X.NB, X.NW, t, grid, X.lds, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
+    if (!h) return FMPC_E_NULL;
+    if (mode != FMPC_PREC_F64 && mode != FMPC_PREC_F32_MIXED) return FMPC_E_DIM;
+    if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, 1, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
+    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, 0, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->prec = mode;
+    return FMPC_OK;
+}
+
 static int fmpc_grid_for(fmpc_handle h, int batch) {
     int cap = h->num_cu * h->wg_per_cu;
     return batch < cap ? batch : cap;
@@ -867,9 +980,20 @@ static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
     return FMPC_OK;
 }
 
+// Orders the solves of a handle that arrive on different streams (they share the handle's workspaces): called with
+// h->mu held, before the first launch of a solve and after its last one.
+static int fmpc_guard_begin(fmpc_handle h, hipStream_t stream) {
+    if (!h->ev && hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) return FMPC_E_HIP;
+    if (h->ev_valid && stream != h->last_stream && hipStreamWaitEvent(stream, h->ev, 0) != hipSuccess) return FMPC_E_HIP;
+    return FMPC_OK;
+}
+static void fmpc_guard_end(fmpc_handle h, hipStream_t stream) {
+    if (h->ev && hipEventRecord(h->ev, stream) == hipSuccess) { h->ev_valid = 1; h->last_stream = stream; }
+}
+
 // fmpc_solve_device (u0_out == NULL) / fmpc_solve_u0_device: the first moves are written by the solve's last kernel
 // where that kernel visits every problem anyway (the wave kernel), by the unpack kernel otherwise
-static int fmpc_solve_device_impl(fmpc_handle h, int batch,
+static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                                   const double* x0, const double* x0_pre, const double* w,
                                   const double* z_init, const double* nu0,
                                   int n_newton, double k,
@@ -878,10 +1002,11 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
     if (!h || !x0 || !z_out) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
-    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
-    std::lock_guard<std::mutex> lk(h->mu);
     const int max_iter = n_newton > 0 ? n_newton : 1000;
     hipError_t e;
+    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || (!h->use_wave && !h->generic_ok))
+        return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
+                                z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
     if (h->use_wave) {
         // one wavefront per problem, 8 per workgroup, one workgroup per CU
         const int wpw = fmpc_wave_waves_per_wg();
@@ -898,6 +1023,9 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
         if (h->sh_enabled && z_init == nullptr) {
             // cold start: the first Newton step of every problem shares one factor (depends on k only)
             if (!h->sh_valid || h->sh_k != k) {
+                // earlier solves (ordered before this point on `stream` by the guard) may still read the constants of
+                // the previous k, which the blocking uploads below overwrite
+                if (h->sh_valid && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
                 double* scr = h->sh_scratch;                 // a zero state: x0 = x0_pre = 0, w = nu0 = 0
                 e = fmpc_launch_wave(h->dev, h->wave, 1, 1, scr, scr, nullptr, nullptr, nullptr, 1, k,
                                      scr + ((h->n + 15) & ~15), nullptr, nullptr, nullptr, nullptr, 1, h->ws, stride,
@@ -1005,6 +1133,25 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
+static int fmpc_solve_device_impl(fmpc_handle h, int batch,
+                                  const double* x0, const double* x0_pre, const double* w,
+                                  const double* z_init, const double* nu0,
+                                  int n_newton, double k,
+                                  double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                  double* u0_out, void* stream) {
+    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = fmpc_guard_begin(h, (hipStream_t)stream);
+    if (rc != FMPC_OK) return rc;
+    rc = fmpc_solve_device_inner(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                 u0_out, stream);
+    fmpc_guard_end(h, (hipStream_t)stream);
+    return rc;
+}
+
 extern "C" int fmpc_solve_device(fmpc_handle h, int batch,
                                  const double* x0, const double* x0_pre, const double* w,
                                  const double* z_init, const double* nu0,
@@ -1089,9 +1236,11 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
         h->ramp_ws_doubles = need;
     }
     h->last_path = FMPC_PATH_RAMP;
+    if (fmpc_guard_begin(h, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
     const hipError_t e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_init,
                                           nu0, max_iter, k, z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
                                           h->ramp_ws, stride, threads, (hipStream_t)stream);
+    fmpc_guard_end(h, (hipStream_t)stream);
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
@@ -1226,6 +1375,29 @@ extern "C" int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U,
     return rc;
 }
 
+// The reference rebuilds its (value-class) object at every timestep (README.md:548) with the same model; doing the same
+// here would allocate, upload and -- on the panel path -- factor again at every call.  fmpc_solve_once therefore keeps
+// the handles of the last few models it has seen, keyed on the exact bytes of every model argument.
+namespace {
+struct OnceEntry { std::vector<double> key; fmpc_handle h; std::vector<double> ramp; unsigned long long stamp; };
+std::mutex once_mu;
+std::vector<OnceEntry> once_cache;
+unsigned long long once_clock = 0;
+const size_t ONCE_CAPACITY = 4;
+
+void once_key_push(std::vector<double>& key, const double* p, size_t cnt) {
+    key.push_back(p ? (double)cnt : -1.0);                        // NULL and present arguments differ
+    if (p) key.insert(key.end(), p, p + cnt);
+}
+}  // namespace
+
+extern "C" int fmpc_solve_once_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(once_mu);
+    for (OnceEntry& e : once_cache) fmpc_destroy(e.h);
+    once_cache.clear();
+    return FMPC_OK;
+}
+
 extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
                                const double* Q, const double* R, const double* S, const double* Qf,
                                const double* q, const double* r, const double* qf,
@@ -1242,17 +1414,48 @@ extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
     // (VAR_1/fast_mpc_ineq_const.m:58-76)
     const bool ramp = var_order == 1 && du_min && du_max && u_prev;
     if (!x0 || (var_order == 2 && !x0_pre)) return FMPC_E_DIM;   // fast_mpc_eq_const.m:27-30
-    fmpc_handle h = nullptr;
-    int rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max,
-                         u_min, u_max, xf, device);
-    if (rc != FMPC_OK) return rc;
+    if (n <= 0 || m <= 0 || T <= 0 || (var_order != 1 && var_order != 2)) return FMPC_E_DIM;
+    if (!A1 || !B || (var_order == 2 && !A2)) return FMPC_E_NULL;
+    if (!Q || !R || !Qf || !x_min || !x_max || !u_min || !u_max) return FMPC_E_NULL;
+    std::lock_guard<std::mutex> lk(once_mu);                  // (also keeps an entry alive while it is in use)
+    std::vector<double> key;
+    key.reserve((size_t)2 * n * n + (size_t)n * m + (size_t)m * m + 8 * (size_t)(n + m) + 32);
+    const double dims[5] = {(double)n, (double)m, (double)T, (double)var_order, (double)device};
+    once_key_push(key, dims, 5);
+    const size_t nn = (size_t)n * n;
+    once_key_push(key, A1, nn); once_key_push(key, var_order == 2 ? A2 : nullptr, nn); once_key_push(key, B, (size_t)n * m);
+    once_key_push(key, Q, nn); once_key_push(key, R, (size_t)m * m); once_key_push(key, Qf, nn);
+    once_key_push(key, q, n); once_key_push(key, r, m); once_key_push(key, qf, n);
+    once_key_push(key, x_min, n); once_key_push(key, x_max, n); once_key_push(key, u_min, m); once_key_push(key, u_max, m);
+    once_key_push(key, xf, n);
+    OnceEntry* ent = nullptr;
+    for (OnceEntry& e : once_cache)
+        if (e.key.size() == key.size() && memcmp(e.key.data(), key.data(), key.size() * sizeof(double)) == 0) { ent = &e; break; }
+    int rc;
+    if (!ent) {
+        fmpc_handle h = nullptr;
+        rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max, u_min, u_max, xf, device);
+        if (rc != FMPC_OK) return rc;
+        if (once_cache.size() >= ONCE_CAPACITY) {             // evict the least recently used model
+            size_t old = 0;
+            for (size_t i = 1; i < once_cache.size(); ++i) if (once_cache[i].stamp < once_cache[old].stamp) old = i;
+            fmpc_destroy(once_cache[old].h);
+            once_cache.erase(once_cache.begin() + old);
+        }
+        once_cache.push_back(OnceEntry{std::move(key), h, {}, 0});
+        ent = &once_cache.back();
+    }
+    ent->stamp = ++once_clock;
     int st = 0;
     if (ramp) {
-        rc = fmpc_set_ramp(h, du_min, du_max);
-        if (rc == FMPC_OK) rc = fmpc_solve_ramp(h, 1, x0, x0_pre, w, u_prev, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+        // (the README shifts du_min/du_max by u_prev at every step, README.md:543-544: the bounds are per-call data)
+        std::vector<double> rb(du_min, du_min + m);
+        rb.insert(rb.end(), du_max, du_max + m);
+        rc = FMPC_OK;
+        if (rb != ent->ramp) { rc = fmpc_set_ramp(ent->h, du_min, du_max); if (rc == FMPC_OK) ent->ramp = rb; }
+        if (rc == FMPC_OK) rc = fmpc_solve_ramp(ent->h, 1, x0, x0_pre, w, u_prev, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
     } else {
-        rc = fmpc_solve(h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
+        rc = fmpc_solve(ent->h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
     }
-    fmpc_destroy(h);
     return rc;
 }

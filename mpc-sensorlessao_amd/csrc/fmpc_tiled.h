@@ -1,0 +1,90 @@
+// Shared between the tiled Newton kernel (fmpc_kernel_tiled.hip) and the host code that builds its constants
+// (fmpc_api.hip).  Internal to the library.
+//
+// The tiled kernel is the per-problem-factor path for any n: ONE WORKGROUP PER PROBLEM, NW wavefronts, every n x n
+// block of the Schur complement handled as NB x NB tiles of 16 x 16 (n_pad = 16 NB >= n + 1: column n of a stage's
+// blocks carries the right-hand side, so the forward substitution rides along in the matrix products).  It is
+// templated on the arithmetic type of the factorisation: double (parity path) or float ("fp32 mixed precision":
+// fp32 factor and substitutions, all residuals, the line search and the iterate in fp64).
+#pragma once
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+#include "fmpc_device.h"
+
+#define FT_TILE 256                      // elements of a 16 x 16 tile, row-major, no padding
+#define FT_MAX_NB 5                      // n <= 79
+#define FT_WLD 17                        // leading dimension of the transposed inverse diagonal factor in LDS
+
+// tiles of one stage in the factor stream (HBM workspace), in elements of FT_TILE:
+//   [0, NB)                  RI(kb)   = R(kb,kb)^-1 (upper triangular), what the backward sweep needs of the diagonal
+//   NB + I NB + J            R(I,J), I < J: the off-diagonal tiles of R_i = L_i'
+//   NB + NB^2 + I NB + J     U1(I,J)  = U_{i,i+1}
+//   NB + 2 NB^2 + I NB + J   U2(I,J)  = U_{i,i+2}
+__host__ __device__ static inline int ft_stage_tiles(int NB) { return NB + 3 * NB * NB; }
+
+struct FtModel {
+    int NB;                 // 16-blocks per stage
+    int mb;                 // 16-blocks covering m
+    int cn, nl;             // tile column / local column of the rhs column: n / 16, n % 16
+    int nblk;               // unique constant blocks; block id nblk is an all-zero block
+    const void* yimg;       // [nblk + 1][NB][NB][256] REAL: constant Y blocks as tiles, zero padded
+    const void* btimg;      // [mb][NB][256] REAL: tile (kb, J) element [c % 16][r % 16] = B[r = 16 J + ..][c = 16 kb + ..]
+    const int* iD;          // per block row: block id of the constant part of Y_ii
+    const int* i1;          //                of Y_{i,i+1}   (zero block if none)
+    const int* i2;          //                of Y_{i,i+2}   (zero block if none)
+    const double* Bm;       // B row-major n x m (Bm[r*m + c]): coalesced B' v products
+};
+
+// Per-workgroup scratch in HBM.  Vectors in doubles, then the factor stream in REAL.
+struct FtWs {
+    size_t b, nu, hess, winv, rdu, rdx, phx, rp, y, dnu, fac, total;   // offsets in doubles
+};
+__host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb, int NB, int real_bytes) {
+    FtWs L; size_t o = 0;
+    const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
+    auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 1) & ~(size_t)1; return r; };
+    L.b = take(nbn); L.nu = take(nbn); L.hess = take(Tm); L.winv = take(Tm); L.rdu = take(Tm);
+    L.rdx = take(Tn); L.phx = take(Tn); L.rp = take(nbn); L.y = take(nbn); L.dnu = take(nbn);
+    o = (o + 31) & ~(size_t)31;
+    L.fac = o;
+    o += ((size_t)nb * ft_stage_tiles(NB) * FT_TILE * real_bytes + 7) / 8;
+    L.total = (o + 31) & ~(size_t)31;
+    return L;
+}
+
+// LDS map in bytes
+struct FtLds { size_t bt, slot, lt, wt, wl, ysh, xv, part, red, flag, total; };
+__host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes) {
+    FtLds L; size_t o = 0;
+    const size_t tile = (size_t)FT_TILE * real_bytes;
+    L.bt = o;   o += (size_t)mb * NB * tile;
+    L.slot = o; o += 3 * (size_t)NB * NB * tile;
+    L.lt = o;   o += (size_t)(NB * (NB + 1) / 2) * tile;
+    L.wt = o;   o += (size_t)16 * FT_WLD * real_bytes;
+    L.wl = o;   o += (size_t)mb * 16 * real_bytes;
+    L.ysh = o;  o += 16 * real_bytes;
+    L.xv = o;   o += 3 * (size_t)16 * NB * real_bytes;
+    L.part = o; o += (size_t)(NW / 4 > 0 ? NW / 4 : 1) * 16 * real_bytes;
+    o = (o + 15) & ~(size_t)15;
+    L.red = o;  o += 16 * sizeof(double);
+    L.flag = o; o += 16;
+    L.total = (o + 15) & ~(size_t)15;
+    return L;
+}
+
+struct FtParams {
+    FmpcDevModel M;
+    FtModel V;
+    int batch;
+    const double* x0; const double* x0p; const double* w; const double* zinit; const double* nu0;
+    int max_iter; double kbar;
+    double* zout; double* nuout; int* status; int* iters; double* step; int step_ld;
+    double* ws; size_t ws_stride;
+    double* u0out;          // nullable: first move of every problem (fmpc_solve_u0_device)
+};
+
+// supported (type, NB) pairs
+bool fmpc_tiled_supports(int n, int m, int is_float, int* NB_out, int* NW_out);
+size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float);
+hipError_t fmpc_tiled_prepare(int NB, int NW, int is_float, size_t lds_bytes);
+hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream);

@@ -93,6 +93,13 @@ class FastMPCHandle:
         if rc != _lib.FMPC_OK:
             raise FastMPCError(rc, "fmpc_set_ramp")
 
+    def set_precision(self, mode):
+        """fmpc_set_precision: 'f64' or 'f32' (fp32 factor + fp64 residuals, BASELINE configs[4])."""
+        code = {"f64": _lib.FMPC_PREC_F64, "f32": _lib.FMPC_PREC_F32_MIXED}.get(mode, mode)
+        rc = self._lib.fmpc_set_precision(self._h, int(code))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_set_precision")
+
     def solve(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
               return_info=False, check=True, u_prev=None):
         """One `inf_newton_solver` per problem.  x0: (batch, n) or (n,).  Returns z (batch, N_z)

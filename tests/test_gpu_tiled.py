@@ -1,0 +1,166 @@
+"""Tiled kernel (fmpc_kernel_tiled.hip: workgroup per problem, 16 x 16 tiles on the matrix cores) through the C ABI
+vs the structured oracle on the same seeded inputs.
+  fp64 factor:  1e-9 relative on z (the parity bar of every fp64 path), iteration counts, status, line-search steps equal.
+  fp32 factor + fp64 residuals (BASELINE configs[4], "fp32 mixed precision"): 1e-4 relative on z."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import canon_steps, handle_from_model, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL64 = 1e-9
+TOL32 = 1e-4
+
+
+@pytest.fixture()
+def tiled_env():
+    old = os.environ.get("FMPC_TILED")
+    os.environ["FMPC_TILED"] = "1"          # read by fmpc_create: every solve of the handle takes the tiled kernel
+    yield
+    if old is None:
+        os.environ.pop("FMPC_TILED", None)
+    else:
+        os.environ["FMPC_TILED"] = old
+
+
+def _solve(pkg, model, data, nw, k, z_init=None, prec=None):
+    h = handle_from_model(pkg, model)
+    if prec is not None:
+        h.set_precision(prec)
+    z, info = h.solve(data["x0"], data.get("x0_pre"), data.get("w"), z_init=z_init, nu0=data.get("nu0"),
+                      n_newton=nw, k=k, return_info=True, check=False)
+    path, _ = h.last_dispatch()
+    h.close()
+    return z, info, path
+
+
+def _compare64(pkg, model, data, nw, k, z_init=None):
+    z, info, path = _solve(pkg, model, data, nw, k, z_init)
+    assert path == pkg._lib.FMPC_PATH_TILED
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, k, z_init=z_init)
+    B = data["x0"].shape[0]
+    assert np.array_equal(info["status"], sto), (info["status"], sto)
+    assert np.array_equal(info["iters"], ito), (info["iters"], ito)
+    for p in range(B):
+        assert rel_err(z[p], zo[p]) <= TOL64, (p, rel_err(z[p], zo[p]))
+        assert rel_err(info["nu"][p], nuo[p]) <= 1e-7
+        t = canon_steps(info["step"][p][:ito[p]])
+        assert np.allclose(t, canon_steps(steps[p]), rtol=0, atol=0), (p, t, steps[p])
+    return z, info
+
+
+@pytest.mark.parametrize("n,m,T,xf,var", [(8, 5, 10, False, 2), (8, 5, 10, True, 2), (8, 5, 10, False, 1),
+                                          (16, 7, 6, False, 2), (16, 7, 6, True, 2), (20, 33, 5, False, 2),
+                                          (40, 21, 7, False, 2), (5, 3, 1, False, 2), (5, 3, 2, True, 2)])
+def test_tiled_fp64_demo_sizes(pkg, gpu, tiled_env, n, m, T, xf, var):
+    """NB = 1, 2, 3 tiles per block incl. n a multiple of 16 (the rhs column then has a tile column of its own)."""
+    model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + T, xf=xf, var_order=var, batch=3)
+    _compare64(pkg, model, data, 5, 0.01)
+
+
+@pytest.mark.parametrize("T,nw", [(2, 1), (10, 5), (30, 1), (30, 5)])
+def test_tiled_fp64_ao_config(pkg, gpu, tiled_env, T, nw):
+    model = pkg.synthetic.make_model(27, 144, T)
+    data = pkg.synthetic.make_replay_batch(model, r=1, steps=40)
+    _compare64(pkg, model, data, nw, 1e-2)
+
+
+def test_tiled_fp64_tight_bounds_and_warm_start(pkg, gpu, tiled_env):
+    model = pkg.synthetic.make_model(27, 144, 10)
+    model["u_min"] = -0.05 * np.ones(144); model["u_max"] = 0.05 * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(model, r=2, steps=16)
+    z, info = _compare64(pkg, model, data, 6, 1e-2)
+    assert info["iters"].min() >= 3
+    rng = np.random.default_rng(7)
+    z0 = np.tile(np.concatenate([0.04 * rng.uniform(-1, 1, 144), rng.standard_normal(27)]), (16, 10))
+    _compare64(pkg, model, data, 4, 1e-2, z_init=z0)
+
+
+def test_tiled_fp64_backtracking_and_collapse(pkg, gpu, tiled_env):
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=3, umax=0.3, batch=4)
+    rng = np.random.default_rng(11)
+    z0 = np.tile(np.concatenate([0.25 * rng.uniform(-1, 1, 5), rng.standard_normal(8)]), (4, 10))
+    _compare64(pkg, model, data, 8, 10.0, z_init=z0)
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=9, umax=0.2, batch=2)
+    z, info, _ = _solve(pkg, model, data, 3, 100.0)
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, 3, 100.0)
+    assert np.array_equal(info["status"], sto)
+    for p in range(2):
+        assert rel_err(z[p], zo[p]) <= TOL64
+
+
+def test_tiled_fp64_batch_beyond_grid_is_position_independent(pkg, gpu, tiled_env):
+    """More problems than resident workgroups (grid-stride loop), bitwise reproducible and slot independent."""
+    model = pkg.synthetic.make_model(27, 144, 4)
+    data = pkg.synthetic.make_replay_batch(model, r=3, steps=700)
+    z1, _, _ = _solve(pkg, model, data, 2, 1e-2)
+    z2, _, _ = _solve(pkg, model, data, 2, 1e-2)
+    assert np.array_equal(z1, z2)
+    perm = np.random.default_rng(0).permutation(700)
+    dperm = {k: (None if v is None else v[perm]) for k, v in data.items()}
+    z3, _, _ = _solve(pkg, model, dperm, 2, 1e-2)
+    assert np.array_equal(z3, z1[perm])
+    zo, *_ = oracle_batch(model, {k: (None if v is None else v[:5]) for k, v in data.items()}, 2, 1e-2)
+    for p in range(5):
+        assert rel_err(z1[p], zo[p]) <= TOL64
+
+
+# ------------------------------------------------------------------ fp32 factor + fp64 residuals
+def _compare32(pkg, model, data, nw, k, z_init=None, expect_path=True):
+    z, info, path = _solve(pkg, model, data, nw, k, z_init, prec="f32")
+    assert path == pkg._lib.FMPC_PATH_TILED_F32
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, k, z_init=z_init)
+    B = data["x0"].shape[0]
+    assert np.array_equal(info["status"], sto)
+    assert np.all(info["iters"] >= ito), (info["iters"], ito)
+    errs = [rel_err(z[p], zo[p]) for p in range(B)]
+    assert max(errs) <= TOL32, errs
+    return max(errs)
+
+
+@pytest.mark.parametrize("nw", [1, 3])
+def test_tiled_fp32_ao_config(pkg, gpu, nw):
+    model = pkg.synthetic.make_model(27, 144, 30)
+    data = pkg.synthetic.make_replay_batch(model, r=1, steps=24)
+    err = _compare32(pkg, model, data, nw, 1e-2)
+    print(f"fp32 factor, n=27 T=30 nw={nw}: max rel err on z {err:.2e}")
+
+
+@pytest.mark.parametrize("nw", [1, 3])
+def test_tiled_fp32_config4_n65_T60(pkg, gpu, nw):
+    """BASELINE configs[4]: VAR(2), n = 65 (radial order 10), T = 60, fp32 mixed precision."""
+    model = pkg.synthetic.make_model(65, 144, 60)
+    data = pkg.synthetic.make_replay_batch(model, r=4, steps=6)
+    h = handle_from_model(pkg, model)
+    z, info = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=1e-2, return_info=True)
+    path, _ = h.last_dispatch()
+    h.close()
+    assert path == pkg._lib.FMPC_PATH_TILED_F32          # the only path at n = 65: default precision there
+    zo, nuo, ito, sto, _ = oracle_batch(model, data, nw, 1e-2)
+    assert np.array_equal(info["status"], sto) and np.all(info["iters"] >= ito), (info["iters"], ito)
+    errs = [rel_err(z[p], zo[p]) for p in range(6)]
+    print(f"fp32 factor, n=65 T=60 nw={nw}: max rel err on z {max(errs):.2e}")
+    assert max(errs) <= TOL32, errs
+
+
+def test_tiled_fp32_tight_bounds_n65(pkg, gpu):
+    """Active barrier, several real Newton steps: the fp64 residuals keep the fp32 solves on the oracle's trajectory."""
+    model = pkg.synthetic.make_model(65, 144, 12)
+    model["u_min"] = -0.05 * np.ones(144); model["u_max"] = 0.05 * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(model, r=5, steps=4)
+    _compare32(pkg, model, data, 5, 1e-2)
+
+
+def test_precision_switch_errors(pkg, gpu):
+    model = pkg.synthetic.make_model(65, 144, 4)
+    h = handle_from_model(pkg, model)
+    with pytest.raises(pkg.FastMPCError) as e:
+        h.set_precision("f64")                            # no fp64 kernel at n = 65
+    assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    h.close()
+    model = pkg.synthetic.make_model(80, 16, 4)
+    with pytest.raises(pkg.FastMPCError) as e:
+        handle_from_model(pkg, model)
+    assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
