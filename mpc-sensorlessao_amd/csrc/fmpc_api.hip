@@ -189,7 +189,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // (n <= 47), else the tiled kernel with an fp32 factor (n <= 79: "fp32 mixed precision", BASELINE configs[4])
     size_t lds = fmpc_generic_lds_bytes(n, m);
     const bool generic_ok = n <= 64 && lds <= FMPC_LDS_LIMIT;
-    const bool tiled64 = fmpc_tiled_supports(n, m, 0, nullptr, nullptr), tiled32 = fmpc_tiled_supports(n, m, 1, nullptr, nullptr);
+    const int nb_ = T + (xf ? 1 : 0);
+    const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr);
     if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
     if (!generic_ok) lds = 0;
 
@@ -888,7 +889,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     fmpc_handle_s::Tiled& X = h->tl[t];
     const int n = h->n, m = h->m, nb = h->nb, nn = n * n;
     int NB = 0, NW = 0;
-    if (!fmpc_tiled_supports(n, m, t, &NB, &NW)) return FMPC_E_UNSUPPORTED;
+    if (!fmpc_tiled_supports(n, m, nb, t, &NB, &NW)) return FMPC_E_UNSUPPORTED;
     const int mb = (m + 15) / 16, NQ = NB * NB;
     const int nblk = (int)(h->hm_blocks.size() / nn);
     std::vector<R> img((size_t)(nblk + 1) * NQ * FT_TILE + (size_t)mb * NB * FT_TILE, (R)0);
@@ -911,7 +912,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
         hipMemcpy(X.ipool, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(X.bm, h->hm_b.data(), h->hm_b.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     X.NB = NB; X.NW = NW;
-    X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t);
+    X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t, nb);
     if (fmpc_tiled_prepare(NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
     X.V.NB = NB; X.V.mb = mb; X.V.cn = n / 16; X.V.nl = n % 16; X.V.nblk = nblk;
     X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
@@ -955,8 +956,8 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
 extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
     if (!h) return FMPC_E_NULL;
     if (mode != FMPC_PREC_F64 && mode != FMPC_PREC_F32_MIXED) return FMPC_E_DIM;
-    if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, 1, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
-    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, 0, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
+    if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, h->nb, 1, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
+    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(h->mu);
     h->prec = mode;
     return FMPC_OK;

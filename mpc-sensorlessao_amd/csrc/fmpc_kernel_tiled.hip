@@ -28,6 +28,20 @@
 
 #define FT_MAX_HALVINGS 64
 
+// diagnostic build (make timing): per-phase cycle counters of workgroup 0, thread 0 (scripts/tiled_phases.py)
+#ifdef FW_TIMING
+__device__ unsigned long long ft_timing[16];
+extern "C" int fmpc_debug_tiled_timing(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(ft_timing), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_timing), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#define FT_T0() unsigned long long _t0 = __builtin_readcyclecounter(), _t1
+#define FT_TICK(k) do { _t1 = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) ft_timing[k] += _t1 - _t0; _t0 = _t1; } while (0)
+#else
+#define FT_T0()
+#define FT_TICK(k)
+#endif
+
 typedef double ft_d4 __attribute__((ext_vector_type(4)));
 typedef float ft_f4 __attribute__((ext_vector_type(4)));
 
@@ -115,6 +129,16 @@ template <int NW> __device__ __forceinline__ double ft_block_sum(double v, doubl
     return s;
 }
 
+// One 16 x 16 output tile of a stage-batched product of the residual phases, always on the fp64 matrix cores:
+// acc += X'Z over k = 0..K-1 (K a multiple of 4).  xf(k) is X[k][a], zf(k) is Z[k][b] for this lane's a = b = lane & 15;
+// the lane group g = lane >> 4 takes k = k0 + g.  The T horizon stages are the row dimension of the output.
+template <class XF, class ZF>
+__device__ __forceinline__ void ft_vec_gemm(ft_d4& acc, int K, int g, XF xf, ZF zf) {
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf(k0 + g), zf(k0 + g), acc, 0, 0, 0);
+}
+
 // acc -= X' Z for two row-major 16 x 16 tiles in LDS (64 consecutive elements per operand read)
 template <typename R> __device__ __forceinline__ void ft_xtz_sub(typename FtT<R>::v4& acc, const R* X, const R* Z, int lane) {
 #pragma unroll
@@ -175,7 +199,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     const bool var2 = M.var2 != 0;
     const int mb = V.mb, cn = V.cn, nl = V.nl;
 
-    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R));
+    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb);
     R* sBT = (R*)(smem + LL.bt);
     R* sSLOT = (R*)(smem + LL.slot);
     R* sLT = (R*)(smem + LL.lt);
@@ -186,6 +210,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     R* sPART = (R*)(smem + LL.part);
     double* red = (double*)(smem + LL.red);
     int* sflag = (int*)(smem + LL.flag);
+    // residual phases: nu / d_nu as [stage][state] (leading dimension NP + 1: conflict-free transposed reads) in the
+    // space of the U slots, which only the factor phase uses
+    double* sNU = (double*)(smem + LL.slot);
+    constexpr int LDN = 16 * NB + 1;
+    const int TA = (nb + 15) / 16, NUROWS = 16 * TA + 2;
 
     {   // B' tiles stay in LDS for the whole launch
         const R* src = (const R*)V.btimg;
@@ -224,6 +253,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
         const double* x0v = P.x0 + (size_t)p * n;
         const double* x0pv = P.x0p ? P.x0p + (size_t)p * n : nullptr;
         __syncthreads();
+        FT_T0();
         // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
         for (int idx = tid; idx < Nz; idx += NT) {
             const int e = idx % s;
@@ -248,64 +278,97 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
         __syncthreads();
 
         int st = FMPC_OK, nsteps = 0;
+        FT_TICK(0);
         for (int it = 0; it < P.max_iter; ++it) {
-            // ================= P1: residuals
+            // ================= P1: residuals.  Every product is a GEMM with the horizon stages as one dimension
+            // (out[stage][entry] = sum_k X[k][stage] Z[k][entry]) on the fp64 matrix cores; Z (B, A1, A2 and transposes)
+            // is read from L2 with 128-byte rows, the epilogues read and write along the entries of a stage.
             double acc_d = 0.0, acc_p = 0.0;
             int bad = 0;
-            for (int idx = tid; idx < T * m; idx += NT) {
-                const int j = idx / m, q = idx - j * m;
-                const double u = zp[j * s + q];
-                const double dp = ft_rcp(M.umax[q] - u), dm = ft_rcp(u - M.umin[q]);
-                const double hs = P.kbar * (dp * dp + dm * dm);
-                const double rt = M.R2[q] + hs;
-                if (!(rt > 0.0) || isinf(rt)) bad = 1;
-                double dot = 0.0;
-                const double* nj = nu + j * n;
-                for (int r = 0; r < n; ++r) dot += V.Bm[(size_t)r * m + q] * nj[r];
-                const double rd = M.R2[q] * u + M.rl[q] + P.kbar * (dp - dm) - dot;
-                hess[idx] = hs;
-                winv[idx] = ft_rcp(rt);
-                rdu[idx] = rd;
-                acc_d += rd * rd;
+            for (int idx = tid; idx < NUROWS * LDN; idx += NT) {       // nu as [stage][state] in LDS, zero padded
+                const int j = idx / LDN, r = idx - j * LDN;
+                sNU[idx] = (j < nb && r < n) ? nu[j * n + r] : 0.0;
             }
-            for (int idx = tid; idx < T * n; idx += NT) {
-                const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
-                const double x = zp[jj * s + m + r];
-                const double q2 = j == T ? M.Qf2[r] : M.Q2[r];
-                double v = q2 * x + (j == T ? M.qfl[r] : M.ql[r]) + nu[jj * n + r];
-                if (j < T) {
-                    const double* nj = nu + j * n;
-                    for (int q = 0; q < n; ++q) v -= M.A1[q * n + r] * nj[q];
-                }
-                if (var2 && j + 1 < T) {
-                    const double* nj = nu + (j + 1) * n;
-                    for (int q = 0; q < n; ++q) v -= M.A2[q * n + r] * nj[q];
-                }
-                if (j == T && M.has_xf) v += nu[T * n + r];
-                rdx[idx] = v;
-                phx[idx] = v * ft_rcp(q2);                            // Phi^-1 r_d on x_j
-                acc_d += v * v;
-            }
-            for (int idx = tid; idx < nbn; idx += NT) {
-                const int i = idx / n, r = idx - i * n;
-                double v;
-                if (i < T) {
-                    v = zp[i * s + m + r] - b[idx];
-                    const double* ui = zp + i * s;
-                    for (int q = 0; q < m; ++q) v -= M.Bt[q * n + r] * ui[q];
-                    if (i >= 1) {
-                        const double* xi = zp + (i - 1) * s + m;
-                        for (int q = 0; q < n; ++q) v -= M.A1t[q * n + r] * xi[q];
+            __syncthreads();
+            {
+                const int nC = NB * TA, nB_ = NB * TA, nA = mb * TA;   // items: r_p tiles, r_d[x] tiles, r_d[u] tiles (heaviest first)
+                for (int item = wv; item < nC + nB_ + nA; item += NW) {
+                    ft_d4 acc = {0, 0, 0, 0};
+                    if (item < nC) {
+                        // ---- r_p,i = x_{i+1} - b_i - B u_i - A1 x_i - A2 x_{i-1}      (terminal row: x_T - xf)
+                        const int Jr = item / TA, A = item - Jr * TA;
+                        const int i = 16 * A + c, r = 16 * Jr + c;      // as A-operand lane: stage i; as B-operand lane: state r
+                        const bool rok = r < n;
+                        ft_vec_gemm(acc, 16 * mb, g,
+                                    [&](int k) { return (i < T && k < m) ? zp[i * s + k] : 0.0; },
+                                    [&](int k) { return (rok && k < m) ? M.Bt[k * n + r] : 0.0; });
+                        ft_vec_gemm(acc, NP, g,
+                                    [&](int k) { return (i >= 1 && i < T && k < n) ? zp[(i - 1) * s + m + k] : 0.0; },
+                                    [&](int k) { return (rok && k < n) ? M.A1t[k * n + r] : 0.0; });
+                        if (var2)
+                            ft_vec_gemm(acc, NP, g,
+                                        [&](int k) { return (i >= 2 && i < T && k < n) ? zp[(i - 2) * s + m + k] : 0.0; },
+                                        [&](int k) { return (rok && k < n) ? M.A2t[k * n + r] : 0.0; });
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int io = 16 * A + g + 4 * rr;
+                            if (io < nb && rok) {
+                                const double v = (io < T ? zp[io * s + m + r] - acc[rr] : zp[(T - 1) * s + m + r]) - b[io * n + r];
+                                rp[io * n + r] = v;
+                                acc_p += v * v;
+                            }
+                        }
+                    } else if (item < nC + nB_) {
+                        // ---- r_d on x_j (j = jj + 1): 2Q x + q + nu_{j-1} - A1' nu_j - A2' nu_{j+1}  (+ nu_T with xf)
+                        const int it2 = item - nC, Jr = it2 / TA, A = it2 - Jr * TA;
+                        const int jj = 16 * A + c, r = 16 * Jr + c;
+                        const bool rok = r < n;
+                        ft_vec_gemm(acc, NP, g,
+                                    [&](int k) { return jj + 1 < T ? sNU[(jj + 1) * LDN + k] : 0.0; },
+                                    [&](int k) { return (rok && k < n) ? M.A1[k * n + r] : 0.0; });
+                        if (var2)
+                            ft_vec_gemm(acc, NP, g,
+                                        [&](int k) { return jj + 2 < T ? sNU[(jj + 2) * LDN + k] : 0.0; },
+                                        [&](int k) { return (rok && k < n) ? M.A2[k * n + r] : 0.0; });
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int jo = 16 * A + g + 4 * rr;
+                            if (jo < T && rok) {
+                                const bool last = jo + 1 == T;
+                                const double q2 = last ? M.Qf2[r] : M.Q2[r];
+                                double v = q2 * zp[jo * s + m + r] + (last ? M.qfl[r] : M.ql[r]) + sNU[jo * LDN + r] - acc[rr];
+                                if (last && M.has_xf) v += sNU[T * LDN + r];
+                                rdx[jo * n + r] = v;
+                                phx[jo * n + r] = v * ft_rcp(q2);              // Phi^-1 r_d on x_j
+                                acc_d += v * v;
+                            }
+                        }
+                    } else {
+                        // ---- r_d on u_j: 2R u + r + k P'd - B' nu_j ; barrier Hessian and Phi^-1 on the way
+                        const int it3 = item - nC - nB_, J = it3 / TA, A = it3 - J * TA;
+                        const int j = 16 * A + c, q = 16 * J + c;
+                        const bool qok = q < m;
+                        ft_vec_gemm(acc, NP, g,
+                                    [&](int k) { return sNU[j * LDN + k]; },
+                                    [&](int k) { return (qok && k < n) ? V.Bm[(size_t)k * m + q] : 0.0; });
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int jo = 16 * A + g + 4 * rr;
+                            if (jo < T && qok) {
+                                const double u = zp[jo * s + q];
+                                const double dp = ft_rcp(M.umax[q] - u), dm = ft_rcp(u - M.umin[q]);
+                                const double hs = P.kbar * (dp * dp + dm * dm);
+                                const double rt = M.R2[q] + hs;
+                                if (!(rt > 0.0) || isinf(rt)) bad = 1;
+                                const double rd = M.R2[q] * u + M.rl[q] + P.kbar * (dp - dm) - acc[rr];
+                                hess[jo * m + q] = hs;
+                                winv[jo * m + q] = ft_rcp(rt);
+                                rdu[jo * m + q] = rd;
+                                acc_d += rd * rd;
+                            }
+                        }
                     }
-                    if (var2 && i >= 2) {
-                        const double* xi = zp + (i - 2) * s + m;
-                        for (int q = 0; q < n; ++q) v -= M.A2t[q * n + r] * xi[q];
-                    }
-                } else {
-                    v = zp[(T - 1) * s + m + r] - b[idx];
                 }
-                rp[idx] = v;
-                acc_p += v * v;
             }
             const double rp2 = ft_block_sum<NW>(acc_p, red);
             const double rho2 = ft_block_sum<NW>(acc_d, red) + rp2;
@@ -313,33 +376,39 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
             if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
+            FT_TICK(1);
 
             // ================= P2: rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into yv)
-            for (int idx = tid; idx < nbn; idx += NT) {
-                const int i = idx / n, r = idx - i * n;
-                double cv;
-                if (i < T) {
-                    cv = phx[i * n + r];
-                    const double* ru = rdu + i * m;
-                    const double* wi = winv + i * m;
-                    for (int q = 0; q < m; ++q) cv -= M.Bt[q * n + r] * (ru[q] * wi[q]);
-                    if (i >= 1) {
-                        const double* px = phx + (i - 1) * n;
-                        for (int q = 0; q < n; ++q) cv -= M.A1t[q * n + r] * px[q];
+            for (int item = wv; item < NB * TA; item += NW) {
+                const int Jr = item / TA, A = item - Jr * TA;
+                const int i = 16 * A + c, r = 16 * Jr + c;
+                const bool rok = r < n;
+                ft_d4 acc = {0, 0, 0, 0};
+                ft_vec_gemm(acc, 16 * mb, g,
+                            [&](int k) { return (i < T && k < m) ? rdu[i * m + k] * winv[i * m + k] : 0.0; },
+                            [&](int k) { return (rok && k < m) ? M.Bt[k * n + r] : 0.0; });
+                ft_vec_gemm(acc, NP, g,
+                            [&](int k) { return (i >= 1 && i < T && k < n) ? phx[(i - 1) * n + k] : 0.0; },
+                            [&](int k) { return (rok && k < n) ? M.A1t[k * n + r] : 0.0; });
+                if (var2)
+                    ft_vec_gemm(acc, NP, g,
+                                [&](int k) { return (i >= 2 && i < T && k < n) ? phx[(i - 2) * n + k] : 0.0; },
+                                [&](int k) { return (rok && k < n) ? M.A2t[k * n + r] : 0.0; });
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int io = 16 * A + g + 4 * rr;
+                    if (io < nb && rok) {
+                        const double cv = io < T ? phx[io * n + r] - acc[rr] : phx[(T - 1) * n + r];
+                        yv[io * n + r] = rp[io * n + r] - cv;
                     }
-                    if (var2 && i >= 2) {
-                        const double* px = phx + (i - 2) * n;
-                        for (int q = 0; q < n; ++q) cv -= M.A2t[q * n + r] * px[q];
-                    }
-                } else {
-                    cv = phx[(T - 1) * n + r];
                 }
-                yv[idx] = rp[idx] - cv;
             }
+            __syncthreads();                                           // (the staging area of nu is the U slots' space)
             // zero the three U slots: stages 0 and 1 then need no special cases
             for (int i = tid; i < 3 * NQ * FT_TILE; i += NT) sSLOT[i] = (R)0;
             if (tid == 0) sflag[0] = 0;
             __syncthreads();
+            FT_TICK(2);
 
             // ================= P3: factor + forward sweep
             int ua = 0, ub = 1, uc = 2;                               // roles of the three LDS slots
@@ -412,6 +481,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     }
                 }
                 ft_lds_barrier();                                      // Ua, Uc are dead from here: their slots take U1_i, U2_i
+                FT_TICK(3);
                 R* U1N = UA; R* U2N = UC;
                 // ---------------- phase B: the 16-row blocks of the stage, in order
                 for (int kb = 0; kb < NB; ++kb) {
@@ -464,6 +534,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         }
                     }
                     ft_lds_barrier();
+                    FT_TICK(4);
                     // (3) scale the tiles of the row: Rwide(kb, .) = W P(kb, .)
                     R wop[4];
 #pragma unroll
@@ -522,6 +593,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         }
                     }
                     ft_lds_barrier();
+                    FT_TICK(5);
                     if (sflag[0]) { fail = true; break; }              // uniform: read after the barrier
                 }
                 if (fail) break;
@@ -530,6 +602,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             }
             if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
             __syncthreads();                                           // the factor stream and y are in HBM (same workgroup reads them)
+            FT_TICK(6);
 
             // ================= P4: backward sweep, d_nu_i = R_i^-1 (y_i - U1_i d_nu_{i+1} - U2_i d_nu_{i+2})
             {
@@ -575,34 +648,61 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 }
             }
             __syncthreads();
+            FT_TICK(7);
 
-            // ================= P5: d_z, line-search scalars, update
+            // ================= P5: d_z, line-search scalars, update (the same stage-batched GEMMs with d_nu)
             double be = 0.0, e2 = 0.0;
-            for (int idx = tid; idx < T * m; idx += NT) {
-                const int j = idx / m, q = idx - j * m;
-                double dot = 0.0;
-                const double* dj = dnu + j * n;
-                for (int r = 0; r < n; ++r) dot += V.Bm[(size_t)r * m + q] * dj[r];
-                const double rd = rdu[idx];
-                const double du = (dot - rd) * winv[idx];
-                const double e = hess[idx] * du;        // k P'DP dz
-                be += rd * e;
-                e2 += e * e;
-                rdu[idx] = du;                          // reuse as d_u
+            for (int idx = tid; idx < NUROWS * LDN; idx += NT) {
+                const int j = idx / LDN, r = idx - j * LDN;
+                sNU[idx] = (j < nb && r < n) ? dnu[j * n + r] : 0.0;
             }
-            for (int idx = tid; idx < T * n; idx += NT) {
-                const int jj = idx / n, r = idx - jj * n, j = jj + 1;
-                double v = -rdx[idx] - dnu[jj * n + r];
-                if (j < T) {
-                    const double* dj = dnu + j * n;
-                    for (int q = 0; q < n; ++q) v += M.A1[q * n + r] * dj[q];
+            __syncthreads();
+            for (int item = wv; item < NB * TA + mb * TA; item += NW) {
+                ft_d4 acc = {0, 0, 0, 0};
+                if (item < NB * TA) {
+                    // ---- d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1' d_nu_j + A2' d_nu_{j+1}  [- d_nu_T])
+                    const int Jr = item / TA, A = item - Jr * TA;
+                    const int jj = 16 * A + c, r = 16 * Jr + c;
+                    const bool rok = r < n;
+                    ft_vec_gemm(acc, NP, g,
+                                [&](int k) { return jj + 1 < T ? sNU[(jj + 1) * LDN + k] : 0.0; },
+                                [&](int k) { return (rok && k < n) ? M.A1[k * n + r] : 0.0; });
+                    if (var2)
+                        ft_vec_gemm(acc, NP, g,
+                                    [&](int k) { return jj + 2 < T ? sNU[(jj + 2) * LDN + k] : 0.0; },
+                                    [&](int k) { return (rok && k < n) ? M.A2[k * n + r] : 0.0; });
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int jo = 16 * A + g + 4 * rr;
+                        if (jo < T && rok) {
+                            const bool last = jo + 1 == T;
+                            double v = -rdx[jo * n + r] - sNU[jo * LDN + r] + acc[rr];
+                            if (last && M.has_xf) v -= sNU[T * LDN + r];
+                            rdx[jo * n + r] = v * ft_rcp(last ? M.Qf2[r] : M.Q2[r]);   // reuse as d_x
+                        }
+                    }
+                } else {
+                    // ---- d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) ; e = k P'DP d_z for the line search
+                    const int it3 = item - NB * TA, J = it3 / TA, A = it3 - J * TA;
+                    const int j = 16 * A + c, q = 16 * J + c;
+                    const bool qok = q < m;
+                    ft_vec_gemm(acc, NP, g,
+                                [&](int k) { return sNU[j * LDN + k]; },
+                                [&](int k) { return (qok && k < n) ? V.Bm[(size_t)k * m + q] : 0.0; });
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int jo = 16 * A + g + 4 * rr;
+                        if (jo < T && qok) {
+                            const int idx = jo * m + q;
+                            const double rd = rdu[idx];
+                            const double du = (acc[rr] - rd) * winv[idx];
+                            const double e = hess[idx] * du;
+                            be += rd * e;
+                            e2 += e * e;
+                            rdu[idx] = du;                              // reuse as d_u
+                        }
+                    }
                 }
-                if (var2 && j + 1 < T) {
-                    const double* dj = dnu + (j + 1) * n;
-                    for (int q = 0; q < n; ++q) v += M.A2[q * n + r] * dj[q];
-                }
-                if (j == T && M.has_xf) v -= dnu[T * n + r];
-                rdx[idx] = v * ft_rcp(j == T ? M.Qf2[r] : M.Q2[r]);   // reuse as d_x
             }
             const double beta_e = ft_block_sum<NW>(be, red);
             const double eps2 = ft_block_sum<NW>(e2, red);
@@ -627,6 +727,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             if (P.step && tid == 0 && it < P.step_ld) P.step[(size_t)p * P.step_ld + it] = t;
             ++nsteps;
             __syncthreads();
+            FT_TICK(8);
         }
         __syncthreads();
         if (P.nuout)
@@ -666,17 +767,17 @@ static hipError_t ft_prepare(size_t lds) {
     }                                                                                          \
     return hipErrorInvalidValue;
 
-bool fmpc_tiled_supports(int n, int m, int is_float, int* NB_out, int* NW_out) {
+bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out) {
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
     if (NB > (is_float ? 5 : 3)) return false;
     const int NW = NB >= 4 ? 8 : 4;
     const int mb = (m + 15) / 16;
-    if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8).total > 160 * 1024) return false;
+    if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total > 160 * 1024) return false;
     if (NB_out) *NB_out = NB;
     if (NW_out) *NW_out = NW;
     return true;
 }
-size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8).total; }
+size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total; }
 hipError_t fmpc_tiled_prepare(int NB, int NW, int is_float, size_t lds_bytes) { FT_DISPATCH(ft_prepare, lds_bytes) }
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream) {
     FT_DISPATCH(ft_launch, P, grid, lds_bytes, stream)

@@ -54,12 +54,17 @@ __host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb,
 
 // LDS map in bytes
 struct FtLds { size_t bt, slot, lt, wt, wl, ysh, xv, part, red, flag, total; };
-__host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes) {
+__host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes, int nb) {
     FtLds L; size_t o = 0;
     const size_t tile = (size_t)FT_TILE * real_bytes;
     L.bt = o;   o += (size_t)mb * NB * tile;
-    L.slot = o; o += 3 * (size_t)NB * NB * tile;
-    L.lt = o;   o += (size_t)(NB * (NB + 1) / 2) * tile;
+    // the U slots + R tiles of the factor phase share their space with the [stage][state] staging of nu / d_nu of the
+    // residual phases: (16 ceil(nb/16) + 2) rows of 16 NB + 1 doubles
+    const size_t fac_bytes = (3 * (size_t)NB * NB + (size_t)(NB * (NB + 1) / 2)) * tile;
+    const size_t nu_bytes = (size_t)(16 * ((nb + 15) / 16) + 2) * (16 * NB + 1) * sizeof(double);
+    L.slot = o; L.lt = o + 3 * (size_t)NB * NB * tile;
+    o += fac_bytes > nu_bytes ? fac_bytes : nu_bytes;
+    o = (o + 15) & ~(size_t)15;
     L.wt = o;   o += (size_t)16 * FT_WLD * real_bytes;
     L.wl = o;   o += (size_t)mb * 16 * real_bytes;
     L.ysh = o;  o += 16 * real_bytes;
@@ -84,7 +89,7 @@ struct FtParams {
 };
 
 // supported (type, NB) pairs
-bool fmpc_tiled_supports(int n, int m, int is_float, int* NB_out, int* NW_out);
-size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float);
+bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out);
+size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb);
 hipError_t fmpc_tiled_prepare(int NB, int NW, int is_float, size_t lds_bytes);
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream);

@@ -1,0 +1,35 @@
+"""Diagnostic: per-phase cycle totals of the tiled kernel (workgroup 0, thread 0); needs `make -C mpc-sensorlessao_amd/csrc timing`.
+  python scripts/tiled_phases.py [n] [T] [batch] [f32]"""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, '.')
+os.environ.setdefault("FMPC_LIB", os.path.abspath("mpc-sensorlessao_amd/lib/libfastmpc_timing.so"))
+os.environ["FMPC_TILED"] = "1"
+import numpy as np, torch
+pkg = importlib.import_module('mpc-sensorlessao_amd')
+lib = pkg.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+f32 = len(sys.argv) > 4 and sys.argv[4] == "f32"
+m = 144
+model = pkg.synthetic.make_model(n, m, T)
+data = pkg.synthetic.make_replay_batch(model, r=0, steps=B)
+h = pkg.FastMPCHandle(model["A1"], model["A2"], model["B"], model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"], model["x_min"], model["x_max"], T)
+if f32 or n > 47:
+    h.set_precision("f32")
+dev = torch.device('cuda:0')
+x0 = torch.from_numpy(data["x0"]).to(dev); x0p = torch.from_numpy(data["x0_pre"]).to(dev); nu0 = torch.from_numpy(data["nu0"]).to(dev)
+out = (C.c_ulonglong * 16)()
+for rep in range(2):
+    lib.fmpc_debug_tiled_timing(out, 1)
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(); h.solve_device(x0, x0p, None, None, nu0, 1, 1e-2); b.record(); torch.cuda.synchronize()
+    lib.fmpc_debug_tiled_timing(out, 0)
+names = ["P0 init", "P1 residuals", "P2 rhs + slot clear", "P3.A stage products", "P3.B products + potrf (to barrier)", "P3.B scale + store",
+         "P3 tail sync", "P4 backward", "P5 dz + update"]
+tot = sum(out[i] for i in range(9)) or 1
+print(f"tiled kernel n={n} T={T} batch={B} {'fp32' if (f32 or n > 47) else 'fp64'}: {a.elapsed_time(b):.3f} ms; cycles of workgroup 0 over its problems "
+      f"(s_memtime units):")
+for i, nm in enumerate(names):
+    print("  %-36s %12d  %5.1f%%" % (nm, out[i], 100.0 * out[i] / tot))
+print("  total %d" % tot)

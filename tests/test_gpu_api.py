@@ -87,6 +87,51 @@ def test_solve_once_reference_signature(pkg, gpu):
     assert it.value == ito[0] and rel_err(z, zo[0]) <= TOL
 
 
+def test_solve_once_caches_the_handle_per_model(pkg, gpu):
+    """The notebook rebuilds the object at every timestep (README.md:548) and the MATLAB shim therefore calls
+    fmpc_solve_once with the full argument set every time: the second call with an unchanged model must reuse the device
+    handle (bit-identical result, no re-allocation / re-factorisation), a changed model must not."""
+    import time
+    lib = pkg.load()
+    lib.fmpc_solve_once_cache_clear()
+    md = pkg.synthetic.make_model(27, 144, 30)
+    d = pkg.synthetic.make_replay_batch(md, r=7, steps=3)
+    F = lambda M: np.asfortranarray(M).ravel(order="K").copy()
+    args = lambda B, k: (27, 144, 30, 2, _p(F(md["Q"])), _p(F(md["R"])), None, _p(F(md["Qf"])), None, None, None,
+                         _p(md["x_min"]), _p(md["x_max"]), _p(md["u_min"]), _p(md["u_max"]), None, None,
+                         _p(d["x0"][k]), _p(d["x0_pre"][k]), _p(np.zeros(144)), _p(F(md["A1"])), _p(F(md["A2"])),
+                         _p(F(B)), None, None, None, _p(d["nu0"][k]), 1, 1e-2, 0)
+
+    def call(B, k):
+        z = np.empty(30 * 171); it = C.c_int()
+        t0 = time.perf_counter()
+        rc = lib.fmpc_solve_once(*args(B, k), _p(z), C.byref(it))
+        return rc, z, time.perf_counter() - t0
+    rc, z1, t_first = call(md["B"], 0)
+    assert rc == 0
+    times = []
+    for _ in range(5):
+        rc, z2, t = call(md["B"], 0)
+        assert rc == 0 and np.array_equal(z1, z2)
+        times.append(t)
+    assert min(times) * 10 <= t_first, (t_first, times)          # no create / upload / factorisation any more
+    zo, *_ = oracle_batch(md, {k: (None if v is None else v[:2]) for k, v in d.items()}, 1, 1e-2)
+    assert rel_err(z1, zo[0]) <= TOL
+    rc, z3, _ = call(md["B"], 1)                                  # same model, next timestep
+    assert rc == 0 and rel_err(z3, zo[1]) <= TOL
+    B2 = md["B"].copy(); B2[3, 5] += 0.01                         # another model: must not hit the cached handle
+    rc, z4, _ = call(B2, 0)
+    md2 = dict(md); md2["B"] = B2
+    zo2, *_ = oracle_batch(md2, {k: (None if v is None else v[:1]) for k, v in d.items()}, 1, 1e-2)
+    assert rc == 0 and rel_err(z4, zo2[0]) <= TOL and not np.array_equal(z4, z1)
+    for i in range(5):                                            # more models than cache slots: eviction keeps working
+        Bi = md["B"].copy(); Bi[0, 0] += 0.001 * (i + 1)
+        assert call(Bi, 0)[0] == 0
+    rc, z5, _ = call(md["B"], 0)
+    assert rc == 0 and np.array_equal(z5, z1)
+    assert lib.fmpc_solve_once_cache_clear() == 0
+
+
 @pytest.mark.parametrize("xf", [False, True])
 def test_fast_mpc2_drivers_match_dense_oracle_drivers(pkg, gpu, xf):
     """Fast_MPC2.m:88-144: every driver, same nu0 sequence on both sides."""
