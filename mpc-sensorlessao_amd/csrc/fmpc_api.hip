@@ -103,9 +103,10 @@ struct fmpc_handle_s {
     int generic_ok;                      // the generic kernel's LDS tiles fit (n <= 64)
     int prec;                            // FMPC_PREC_F64 / FMPC_PREC_F32_MIXED of the per-problem-factor path
     int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
-    struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // [0] fp64, [1] fp32
+    struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // bm: padded fp64 images   // [0] fp64, [1] fp32
     double* tl_ws; size_t tl_ws_doubles;
     std::vector<double> hm_b;            // B row-major n x m
+    std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
     // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
     double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
     double* ramp_ws; size_t ramp_ws_doubles;
@@ -364,6 +365,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     if (generic_ok && fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
     // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
     h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
+    h->hm_a1f = a1; h->hm_a2f = a2;
     h->hm_b.resize((size_t)n * m);
     for (int rr = 0; rr < n; ++rr)
         for (int c = 0; c < m; ++c) h->hm_b[(size_t)rr * m + c] = cm(B, n, rr, c);
@@ -905,19 +907,34 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idxD[i]);
     for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idx1[i] >= 0 ? h->hm_idx1[i] : nblk);
     for (int i = 0; i < nb; ++i) ids.push_back(h->hm_idx2[i] >= 0 ? h->hm_idx2[i] : nblk);
+    // zero-padded fp64 images of B', B, A1, A2, A1', A2' for the residual GEMMs
+    const int NP = 16 * NB, MP = 16 * mb;
+    const size_t oBt = 0, oBm = oBt + (size_t)MP * NP, oA1 = oBm + (size_t)NP * MP, oA2 = oA1 + (size_t)NP * NP,
+                 oA1t = oA2 + (size_t)NP * NP, oA2t = oA1t + (size_t)NP * NP, ptot = oA2t + (size_t)NP * NP;
+    std::vector<double> pad(ptot, 0.0);
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < n; ++r) {
+            pad[oBt + (size_t)c * NP + r] = h->hm_bt[(size_t)c * n + r];
+            pad[oBm + (size_t)r * MP + c] = h->hm_bt[(size_t)c * n + r];
+        }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            pad[oA1 + (size_t)a * NP + b] = h->hm_a1f[(size_t)a * n + b]; pad[oA1t + (size_t)b * NP + a] = h->hm_a1f[(size_t)a * n + b];
+            pad[oA2 + (size_t)a * NP + b] = h->hm_a2f[(size_t)a * n + b]; pad[oA2t + (size_t)b * NP + a] = h->hm_a2f[(size_t)a * n + b];
+        }
     if (hipMalloc(&X.pool, img.size() * sizeof(R)) != hipSuccess ||
         hipMalloc((void**)&X.ipool, ids.size() * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&X.bm, h->hm_b.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        hipMalloc((void**)&X.bm, pad.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
     if (hipMemcpy(X.pool, img.data(), img.size() * sizeof(R), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(X.ipool, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(X.bm, h->hm_b.data(), h->hm_b.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+        hipMemcpy(X.bm, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     X.NB = NB; X.NW = NW;
     X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t, nb);
     if (fmpc_tiled_prepare(NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
     X.V.NB = NB; X.V.mb = mb; X.V.cn = n / 16; X.V.nl = n % 16; X.V.nblk = nblk;
     X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
     X.V.iD = X.ipool; X.V.i1 = X.ipool + nb; X.V.i2 = X.ipool + 2 * nb;
-    X.V.Bm = X.bm;
+    X.V.BtP = X.bm + oBt; X.V.BmP = X.bm + oBm; X.V.A1P = X.bm + oA1; X.V.A2P = X.bm + oA2; X.V.A1tP = X.bm + oA1t; X.V.A2tP = X.bm + oA2t;
     X.ready = 1;
     return FMPC_OK;
 }
@@ -933,7 +950,7 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     }
     int wgs = (int)(FMPC_LDS_LIMIT / X.lds);
     if (wgs < 1) wgs = 1;
-    if (wgs * X.NW > 8) wgs = 8 / X.NW > 0 ? 8 / X.NW : 1;             // two waves per SIMD (launch bound)
+    if (wgs * X.NW > 8) wgs = 8 / X.NW > 0 ? 8 / X.NW : 1;             // two waves per SIMD (the kernel's launch bound)
     const int cap = h->num_cu * wgs;
     const int grid = batch < cap ? batch : cap;
     const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8);

@@ -23,6 +23,7 @@
 // (the Newton iteration itself is the fp64 residual refinement of the fp32 KKT solves).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "fmpc_tiled.h"
 #include "../../include/fastmpc.h"
 
@@ -157,18 +158,27 @@ __device__ __forceinline__ bool ft_potrf16(const typename FtT<R>::v4& P, int cnt
 #pragma unroll
     for (int r = 0; r < 4; ++r) { E[r] = TT::row(g, r) == c ? (R)1 : (R)0; Rout[r] = (R)0; Wout[r] = (R)0; }
     bool ok = true;
+    // the pivot of step k + 1 is formed from the still unreduced tile and row k (two readlanes and an fma), so its
+    // reciprocal square root is computed while the matrix cores apply the rank-1 update of step k
+    R piv = TT::readlane(acc[TT::kr(0)], 16 * TT::kg(0));
+    R rinv = TT::rsqrt(piv);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (k < cnt) {                                           // uniform
             const int gk = TT::kg(k), rk = TT::kr(k);          // constants after unrolling
-            const R piv = TT::readlane(acc[rk], k + 16 * gk);
             ok = ok && (piv > (R)0) && (piv < (R)INFINITY);
-            const R rinv = TT::rsqrt(piv);
             const bool sel = g == gk;
             const R t = sel ? acc[rk] * rinv : (R)0;
             const R te = sel ? E[rk] * rinv : (R)0;
             Rout[rk] = sel ? t : Rout[rk];
             Wout[rk] = sel ? te : Wout[rk];
+            if (k + 1 < 16 && k + 1 < cnt) {
+                const int g1 = TT::kg(k + 1), r1 = TT::kr(k + 1);
+                const R aold = TT::readlane(acc[r1], (k + 1) + 16 * g1);
+                const R tk = TT::readlane(t, (k + 1) + 16 * gk);
+                piv = aold - tk * tk;
+                rinv = TT::rsqrt(piv);
+            }
             acc = TT::mfma_sub(t, t, acc);
             E = TT::mfma_sub(t, te, E);
         }
@@ -204,8 +214,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     R* sSLOT = (R*)(smem + LL.slot);
     R* sLT = (R*)(smem + LL.lt);
     R* sWT = (R*)(smem + LL.wt);
-    R* sWL = (R*)(smem + LL.wl);
     R* sYSH = (R*)(smem + LL.ysh);
+    R* sWL = (R*)(smem + LL.wl);
     R* sXV = (R*)(smem + LL.xv);
     R* sPART = (R*)(smem + LL.part);
     double* red = (double*)(smem + LL.red);
@@ -214,12 +224,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     // space of the U slots, which only the factor phase uses
     double* sNU = (double*)(smem + LL.slot);
     constexpr int LDN = 16 * NB + 1;
-    const int TA = (nb + 15) / 16, NUROWS = 16 * TA + 2;
-
-    {   // B' tiles stay in LDS for the whole launch
-        const R* src = (const R*)V.btimg;
-        for (int i = tid; i < mb * NB * FT_TILE; i += NT) sBT[i] = src[i];
-    }
+    const int TA = (nb + 15) / 16, NUROWS = 16 * TA + 2, MP = 16 * mb;
 
     const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R));
     double* wsp = P.ws + (size_t)blockIdx.x * P.ws_stride;
@@ -232,9 +237,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     double* phx = wsp + L.phx;
     double* rp = wsp + L.rp;
     double* yv = wsp + L.y;
-    double* dnu = wsp + L.dnu;
     R* fac = (R*)(wsp + L.fac);
-    constexpr int STAGE_TILES = NB + 3 * NB * NB;
+    R* gws = (R*)(wsp + L.gt);
+    constexpr int STAGE_TILES = 3 * NB * NB, REC_TILES = 3 * NB;       // factor stream: one record per 16-row block
     const R* yimg = (const R*)V.yimg;
 
     // tile ownership: S tile t (upper-triangular enumeration) -> wave t % NW; M1 tile q = I NB + J -> wave (NS + q) % NW;
@@ -299,16 +304,23 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         const int Jr = item / TA, A = item - Jr * TA;
                         const int i = 16 * A + c, r = 16 * Jr + c;      // as A-operand lane: stage i; as B-operand lane: state r
                         const bool rok = r < n;
-                        ft_vec_gemm(acc, 16 * mb, g,
-                                    [&](int k) { return (i < T && k < m) ? zp[i * s + k] : 0.0; },
-                                    [&](int k) { return (rok && k < m) ? M.Bt[k * n + r] : 0.0; });
+                        // Z comes from zero-padded images and X needs no zeros where Z has them, so every load is
+                        // unconditional (a conditional load is a branch with a wait behind it); stage 0 / 1 terms that
+                        // do not exist are switched off by a factor
+                        const double* zi0 = zp + (size_t)(i < T ? i : T - 1) * s;
+                        const double* zi1 = zp + (size_t)((i >= 1 && i < T) ? i - 1 : 0) * s + m;
+                        const double* zi2 = zp + (size_t)((i >= 2 && i < T) ? i - 2 : 0) * s + m;
+                        const double f1 = (i >= 1 && i < T) ? 1.0 : 0.0, f2 = (i >= 2 && i < T) ? 1.0 : 0.0;
+                        ft_vec_gemm(acc, MP, g,
+                                    [&](int k) { return zi0[k < m ? k : m - 1]; },
+                                    [&](int k) { return V.BtP[(size_t)k * NP + r]; });
                         ft_vec_gemm(acc, NP, g,
-                                    [&](int k) { return (i >= 1 && i < T && k < n) ? zp[(i - 1) * s + m + k] : 0.0; },
-                                    [&](int k) { return (rok && k < n) ? M.A1t[k * n + r] : 0.0; });
+                                    [&](int k) { return zi1[k < n ? k : n - 1] * f1; },
+                                    [&](int k) { return V.A1tP[k * NP + r]; });
                         if (var2)
                             ft_vec_gemm(acc, NP, g,
-                                        [&](int k) { return (i >= 2 && i < T && k < n) ? zp[(i - 2) * s + m + k] : 0.0; },
-                                        [&](int k) { return (rok && k < n) ? M.A2t[k * n + r] : 0.0; });
+                                        [&](int k) { return zi2[k < n ? k : n - 1] * f2; },
+                                        [&](int k) { return V.A2tP[k * NP + r]; });
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int io = 16 * A + g + 4 * rr;
@@ -323,13 +335,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         const int it2 = item - nC, Jr = it2 / TA, A = it2 - Jr * TA;
                         const int jj = 16 * A + c, r = 16 * Jr + c;
                         const bool rok = r < n;
+                        const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
                         ft_vec_gemm(acc, NP, g,
-                                    [&](int k) { return jj + 1 < T ? sNU[(jj + 1) * LDN + k] : 0.0; },
-                                    [&](int k) { return (rok && k < n) ? M.A1[k * n + r] : 0.0; });
+                                    [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
+                                    [&](int k) { return V.A1P[k * NP + r]; });
                         if (var2)
                             ft_vec_gemm(acc, NP, g,
-                                        [&](int k) { return jj + 2 < T ? sNU[(jj + 2) * LDN + k] : 0.0; },
-                                        [&](int k) { return (rok && k < n) ? M.A2[k * n + r] : 0.0; });
+                                        [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
+                                        [&](int k) { return V.A2P[k * NP + r]; });
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int jo = 16 * A + g + 4 * rr;
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         const bool qok = q < m;
                         ft_vec_gemm(acc, NP, g,
                                     [&](int k) { return sNU[j * LDN + k]; },
-                                    [&](int k) { return (qok && k < n) ? V.Bm[(size_t)k * m + q] : 0.0; });
+                                    [&](int k) { return V.BmP[(size_t)k * MP + q]; });
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int jo = 16 * A + g + 4 * rr;
@@ -384,16 +397,20 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 const int i = 16 * A + c, r = 16 * Jr + c;
                 const bool rok = r < n;
                 ft_d4 acc = {0, 0, 0, 0};
-                ft_vec_gemm(acc, 16 * mb, g,
-                            [&](int k) { return (i < T && k < m) ? rdu[i * m + k] * winv[i * m + k] : 0.0; },
-                            [&](int k) { return (rok && k < m) ? M.Bt[k * n + r] : 0.0; });
+                const size_t iu = (size_t)(i < T ? i : T - 1) * m;
+                const double* ph1 = phx + (size_t)((i >= 1 && i < T) ? i - 1 : 0) * n;
+                const double* ph2 = phx + (size_t)((i >= 2 && i < T) ? i - 2 : 0) * n;
+                const double f1 = (i >= 1 && i < T) ? 1.0 : 0.0, f2 = (i >= 2 && i < T) ? 1.0 : 0.0;
+                ft_vec_gemm(acc, MP, g,
+                            [&](int k) { const int kc = k < m ? k : m - 1; return rdu[iu + kc] * winv[iu + kc]; },
+                            [&](int k) { return V.BtP[(size_t)k * NP + r]; });
                 ft_vec_gemm(acc, NP, g,
-                            [&](int k) { return (i >= 1 && i < T && k < n) ? phx[(i - 1) * n + k] : 0.0; },
-                            [&](int k) { return (rok && k < n) ? M.A1t[k * n + r] : 0.0; });
+                            [&](int k) { return ph1[k < n ? k : n - 1] * f1; },
+                            [&](int k) { return V.A1tP[k * NP + r]; });
                 if (var2)
                     ft_vec_gemm(acc, NP, g,
-                                [&](int k) { return (i >= 2 && i < T && k < n) ? phx[(i - 2) * n + k] : 0.0; },
-                                [&](int k) { return (rok && k < n) ? M.A2t[k * n + r] : 0.0; });
+                                [&](int k) { return ph2[k < n ? k : n - 1] * f2; },
+                                [&](int k) { return V.A2tP[k * NP + r]; });
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int io = 16 * A + g + 4 * rr;
@@ -404,8 +421,84 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 }
             }
             __syncthreads();                                           // (the staging area of nu is the U slots' space)
+            // ================= S pre-pass: the initial diagonal blocks S0_i = Y_ii const + B W_i B' (upper-triangular tiles,
+            // rhs_i in column n) of EVERY block row, all independent, ahead of the serial factorisation.  The B' tiles are
+            // in LDS only for this (the factor phase reuses the space); Phi^-1 of FT_GCH stages at a time in LDS.
+            {
+                const R* src = (const R*)V.btimg;
+                for (int q = tid; q < mb * NB * FT_TILE; q += NT) sBT[q] = src[q];
+            }
+            {
+                constexpr int IPW = (FT_GCH * NS + NW - 1) / NW;       // items per wave and chunk
+                constexpr int WPT = (FT_GCH * 16 * 16 + NT - 1) / NT;  // Phi^-1 entries per thread and chunk (mb <= 16)
+                R wreg[WPT];
+                auto wload = [&](int i0) {
+#pragma unroll
+                    for (int e = 0; e < WPT; ++e) {
+                        const int q = tid + e * NT;
+                        const int ii = q / (mb * 16), k = q - ii * (mb * 16);
+                        wreg[e] = (q < FT_GCH * mb * 16 && i0 + ii < T && k < m) ? (R)winv[(size_t)(i0 + ii) * m + k] : (R)0;
+                    }
+                };
+                wload(0);
+                for (int i0 = 0; i0 < nb; i0 += FT_GCH) {
+                    __syncthreads();                                   // (the previous chunk's products are done with sWL)
+#pragma unroll
+                    for (int e = 0; e < WPT; ++e) {
+                        const int q = tid + e * NT;
+                        if (q < FT_GCH * mb * 16) sWL[q] = wreg[e];
+                    }
+                    __syncthreads();
+                    v4 a[IPW];
+                    int iI[IPW], iJ[IPW], iS[IPW];
+#pragma unroll
+                    for (int u = 0; u < IPW; ++u) {                    // every load of the chunk first ...
+                        const int item = wv + u * NW;
+                        const int ii = item / NS, i = i0 + ii;
+                        int t = item - ii * NS, I = 0;
+                        while (t >= NB - I) { t -= NB - I; ++I; }
+                        const int J = I + t;
+                        iI[u] = I; iJ[u] = J; iS[u] = (item < FT_GCH * NS && i < nb) ? i : -1;
+                        if (iS[u] >= 0) {
+                            const R* yt = yimg + ((size_t)V.iD[i] * NQ + I * NB + J) * FT_TILE;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a[u][r] = yt[TT::row(g, r) * 16 + c];
+                            if (J == cn) {                             // uniform; the loads themselves are unconditional
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = 16 * I + TT::row(g, r);
+                                    const R yr = (R)yv[i * n + (row < n ? row : n - 1)];
+                                    a[u][r] = c == nl ? (row < n ? yr : (R)0) : a[u][r];
+                                }
+                            }
+                        }
+                    }
+                    if (i0 + FT_GCH < nb) wload(i0 + FT_GCH);
+#pragma unroll
+                    for (int u = 0; u < IPW; ++u) {                    // ... then the products and the stores
+                        if (iS[u] >= 0) {
+                            const int i = iS[u], I = iI[u], J = iJ[u];
+                            if (i < T) {
+                                const R* wl = sWL + (i - i0) * mb * 16;
+#pragma unroll 3
+                                for (int kb = 0; kb < mb; ++kb) {
+                                    const R* X = sBT + (size_t)(kb * NB + I) * FT_TILE;
+                                    const R* Z = sBT + (size_t)(kb * NB + J) * FT_TILE;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        a[u] = TT::mfma(X[64 * r + lane], Z[64 * r + lane] * wl[16 * kb + 4 * r + g], a[u]);
+                                }
+                            }
+                            R* dst = gws + ((size_t)i * NS + ft_lt_index(NB, I, J)) * FT_TILE;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dst[TT::row(g, r) * 16 + c] = a[u][r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
             // zero the three U slots: stages 0 and 1 then need no special cases
-            for (int i = tid; i < 3 * NQ * FT_TILE; i += NT) sSLOT[i] = (R)0;
+            for (int q = tid; q < 3 * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
             if (tid == 0) sflag[0] = 0;
             __syncthreads();
             FT_TICK(2);
@@ -413,49 +506,51 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // ================= P3: factor + forward sweep
             int ua = 0, ub = 1, uc = 2;                               // roles of the three LDS slots
             bool fail = false;
+            // Loads queue behind the stores a wave has issued (vmcnt is in order), so everything stage i + 1 needs from
+            // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
+            // before that stage's factor tiles are stored.
+            v4 nS[SS], nM1[MS];
+            auto request = [&](int i) {
+                const R* Y1 = yimg + (size_t)V.i1[i] * NQ * FT_TILE;
+#pragma unroll
+                for (int sl = 0; sl < SS; ++sl)
+                    if (sI[sl] >= 0) {
+                        const R* gt = gws + ((size_t)i * NS + firstS + sl * NW) * FT_TILE;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) nS[sl][r] = gt[TT::row(g, r) * 16 + c];
+                    }
+#pragma unroll
+                for (int sl = 0; sl < MS; ++sl) {
+                    const int q1 = firstM1 + sl * NW;
+                    if (q1 < NQ) {
+                        const R* yt = Y1 + (size_t)q1 * FT_TILE;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) nM1[sl][r] = yt[TT::row(g, r) * 16 + c];
+                    }
+                }
+            };
+            request(0);
             for (int i = 0; i < nb; ++i) {
-                const bool hasB = i < T;
                 R* UA = sSLOT + (size_t)ua * NQ * FT_TILE;
                 R* UB = sSLOT + (size_t)ub * NQ * FT_TILE;
                 R* UC = sSLOT + (size_t)uc * NQ * FT_TILE;
                 R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
-                const R* YD = yimg + (size_t)V.iD[i] * NQ * FT_TILE;
-                const R* Y1 = yimg + (size_t)V.i1[i] * NQ * FT_TILE;
                 const R* Y2 = yimg + (size_t)V.i2[i] * NQ * FT_TILE;
-                if (hasB)
-                    for (int q = tid; q < mb * 16; q += NT) sWL[q] = q < m ? (R)winv[i * m + q] : (R)0;
-                ft_lds_barrier();
                 // ---------------- phase A: all tiles of the stage, independent
-                v4 aS[SS], aM1[MS], aM2[MS];
+                v4 aS[SS], aM1[MS];
+#pragma unroll
+                for (int sl = 0; sl < SS; ++sl) aS[sl] = nS[sl];
+#pragma unroll
+                for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
 #pragma unroll
                 for (int sl = 0; sl < SS; ++sl) {
                     const int I = sI[sl], J = sJ[sl];
                     if (I >= 0) {
-                        v4 a;
-                        const R* yt = YD + (size_t)(I * NB + J) * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] = yt[TT::row(g, r) * 16 + c];
-                        if (J == cn && c == nl) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = 16 * I + TT::row(g, r);
-                                a[r] = row < n ? (R)yv[i * n + row] : (R)0;
-                            }
-                        }
-                        if (hasB) {                                    // + B'(W B): contraction over the actuators
-                            for (int kb = 0; kb < mb; ++kb) {
-                                const R* X = sBT + (size_t)(kb * NB + I) * FT_TILE;
-                                const R* Z = sBT + (size_t)(kb * NB + J) * FT_TILE;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    a = TT::mfma(X[64 * r + lane], Z[64 * r + lane] * sWL[16 * kb + 4 * r + g], a);
-                            }
-                        }
+#pragma unroll 1
                         for (int j = 0; j < NB; ++j) {
-                            ft_xtz_sub<R>(a, UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
-                            ft_xtz_sub<R>(a, UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
+                            ft_xtz_sub<R>(aS[sl], UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
+                            ft_xtz_sub<R>(aS[sl], UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
                         }
-                        aS[sl] = a;
                     }
                 }
 #pragma unroll
@@ -463,26 +558,25 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     const int q1 = firstM1 + sl * NW;
                     if (q1 < NQ) {
                         const int I = q1 / NB, J = q1 - I * NB;
-                        v4 a;
-                        const R* yt = Y1 + (size_t)q1 * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] = yt[TT::row(g, r) * 16 + c];
+#pragma unroll 1
                         for (int j = 0; j < NB; ++j)
-                            ft_xtz_sub<R>(a, UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
-                        aM1[sl] = a;
-                    }
-                    const int q2 = firstM2 + sl * NW;
-                    if (q2 < NQ) {
-                        v4 a;
-                        const R* yt = Y2 + (size_t)q2 * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] = yt[TT::row(g, r) * 16 + c];
-                        aM2[sl] = a;
+                            ft_xtz_sub<R>(aM1[sl], UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
                     }
                 }
                 ft_lds_barrier();                                      // Ua, Uc are dead from here: their slots take U1_i, U2_i
                 FT_TICK(3);
                 R* U1N = UA; R* U2N = UC;
+                if (i + 1 < nb) request(i + 1);
+                v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
+#pragma unroll
+                for (int sl = 0; sl < MS; ++sl) {
+                    const int q2 = firstM2 + sl * NW;
+                    if (q2 < NQ) {
+                        const R* yt = Y2 + (size_t)q2 * FT_TILE;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) aM2[sl][r] = yt[TT::row(g, r) * 16 + c];
+                    }
+                }
                 // ---------------- phase B: the 16-row blocks of the stage, in order
                 for (int kb = 0; kb < NB; ++kb) {
                     int cnt = n - 16 * kb; cnt = cnt > 16 ? 16 : (cnt < 0 ? 0 : cnt);
@@ -500,10 +594,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             for (int j = 0; j < kb; ++j)
                                 ft_xtz_sub<R>(aM1[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
                                               U1N + (size_t)(j * NB + q1 % NB) * FT_TILE, lane);
-                        if (q2 < NQ && q2 / NB == kb)
+                        if (q2 < NQ && q2 / NB == kb) {
                             for (int j = 0; j < kb; ++j)
                                 ft_xtz_sub<R>(aM2[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
                                               U2N + (size_t)(j * NB + q2 % NB) * FT_TILE, lane);
+                        }
                     }
                     // (2) the rhs column of this row block, still unscaled: shared with the owners of M1(kb,cn), M2(kb,cn);
                     //     the owner of the diagonal tile factors it
@@ -517,7 +612,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             v4 Ro, Wo;
                             const bool ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
                             if (!ok && lane == 0) sflag[0] = 1;
-                            R* ri = facs + (size_t)kb * FT_TILE;       // R(kb,kb)^-1 = W' for the backward sweep
+                            R* ri = facs + (size_t)(kb * REC_TILES) * FT_TILE;   // R(kb,kb)^-1 = W' for the backward sweep
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 sWT[c * FT_WLD + TT::row(g, r)] = Wo[r];
@@ -546,7 +641,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], aS[sl][r], o);
                             R* dl = sLT + (size_t)ft_lt_index(NB, kb, sJ[sl]) * FT_TILE;
-                            R* dg = facs + (size_t)(NB + kb * NB + sJ[sl]) * FT_TILE;
+                            R* dg = facs + (size_t)(kb * REC_TILES + sJ[sl]) * FT_TILE;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
                             if (sJ[sl] == cn && c == nl) {
@@ -572,7 +667,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
                             R* dl = U1N + (size_t)q1 * FT_TILE;
-                            R* dg = facs + (size_t)(NB + NQ + q1) * FT_TILE;
+                            R* dg = facs + (size_t)(kb * REC_TILES + NB + J) * FT_TILE;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
                         }
@@ -587,7 +682,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
                             R* dl = U2N + (size_t)q2 * FT_TILE;
-                            R* dg = facs + (size_t)(NB + 2 * NQ + q2) * FT_TILE;
+                            R* dg = facs + (size_t)(kb * REC_TILES + 2 * NB + J) * FT_TILE;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
                         }
@@ -604,47 +699,84 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             __syncthreads();                                           // the factor stream and y are in HBM (same workgroup reads them)
             FT_TICK(6);
 
-            // ================= P4: backward sweep, d_nu_i = R_i^-1 (y_i - U1_i d_nu_{i+1} - U2_i d_nu_{i+2})
+            // ================= P4: backward sweep, d_nu_i = R_i^-1 (y_i - U1_i d_nu_{i+1} - U2_i d_nu_{i+2}), one 16-row
+            // block at a time from the bottom: x_kb = RI(kb) (y_kb - sum of tile x vector products).  16 consecutive threads
+            // read a tile row (coalesced) and sum over it by DPP; the tiles of the NEXT block row are requested before the
+            // current one is reduced.  x of stage i lives in buffer i % 3.
             {
-                constexpr int NG = NT / 256;                           // tile groups: 256 threads cover one tile
-                const int tg = tid >> 8, ta = (tid >> 4) & 15, tb = tid & 15;
+                constexpr int NG = NT >= 256 ? NT / 256 : 1;           // tile groups working on different tiles
+                constexpr int RPT = NT >= 256 ? 1 : 256 / NT;          // tile rows per thread (128 threads: rows ta, ta + 8)
+                constexpr int RSTEP = 16 / RPT;
+                constexpr int MAXT = (REC_TILES - 1 + NG - 1) / NG;    // tiles 1 .. 3 NB - 1 of a record, dealt to the groups
+                constexpr int PD = 2;                                  // records in flight
+                const int tg = tid >> 8, ta = (tid >> 4) & (RSTEP - 1), tb = tid & 15;
                 for (int q = tid; q < 3 * NP; q += NT) sXV[q] = (R)0;
-                int xc = 0, x1 = 1, x2 = 2;                            // roles of the three x vectors
-                __syncthreads();
-                for (int i = nb - 1; i >= 0; --i) {
-                    const R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
-                    R* XC = sXV + xc * NP; const R* X1 = sXV + x1 * NP; const R* X2 = sXV + x2 * NP;
-                    for (int kb = NB - 1; kb >= 0; --kb) {
-                        const int nt = (NB - 1 - kb) + 2 * NB;         // tiles of this block row: R(kb, c > kb), U1(kb, .), U2(kb, .)
-                        R accv = (R)0;
-                        for (int t = tg; t < nt; t += NG) {
-                            const R* tile; const R* xvv;
-                            if (t < NB - 1 - kb) { const int cc = kb + 1 + t; tile = facs + (size_t)(NB + kb * NB + cc) * FT_TILE; xvv = XC + 16 * cc; }
-                            else if (t < NB - 1 - kb + NB) { const int cc = t - (NB - 1 - kb); tile = facs + (size_t)(NB + NQ + kb * NB + cc) * FT_TILE; xvv = X1 + 16 * cc; }
-                            else { const int cc = t - (NB - 1 - kb) - NB; tile = facs + (size_t)(NB + 2 * NQ + kb * NB + cc) * FT_TILE; xvv = X2 + 16 * cc; }
-                            accv += tile[ta * 16 + tb] * xvv[tb];
-                        }
-                        accv = ft_row16_sum<R>(accv);
-                        const R riv = tg == 0 ? facs[(size_t)kb * FT_TILE + ta * 16 + tb] : (R)0;
-                        const int yrow = 16 * kb + tb;
-                        const R yb = (tg == 0 && yrow < n) ? (R)yv[i * n + yrow] : (R)0;
-                        if (tb == 0) sPART[tg * 16 + ta] = accv;
-                        ft_lds_barrier();
-                        if (tg == 0) {
-                            R sb = yb;
+                for (int q = tid; q < NUROWS * LDN; q += NT) sNU[q] = 0.0;   // d_nu as [stage][state] for P5 (the U slots are dead)
+                R buf[PD][MAXT][RPT], briv[PD][RPT], byb[PD];
+                // every load unconditional, at a constant offset from the record: tile 1 + tg + q NG (clamped), RI = tile 0
+                auto fetch = [&](int blk, R (&tv)[MAXT][RPT], R (&riv)[RPT], R& yb) {
+                    const R* rec = fac + (size_t)blk * REC_TILES * FT_TILE + ta * 16 + tb;
 #pragma unroll
-                            for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
-                            R xv = ft_row16_sum<R>(riv * sb);
-                            if (tb == 0) {
-                                XC[16 * kb + ta] = xv;
-                                const int row = 16 * kb + ta;
-                                if (row < n) dnu[i * n + row] = (double)xv;
-                            }
-                        }
-                        ft_lds_barrier();
+                    for (int q = 0; q < MAXT; ++q) {
+                        const int t = 1 + tg + q * NG;
+                        const int tc = t < REC_TILES ? t : REC_TILES - 1;
+#pragma unroll
+                        for (int h = 0; h < RPT; ++h) tv[q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
                     }
-                    const int t = x2; x2 = x1; x1 = xc; xc = t;
-                    for (int q = tid; q < NP; q += NT) sXV[xc * NP + q] = (R)0;
+#pragma unroll
+                    for (int h = 0; h < RPT; ++h) riv[h] = rec[RSTEP * h * 16];
+                    const int i = blk / NB, kb = blk - i * NB;
+                    const int yrow = 16 * kb + tb;
+                    yb = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
+                };
+                __syncthreads();
+                const int top = nb * NB - 1;
+#pragma unroll
+                for (int d = 0; d < PD; ++d) fetch(top - d >= 0 ? top - d : 0, buf[d], briv[d], byb[d]);
+                for (int blk0 = top; blk0 >= 0; blk0 -= PD) {
+#pragma unroll
+                    for (int d = 0; d < PD; ++d) {
+                        const int blk = blk0 - d;
+                        if (blk >= 0) {                                // uniform
+                            const int i = blk / NB, kb = blk - i * NB;
+                            R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+                            R accv[RPT];
+#pragma unroll
+                            for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
+#pragma unroll
+                            for (int q = 0; q < MAXT; ++q) {
+                                const int t = 1 + tg + q * NG;         // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
+                                const int tc = t < REC_TILES ? t : REC_TILES - 1;
+                                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                                const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
+                                const R xb = use ? xvv[tb] : (R)0;
+#pragma unroll
+                                for (int h = 0; h < RPT; ++h) accv[h] += (use ? buf[d][q][h] : (R)0) * xb;
+                            }
+#pragma unroll
+                            for (int h = 0; h < RPT; ++h) {
+                                accv[h] = ft_row16_sum<R>(accv[h]);
+                                if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
+                            }
+                            ft_lds_barrier();
+                            if (tg == 0) {
+                                R sb = 16 * kb + tb < n ? byb[d] : (R)0;
+#pragma unroll
+                                for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
+#pragma unroll
+                                for (int h = 0; h < RPT; ++h) {
+                                    const R xv = ft_row16_sum<R>(briv[d][h] * sb);
+                                    if (tb == 0) {
+                                        const int lr = ta + RSTEP * h;
+                                        XC[16 * kb + lr] = xv;
+                                        if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
+                                    }
+                                }
+                            }
+                            ft_lds_barrier();
+                            fetch(blk - PD >= 0 ? blk - PD : 0, buf[d], briv[d], byb[d]);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -652,25 +784,21 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 
             // ================= P5: d_z, line-search scalars, update (the same stage-batched GEMMs with d_nu)
             double be = 0.0, e2 = 0.0;
-            for (int idx = tid; idx < NUROWS * LDN; idx += NT) {
-                const int j = idx / LDN, r = idx - j * LDN;
-                sNU[idx] = (j < nb && r < n) ? dnu[j * n + r] : 0.0;
-            }
-            __syncthreads();
-            for (int item = wv; item < NB * TA + mb * TA; item += NW) {
+            for (int item = wv; item < NB * TA + mb * TA; item += NW) {          // (d_nu is in the staging area: written by P4)
                 ft_d4 acc = {0, 0, 0, 0};
                 if (item < NB * TA) {
                     // ---- d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1' d_nu_j + A2' d_nu_{j+1}  [- d_nu_T])
                     const int Jr = item / TA, A = item - Jr * TA;
                     const int jj = 16 * A + c, r = 16 * Jr + c;
                     const bool rok = r < n;
+                    const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
                     ft_vec_gemm(acc, NP, g,
-                                [&](int k) { return jj + 1 < T ? sNU[(jj + 1) * LDN + k] : 0.0; },
-                                [&](int k) { return (rok && k < n) ? M.A1[k * n + r] : 0.0; });
+                                [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
+                                [&](int k) { return V.A1P[k * NP + r]; });
                     if (var2)
                         ft_vec_gemm(acc, NP, g,
-                                    [&](int k) { return jj + 2 < T ? sNU[(jj + 2) * LDN + k] : 0.0; },
-                                    [&](int k) { return (rok && k < n) ? M.A2[k * n + r] : 0.0; });
+                                    [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
+                                    [&](int k) { return V.A2P[k * NP + r]; });
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int jo = 16 * A + g + 4 * rr;
@@ -688,7 +816,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     const bool qok = q < m;
                     ft_vec_gemm(acc, NP, g,
                                 [&](int k) { return sNU[j * LDN + k]; },
-                                [&](int k) { return (qok && k < n) ? V.Bm[(size_t)k * m + q] : 0.0; });
+                                [&](int k) { return V.BmP[(size_t)k * MP + q]; });
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int jo = 16 * A + g + 4 * rr;
@@ -723,7 +851,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 const int j = idx / s, e = idx - j * s;
                 zp[idx] += t * (e < m ? rdu[j * m + e] : rdx[j * n + e - m]);
             }
-            for (int idx = tid; idx < nbn; idx += NT) nu[idx] += t * dnu[idx];
+            for (int idx = tid; idx < nbn; idx += NT) { const int j = idx / n; nu[idx] += t * sNU[j * LDN + idx - j * n]; }
             if (P.step && tid == 0 && it < P.step_ld) P.step[(size_t)p * P.step_ld + it] = t;
             ++nsteps;
             __syncthreads();
@@ -752,25 +880,45 @@ static hipError_t ft_prepare(size_t lds) {
     return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-// instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5)
+// instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5); NW wavefronts per problem
 #define FT_DISPATCH(fn, ...)                                                                   \
     if (!is_float) {                                                                           \
+        if (NB == 1 && NW == 2) return fn<double, 1, 2>(__VA_ARGS__);                          \
+        if (NB == 2 && NW == 2) return fn<double, 2, 2>(__VA_ARGS__);                          \
+        if (NB == 3 && NW == 2) return fn<double, 3, 2>(__VA_ARGS__);                          \
         if (NB == 1 && NW == 4) return fn<double, 1, 4>(__VA_ARGS__);                          \
         if (NB == 2 && NW == 4) return fn<double, 2, 4>(__VA_ARGS__);                          \
         if (NB == 3 && NW == 4) return fn<double, 3, 4>(__VA_ARGS__);                          \
     } else {                                                                                   \
-        if (NB == 1 && NW == 4) return fn<float, 1, 4>(__VA_ARGS__);                           \
+        if (NB == 1 && NW == 2) return fn<float, 1, 2>(__VA_ARGS__);                           \
+        if (NB == 2 && NW == 2) return fn<float, 2, 2>(__VA_ARGS__);                           \
         if (NB == 2 && NW == 4) return fn<float, 2, 4>(__VA_ARGS__);                           \
         if (NB == 3 && NW == 4) return fn<float, 3, 4>(__VA_ARGS__);                           \
+        if (NB == 4 && NW == 4) return fn<float, 4, 4>(__VA_ARGS__);                           \
         if (NB == 4 && NW == 8) return fn<float, 4, 8>(__VA_ARGS__);                           \
+        if (NB == 5 && NW == 4) return fn<float, 5, 4>(__VA_ARGS__);                           \
         if (NB == 5 && NW == 8) return fn<float, 5, 8>(__VA_ARGS__);                           \
     }                                                                                          \
     return hipErrorInvalidValue;
 
+// Wavefronts per problem.  Few waves per problem = many problems per CU (the factorisation is a chain of dependent
+// steps that only other problems can hide) at two waves per SIMD, i.e. the full 256-register budget per lane.
+static int ft_default_nw(int NB, int is_float) {
+    int NW = is_float ? (NB >= 4 ? 8 : (NB >= 2 ? 4 : 2)) : (NB >= 3 ? 4 : 2);
+    const char* e = getenv("FMPC_TILED_NW");                      // experiments
+    if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8')) {
+        const int w = e[0] - '0';
+        const bool ok = is_float ? ((NB <= 2 && w == 2) || (NB >= 2 && NB <= 5 && w == 4) || (NB >= 4 && w == 8))
+                                 : (w == 2 || w == 4);
+        if (ok) NW = w;
+    }
+    return NW;
+}
+
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out) {
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
     if (NB > (is_float ? 5 : 3)) return false;
-    const int NW = NB >= 4 ? 8 : 4;
+    const int NW = ft_default_nw(NB, is_float);
     const int mb = (m + 15) / 16;
     if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total > 160 * 1024) return false;
     if (NB_out) *NB_out = NB;

@@ -13,14 +13,16 @@
 
 #define FT_TILE 256                      // elements of a 16 x 16 tile, row-major, no padding
 #define FT_MAX_NB 5                      // n <= 79
+#define FT_GCH 2                         // stages per chunk of the G pre-pass
 #define FT_WLD 17                        // leading dimension of the transposed inverse diagonal factor in LDS
 
-// tiles of one stage in the factor stream (HBM workspace), in elements of FT_TILE:
-//   [0, NB)                  RI(kb)   = R(kb,kb)^-1 (upper triangular), what the backward sweep needs of the diagonal
-//   NB + I NB + J            R(I,J), I < J: the off-diagonal tiles of R_i = L_i'
-//   NB + NB^2 + I NB + J     U1(I,J)  = U_{i,i+1}
-//   NB + 2 NB^2 + I NB + J   U2(I,J)  = U_{i,i+2}
-__host__ __device__ static inline int ft_stage_tiles(int NB) { return NB + 3 * NB * NB; }
+// The factor stream (HBM workspace) is a sequence of fixed-size RECORDS, one per 16-row block (i, kb), 3 NB tiles each,
+// in the order the backward sweep walks them (a record is one contiguous read with constant offsets):
+//   tile 0                   RI(kb)    = R(kb,kb)^-1 (upper triangular): what the backward sweep needs of the diagonal
+//   tile J, kb < J < NB      R(kb,J):   the off-diagonal tiles of R_i = L_i'   (tiles 1..kb are never written nor used)
+//   tile NB + J              U1(kb,J)  = U_{i,i+1}
+//   tile 2 NB + J            U2(kb,J)  = U_{i,i+2}
+__host__ __device__ static inline int ft_stage_tiles(int NB) { return 3 * NB * NB; }
 
 struct FtModel {
     int NB;                 // 16-blocks per stage
@@ -32,12 +34,16 @@ struct FtModel {
     const int* iD;          // per block row: block id of the constant part of Y_ii
     const int* i1;          //                of Y_{i,i+1}   (zero block if none)
     const int* i2;          //                of Y_{i,i+2}   (zero block if none)
-    const double* Bm;       // B row-major n x m (Bm[r*m + c]): coalesced B' v products
+    // zero-padded fp64 copies for the stage-batched GEMMs of the residual phases (no masks, no conditional loads):
+    const double* BtP;      // [16 mb][16 NB]: BtP[c*NP + r] = B[r][c]
+    const double* BmP;      // [16 NB][16 mb]: BmP[r*MP + c] = B[r][c]
+    const double* A1P; const double* A2P;       // [16 NB][16 NB] row-major A1, A2
+    const double* A1tP; const double* A2tP;     // and their transposes
 };
 
 // Per-workgroup scratch in HBM.  Vectors in doubles, then the factor stream in REAL.
 struct FtWs {
-    size_t b, nu, hess, winv, rdu, rdx, phx, rp, y, dnu, fac, total;   // offsets in doubles
+    size_t b, nu, hess, winv, rdu, rdx, phx, rp, y, dnu, gt, fac, total;   // offsets in doubles
 };
 __host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb, int NB, int real_bytes) {
     FtWs L; size_t o = 0;
@@ -46,30 +52,38 @@ __host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb,
     L.b = take(nbn); L.nu = take(nbn); L.hess = take(Tm); L.winv = take(Tm); L.rdu = take(Tm);
     L.rdx = take(Tn); L.phx = take(Tn); L.rp = take(nbn); L.y = take(nbn); L.dnu = take(nbn);
     o = (o + 31) & ~(size_t)31;
+    L.gt = o;                                                    // Y_ii const + B W_i B' (+ rhs column) of every block row, REAL
+    o += ((size_t)nb * (NB * (NB + 1) / 2) * FT_TILE * real_bytes + 7) / 8;
+    o = (o + 31) & ~(size_t)31;
     L.fac = o;
     o += ((size_t)nb * ft_stage_tiles(NB) * FT_TILE * real_bytes + 7) / 8;
     L.total = (o + 31) & ~(size_t)31;
     return L;
 }
 
-// LDS map in bytes
-struct FtLds { size_t bt, slot, lt, wt, wl, ysh, xv, part, red, flag, total; };
+// LDS map in bytes.  One region is used three ways, by phases separated by workgroup barriers:
+//   residual phases   nu / d_nu as [stage][state]: (16 ceil(nb/16) + 2) rows of 16 NB + 1 doubles
+//   G pre-pass        the B' tiles [mb][NB] (B W_i B' for all stages, ahead of the serial factorisation)
+//   factor + sweeps   three U slots (NB^2 tiles each), the R tiles of the stage, W' of the diagonal tile, small vectors
+struct FtLds { size_t bt, slot, lt, wt, ysh, xv, part, wl, red, flag, total; };
 __host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes, int nb) {
     FtLds L; size_t o = 0;
     const size_t tile = (size_t)FT_TILE * real_bytes;
-    L.bt = o;   o += (size_t)mb * NB * tile;
-    // the U slots + R tiles of the factor phase share their space with the [stage][state] staging of nu / d_nu of the
-    // residual phases: (16 ceil(nb/16) + 2) rows of 16 NB + 1 doubles
-    const size_t fac_bytes = (3 * (size_t)NB * NB + (size_t)(NB * (NB + 1) / 2)) * tile;
-    const size_t nu_bytes = (size_t)(16 * ((nb + 15) / 16) + 2) * (16 * NB + 1) * sizeof(double);
-    L.slot = o; L.lt = o + 3 * (size_t)NB * NB * tile;
-    o += fac_bytes > nu_bytes ? fac_bytes : nu_bytes;
-    o = (o + 15) & ~(size_t)15;
+    L.bt = 0; L.slot = 0;
+    o = 3 * (size_t)NB * NB * tile;
+    L.lt = o;   o += (size_t)(NB * (NB + 1) / 2) * tile;
     L.wt = o;   o += (size_t)16 * FT_WLD * real_bytes;
-    L.wl = o;   o += (size_t)mb * 16 * real_bytes;
     L.ysh = o;  o += 16 * real_bytes;
+    const size_t bt_bytes = (size_t)mb * NB * tile;
+    const size_t nu_bytes = (size_t)(16 * ((nb + 15) / 16) + 2) * (16 * NB + 1) * sizeof(double);
+    if (bt_bytes > o) o = bt_bytes;
+    if (nu_bytes > o) o = nu_bytes;
+    o = (o + 15) & ~(size_t)15;
+    // outside the shared region: the x vectors of the backward sweep (live while d_nu is written to the staging area),
+    // the Phi^-1 diagonal of FT_GCH stages during the G pre-pass
     L.xv = o;   o += 3 * (size_t)16 * NB * real_bytes;
     L.part = o; o += (size_t)(NW / 4 > 0 ? NW / 4 : 1) * 16 * real_bytes;
+    L.wl = o;   o += (size_t)FT_GCH * mb * 16 * real_bytes;
     o = (o + 15) & ~(size_t)15;
     L.red = o;  o += 16 * sizeof(double);
     L.flag = o; o += 16;
