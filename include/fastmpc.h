@@ -210,6 +210,18 @@ int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                            void* stream);
 
 /*
+ * VAR(2) model identification (the step that produces A1, A2 for the solver; reference README.md:108-130):
+ *     AA(i-2,:) = [ad_acc(i-1,:), ad_acc(i-2,:)],  BB(i-2,:) = ad_acc(i,:),  i = 3..num_train
+ *     PARA = (AA'*AA) \ AA'*BB ;  A1 = PARA(1:n,:)' ;  A2 = PARA(n+1:2n,:)'
+ * for `batch` coefficient series at once, on the device (Gram matrices on the fp64 matrix cores, Cholesky solve of the
+ * normal equations).  Device pointers; series: per realisation n x num_samples column-major (MATLAB: ad_acc', one
+ * n-vector per time step), the first num_train samples are used; A1, A2: per realisation n x n column-major;
+ * status (nullable): per realisation 0 or FMPC_E_NOT_PD_SCHUR when AA'AA is not positive definite.  n <= 32.
+ */
+int fmpc_var_identify_device(int n, int num_train, int num_samples, int batch, const double* series,
+                             double* A1, double* A2, int* status, void* stream);
+
+/*
  * Arithmetic of the per-problem-factor path (no counterpart in the reference, which is fp64 throughout).
  *   FMPC_PREC_F64        everything in fp64 (default wherever an fp64 kernel exists: n <= 64)
  *   FMPC_PREC_F32_MIXED  "fp32 mixed precision" (BASELINE configs[4]): Y = C Phi^-1 C', its block Cholesky factor

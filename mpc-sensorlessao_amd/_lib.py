@@ -55,6 +55,7 @@ SIGNATURES = {
     "fmpc_solve_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),
     "fmpc_set_precision": (C.c_int, [_vp, C.c_int]),
+    "fmpc_var_identify_device": (C.c_int, [C.c_int] * 4 + [_vp] * 5),
     "fmpc_solve_ramp": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5),
     "fmpc_solve_ramp_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5 + [_vp]),
 }

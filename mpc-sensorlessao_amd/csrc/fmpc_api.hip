@@ -58,6 +58,9 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
+hipError_t fmpc_launch_var_identify(int n, int num_train, int num_samples, int batch, const double* series, double* A1,
+                                    double* A2, int* status, hipStream_t stream);
+
 #define FMPC_LDS_LIMIT (160 * 1024)
 
 struct fmpc_handle_s {
@@ -1476,4 +1479,15 @@ extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
         rc = fmpc_solve(ent->h, 1, x0, x0_pre, w, x_init, nu0, nw, k, x_opt, nullptr, &st, iters, nullptr);
     }
     return rc;
+}
+
+// VAR(2) identification (README.md:108-130) on the device; see include/fastmpc.h
+extern "C" int fmpc_var_identify_device(int n, int num_train, int num_samples, int batch, const double* series,
+                                        double* A1, double* A2, int* status, void* stream) {
+    if (!series || !A1 || !A2) return FMPC_E_NULL;
+    if (n <= 0 || batch < 0 || num_train < 2 * n + 2 || num_samples < num_train) return FMPC_E_DIM;   // fewer rows than unknowns: singular
+    if (n > 32) return FMPC_E_UNSUPPORTED;
+    if (batch == 0) return FMPC_OK;
+    return fmpc_launch_var_identify(n, num_train, num_samples, batch, series, A1, A2, status, (hipStream_t)stream) == hipSuccess
+               ? FMPC_OK : FMPC_E_HIP;
 }

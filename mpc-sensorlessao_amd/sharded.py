@@ -24,6 +24,14 @@ class ShardedFastMPC:
         self.nz, self.m, self.T, self.n = nz, m, T, n
         self.group = group
 
+    @classmethod
+    def from_handle(cls, handle, group=None):
+        """The production wiring: every rank solves its block with its own `FastMPCHandle.solve_device` (HIP kernels on
+        the rank's GPU, asynchronous on torch's current stream)."""
+        def solve_fn(x0, x0_pre, w, nu0, n_newton, k):
+            return handle.solve_device(x0, x0_pre, w, None, nu0, n_newton, k)[0]
+        return cls(solve_fn, handle.nz, handle.m, handle.T, handle.n, group)
+
     def _dist(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -55,6 +63,12 @@ class ShardedFastMPC:
         cols = local.shape[1]
         pad = local.new_zeros((per, cols))
         pad[:local.shape[0]] = local
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal on one GPU / CPU clusters: gloo gathers host tensors (RCCL, the production backend, gathers in HBM)
+            host = pad.cpu()
+            out = host.new_empty((ws * per, cols))
+            dist.all_gather_into_tensor(out, host, group=self.group)
+            return out[:batch].to(local.device)
         out = local.new_empty((ws * per, cols))
         dist.all_gather_into_tensor(out, pad, group=self.group)
         return out[:batch]

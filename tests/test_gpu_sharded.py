@@ -1,0 +1,67 @@
+"""shard -> HIP solve -> gather == single-process HIP solve, bit for bit.  Two gloo ranks share device 0
+(RCCL refuses two ranks on one GPU; the production group is `nccl`), each with its own FastMPCHandle; the per-rank
+shape is that of BASELINE configs[3] (4096 realisations over 8 GPUs = 512 problems per rank) scaled to two ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, batch, nw, out_dir):
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("mpc-sensorlessao_amd")
+    from tests.util import handle_from_model
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    model = pkg.synthetic.make_model(27, 144, 30)
+    data = pkg.synthetic.make_replay_batch(model, r=11, steps=batch)
+    h = handle_from_model(pkg, model)
+    sh = pkg.ShardedFastMPC.from_handle(h)
+    t = {k: (None if v is None else torch.from_numpy(v).to(dev)) for k, v in data.items()}
+    u0 = sh.solve_gather(t["x0"], t["x0_pre"], None, t["nu0"], nw, 1e-2, what="u0")
+    zl, lo, hi = sh.solve_local(t["x0"], t["x0_pre"], None, t["nu0"], nw, 1e-2)
+    z = sh.gather(zl, batch, "z")
+    torch.cuda.synchronize()
+    path, _ = h.last_dispatch()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u0=u0.cpu().numpy(), z=z.cpu().numpy(), lo=lo, hi=hi, path=path)
+    h.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch,nw", [(1024, 1), (75, 3)])
+def test_sharded_hip_solve_equals_single_process(tmp_path, pkg, gpu, batch, nw):
+    from tests.util import handle_from_model, oracle_batch, rel_err
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, batch, nw, str(tmp_path)), nprocs=2, join=True)
+    model = pkg.synthetic.make_model(27, 144, 30)
+    data = pkg.synthetic.make_replay_batch(model, r=11, steps=batch)
+    h = handle_from_model(pkg, model)
+    zref = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=1e-2)
+    h.close()
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    per = -(-batch // 2)
+    assert (int(r0["lo"]), int(r0["hi"])) == (0, per) and (int(r1["lo"]), int(r1["hi"])) == (per, batch)
+    for r in (r0, r1):
+        assert np.array_equal(r["z"], zref), "sharded result differs from the single-process result"
+        assert np.array_equal(r["u0"], zref[:, :144])
+    zo, *_ = oracle_batch(model, {k: (None if v is None else v[:3]) for k, v in data.items()}, nw, 1e-2)
+    assert max(rel_err(zref[p], zo[p]) for p in range(3)) <= 1e-9
