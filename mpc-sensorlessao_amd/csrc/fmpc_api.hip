@@ -933,7 +933,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
         hipMemcpy(X.bm, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     X.NB = NB; X.NW = NW;
     X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t, nb);
-    if (fmpc_tiled_prepare(NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
+    if (fmpc_tiled_prepare(n, NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
     X.V.NB = NB; X.V.mb = mb; X.V.cn = n / 16; X.V.nl = n % 16; X.V.nblk = nblk;
     X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
     X.V.iD = X.ipool; X.V.i1 = X.ipool + nb; X.V.i2 = X.ipool + 2 * nb;

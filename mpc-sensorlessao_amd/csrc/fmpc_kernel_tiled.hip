@@ -189,10 +189,53 @@ __device__ __forceinline__ bool ft_potrf16(const typename FtT<R>::v4& P, int cnt
     return ok;
 }
 
+// The same with the number of live rows known at compile time: straight-line code (the runtime version pays a uniform
+// branch and the register copies of its merge per step).  The matrix-core updates of step k are issued first, the
+// pivot of step k + 1 and its reciprocal square root follow in their shadow.
+template <typename R, int CNT>
+__device__ __forceinline__ bool ft_potrf16_ct(const typename FtT<R>::v4& P, int c, int g,
+                                              typename FtT<R>::v4& Rout, typename FtT<R>::v4& Wout) {
+    typedef FtT<R> TT;
+    typename TT::v4 acc = P, E;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { E[r] = TT::row(g, r) == c ? (R)1 : (R)0; Rout[r] = (R)0; Wout[r] = (R)0; }
+    bool ok = true;
+    if (CNT > 0) {
+        R piv = TT::readlane(acc[TT::kr(0)], 16 * TT::kg(0));
+        R rinv = TT::rsqrt(piv);
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            const int gk = TT::kg(k), rk = TT::kr(k);
+            ok = ok && (piv > (R)0) && (piv < (R)INFINITY);
+            const bool sel = g == gk;
+            const R t = sel ? acc[rk] * rinv : (R)0;
+            const R te = sel ? E[rk] * rinv : (R)0;
+            Rout[rk] = sel ? t : Rout[rk];
+            Wout[rk] = sel ? te : Wout[rk];
+            R aold = (R)0, tk = (R)0;
+            if (k + 1 < CNT) {
+                aold = TT::readlane(acc[TT::kr(k + 1)], (k + 1) + 16 * TT::kg(k + 1));
+                tk = TT::readlane(t, (k + 1) + 16 * gk);
+            }
+            acc = TT::mfma_sub(t, t, acc);
+            E = TT::mfma_sub(t, te, E);
+            if (k + 1 < CNT) {
+                piv = aold - tk * tk;
+                rinv = TT::rsqrt(piv);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (TT::row(g, r) > c) Rout[r] = (R)0;
+    return ok;
+}
+
 // upper-triangular tile enumeration (row-major, I <= J)
 __device__ __forceinline__ int ft_lt_index(int NB, int I, int J) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
 
-template <typename R, int NB, int NW>
+// NL: live rows of the last 16-row block of a stage, n - 16 (NB - 1), when known at compile time (the AO sizes), else -1
+template <typename R, int NB, int NW, int NL>
 __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     typedef FtT<R> TT;
     typedef typename TT::v4 v4;
@@ -429,69 +472,74 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 for (int q = tid; q < mb * NB * FT_TILE; q += NT) sBT[q] = src[q];
             }
             {
-                constexpr int IPW = (FT_GCH * NS + NW - 1) / NW;       // items per wave and chunk
-                constexpr int WPT = (FT_GCH * 16 * 16 + NT - 1) / NT;  // Phi^-1 entries per thread and chunk (mb <= 16)
+                // One block row (all its NS upper-triangular tiles) per wave and chunk: the B' tiles and Phi^-1 read from LDS
+                // feed NS products (one LDS read per MFMA instead of three; the LDS port is what bounds this phase).
+                constexpr int WPT = (NW * 16 * 16 + NT - 1) / NT;      // Phi^-1 entries per thread and chunk (mb <= 16)
                 R wreg[WPT];
                 auto wload = [&](int i0) {
 #pragma unroll
                     for (int e = 0; e < WPT; ++e) {
                         const int q = tid + e * NT;
                         const int ii = q / (mb * 16), k = q - ii * (mb * 16);
-                        wreg[e] = (q < FT_GCH * mb * 16 && i0 + ii < T && k < m) ? (R)winv[(size_t)(i0 + ii) * m + k] : (R)0;
+                        const bool ok = q < NW * mb * 16 && i0 + ii < T && k < m;
+                        const R v = (R)winv[ok ? (size_t)(i0 + ii) * m + k : 0];
+                        wreg[e] = ok ? v : (R)0;
                     }
                 };
                 wload(0);
-                for (int i0 = 0; i0 < nb; i0 += FT_GCH) {
+                for (int i0 = 0; i0 < nb; i0 += NW) {
                     __syncthreads();                                   // (the previous chunk's products are done with sWL)
 #pragma unroll
                     for (int e = 0; e < WPT; ++e) {
                         const int q = tid + e * NT;
-                        if (q < FT_GCH * mb * 16) sWL[q] = wreg[e];
+                        if (q < NW * mb * 16) sWL[q] = wreg[e];
                     }
                     __syncthreads();
-                    v4 a[IPW];
-                    int iI[IPW], iJ[IPW], iS[IPW];
+                    const int i = i0 + wv;
+                    if (i0 + NW < nb) wload(i0 + NW);
+                    if (i < nb) {                                      // uniform per wave
+                        v4 a[NS];
+                        const R* yd = yimg + (size_t)V.iD[i] * NQ * FT_TILE;
 #pragma unroll
-                    for (int u = 0; u < IPW; ++u) {                    // every load of the chunk first ...
-                        const int item = wv + u * NW;
-                        const int ii = item / NS, i = i0 + ii;
-                        int t = item - ii * NS, I = 0;
-                        while (t >= NB - I) { t -= NB - I; ++I; }
-                        const int J = I + t;
-                        iI[u] = I; iJ[u] = J; iS[u] = (item < FT_GCH * NS && i < nb) ? i : -1;
-                        if (iS[u] >= 0) {
-                            const R* yt = yimg + ((size_t)V.iD[i] * NQ + I * NB + J) * FT_TILE;
+                        for (int t = 0, I = 0, J = 0; t < NS; ++t) {  // every load of the block row first ...
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) a[u][r] = yt[TT::row(g, r) * 16 + c];
-                            if (J == cn) {                             // uniform; the loads themselves are unconditional
+                            for (int r = 0; r < 4; ++r) a[t][r] = yd[(size_t)(I * NB + J) * FT_TILE + TT::row(g, r) * 16 + c];
+                            if (J == cn) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = 16 * I + TT::row(g, r);
                                     const R yr = (R)yv[i * n + (row < n ? row : n - 1)];
-                                    a[u][r] = c == nl ? (row < n ? yr : (R)0) : a[u][r];
+                                    a[t][r] = c == nl ? (row < n ? yr : (R)0) : a[t][r];
+                                }
+                            }
+                            if (++J == NB) { ++I; J = I; }
+                        }
+                        if (i < T) {
+                            const R* wl = sWL + wv * mb * 16;
+                            for (int kb = 0; kb < mb; ++kb) {
+                                R x[NB][4], zw[NB][4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const R wk = wl[16 * kb + 4 * r + g];
+#pragma unroll
+                                    for (int J = 0; J < NB; ++J) {
+                                        x[J][r] = sBT[(size_t)(kb * NB + J) * FT_TILE + 64 * r + lane];
+                                        zw[J][r] = x[J][r] * wk;
+                                    }
+                                }
+#pragma unroll
+                                for (int t = 0, I = 0, J = 0; t < NS; ++t) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) a[t] = TT::mfma(x[I][r], zw[J][r], a[t]);
+                                    if (++J == NB) { ++I; J = I; }
                                 }
                             }
                         }
-                    }
-                    if (i0 + FT_GCH < nb) wload(i0 + FT_GCH);
 #pragma unroll
-                    for (int u = 0; u < IPW; ++u) {                    // ... then the products and the stores
-                        if (iS[u] >= 0) {
-                            const int i = iS[u], I = iI[u], J = iJ[u];
-                            if (i < T) {
-                                const R* wl = sWL + (i - i0) * mb * 16;
-#pragma unroll 3
-                                for (int kb = 0; kb < mb; ++kb) {
-                                    const R* X = sBT + (size_t)(kb * NB + I) * FT_TILE;
-                                    const R* Z = sBT + (size_t)(kb * NB + J) * FT_TILE;
+                        for (int t = 0; t < NS; ++t) {                 // ... the stores last
+                            R* dst = gws + ((size_t)i * NS + t) * FT_TILE;
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r)
-                                        a[u] = TT::mfma(X[64 * r + lane], Z[64 * r + lane] * wl[16 * kb + 4 * r + g], a[u]);
-                                }
-                            }
-                            R* dst = gws + ((size_t)i * NS + ft_lt_index(NB, I, J)) * FT_TILE;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dst[TT::row(g, r) * 16 + c] = a[u][r];
+                            for (int r = 0; r < 4; ++r) dst[TT::row(g, r) * 16 + c] = a[t][r];
                         }
                     }
                 }
@@ -610,7 +658,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         }
                         if (sI[sl] == kb && sJ[sl] == kb) {
                             v4 Ro, Wo;
-                            const bool ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
+                            __builtin_amdgcn_s_setprio(3);             // a chain of dependent steps: issue ahead of the SIMD's other wave
+                            bool ok;
+                            if (kb < NB - 1) ok = ft_potrf16_ct<R, 16>(aS[sl], c, g, Ro, Wo);        // (all blocks but the last are full)
+                            else if (NL >= 0) ok = ft_potrf16_ct<R, (NL >= 0 ? NL : 0)>(aS[sl], c, g, Ro, Wo);
+                            else ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
+                            __builtin_amdgcn_s_setprio(0);
                             if (!ok && lane == 0) sflag[0] = 1;
                             R* ri = facs + (size_t)(kb * REC_TILES) * FT_TILE;   // R(kb,kb)^-1 = W' for the backward sweep
 #pragma unroll
@@ -708,14 +761,15 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 constexpr int RPT = NT >= 256 ? 1 : 256 / NT;          // tile rows per thread (128 threads: rows ta, ta + 8)
                 constexpr int RSTEP = 16 / RPT;
                 constexpr int MAXT = (REC_TILES - 1 + NG - 1) / NG;    // tiles 1 .. 3 NB - 1 of a record, dealt to the groups
-                constexpr int PD = 2;                                  // records in flight
                 const int tg = tid >> 8, ta = (tid >> 4) & (RSTEP - 1), tb = tid & 15;
                 for (int q = tid; q < 3 * NP; q += NT) sXV[q] = (R)0;
                 for (int q = tid; q < NUROWS * LDN; q += NT) sNU[q] = 0.0;   // d_nu as [stage][state] for P5 (the U slots are dead)
-                R buf[PD][MAXT][RPT], briv[PD][RPT], byb[PD];
-                // every load unconditional, at a constant offset from the record: tile 1 + tg + q NG (clamped), RI = tile 0
-                auto fetch = [&](int blk, R (&tv)[MAXT][RPT], R (&riv)[RPT], R& yb) {
+                __syncthreads();
+                for (int blk = nb * NB - 1; blk >= 0; --blk) {
+                    const int i = blk / NB, kb = blk - i * NB;
+                    // every load unconditional, at a constant offset from the record: tile 1 + tg + q NG (clamped), RI = tile 0
                     const R* rec = fac + (size_t)blk * REC_TILES * FT_TILE + ta * 16 + tb;
+                    R tv[MAXT][RPT], riv[RPT];
 #pragma unroll
                     for (int q = 0; q < MAXT; ++q) {
                         const int t = 1 + tg + q * NG;
@@ -725,58 +779,44 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     }
 #pragma unroll
                     for (int h = 0; h < RPT; ++h) riv[h] = rec[RSTEP * h * 16];
-                    const int i = blk / NB, kb = blk - i * NB;
                     const int yrow = 16 * kb + tb;
-                    yb = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
-                };
-                __syncthreads();
-                const int top = nb * NB - 1;
+                    const R ybv = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
+                    R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+                    R accv[RPT];
 #pragma unroll
-                for (int d = 0; d < PD; ++d) fetch(top - d >= 0 ? top - d : 0, buf[d], briv[d], byb[d]);
-                for (int blk0 = top; blk0 >= 0; blk0 -= PD) {
+                    for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
 #pragma unroll
-                    for (int d = 0; d < PD; ++d) {
-                        const int blk = blk0 - d;
-                        if (blk >= 0) {                                // uniform
-                            const int i = blk / NB, kb = blk - i * NB;
-                            R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
-                            R accv[RPT];
+                    for (int q = 0; q < MAXT; ++q) {
+                        const int t = 1 + tg + q * NG;             // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
+                        const int tc = t < REC_TILES ? t : REC_TILES - 1;
+                        const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                        const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
+                        const R xraw = xvv[tb];                    // (unconditional: always a valid LDS address)
+                        const R xb = use ? xraw : (R)0;
 #pragma unroll
-                            for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
+                        for (int h = 0; h < RPT; ++h) accv[h] += (use ? tv[q][h] : (R)0) * xb;
+                    }
 #pragma unroll
-                            for (int q = 0; q < MAXT; ++q) {
-                                const int t = 1 + tg + q * NG;         // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
-                                const int tc = t < REC_TILES ? t : REC_TILES - 1;
-                                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
-                                const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
-                                const R xb = use ? xvv[tb] : (R)0;
+                    for (int h = 0; h < RPT; ++h) {
+                        accv[h] = ft_row16_sum<R>(accv[h]);
+                        if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
+                    }
+                    ft_lds_barrier();
+                    if (tg == 0) {
+                        R sb = yrow < n ? ybv : (R)0;
 #pragma unroll
-                                for (int h = 0; h < RPT; ++h) accv[h] += (use ? buf[d][q][h] : (R)0) * xb;
+                        for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
+#pragma unroll
+                        for (int h = 0; h < RPT; ++h) {
+                            const R xv = ft_row16_sum<R>(riv[h] * sb);
+                            if (tb == 0) {
+                                const int lr = ta + RSTEP * h;
+                                XC[16 * kb + lr] = xv;
+                                if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
                             }
-#pragma unroll
-                            for (int h = 0; h < RPT; ++h) {
-                                accv[h] = ft_row16_sum<R>(accv[h]);
-                                if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
-                            }
-                            ft_lds_barrier();
-                            if (tg == 0) {
-                                R sb = 16 * kb + tb < n ? byb[d] : (R)0;
-#pragma unroll
-                                for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
-#pragma unroll
-                                for (int h = 0; h < RPT; ++h) {
-                                    const R xv = ft_row16_sum<R>(briv[d][h] * sb);
-                                    if (tb == 0) {
-                                        const int lr = ta + RSTEP * h;
-                                        XC[16 * kb + lr] = xv;
-                                        if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
-                                    }
-                                }
-                            }
-                            ft_lds_barrier();
-                            fetch(blk - PD >= 0 ? blk - PD : 0, buf[d], briv[d], byb[d]);
                         }
                     }
+                    ft_lds_barrier();
                 }
             }
             __syncthreads();
@@ -870,18 +910,25 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 }
 
 // ---------------------------------------------------------------- host side
-template <typename R, int NB, int NW>
+template <typename R, int NB, int NW, int NL = -1>
 static hipError_t ft_launch(const FtParams& P, int grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((fmpc_newton_tiled<R, NB, NW>), dim3(grid), dim3(NW * 64), lds, stream, P);
+    hipLaunchKernelGGL((fmpc_newton_tiled<R, NB, NW, NL>), dim3(grid), dim3(NW * 64), lds, stream, P);
     return hipGetLastError();
 }
-template <typename R, int NB, int NW>
+template <typename R, int NB, int NW, int NL = -1>
 static hipError_t ft_prepare(size_t lds) {
-    return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 // instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5); NW wavefronts per problem
 #define FT_DISPATCH(fn, ...)                                                                   \
+    /* the AO sizes (n = 27 Zernike modes; n = 65: radial order 10) with their block structure at compile time */ \
+    if (!is_float && nlast == 11 && NB == 2 && NW == 2) return fn<double, 2, 2, 11>(__VA_ARGS__);  \
+    if (!is_float && nlast == 11 && NB == 2 && NW == 4) return fn<double, 2, 4, 11>(__VA_ARGS__);  \
+    if (is_float && nlast == 11 && NB == 2 && NW == 2) return fn<float, 2, 2, 11>(__VA_ARGS__);    \
+    if (is_float && nlast == 11 && NB == 2 && NW == 4) return fn<float, 2, 4, 11>(__VA_ARGS__);    \
+    if (is_float && nlast == 1 && NB == 5 && NW == 8) return fn<float, 5, 8, 1>(__VA_ARGS__);      \
+    if (is_float && nlast == 1 && NB == 5 && NW == 4) return fn<float, 5, 4, 1>(__VA_ARGS__);      \
     if (!is_float) {                                                                           \
         if (NB == 1 && NW == 2) return fn<double, 1, 2>(__VA_ARGS__);                          \
         if (NB == 2 && NW == 2) return fn<double, 2, 2>(__VA_ARGS__);                          \
@@ -926,7 +973,15 @@ bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* N
     return true;
 }
 size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total; }
-hipError_t fmpc_tiled_prepare(int NB, int NW, int is_float, size_t lds_bytes) { FT_DISPATCH(ft_prepare, lds_bytes) }
+static int ft_nlast(int n, int NB) {
+    const char* e = getenv("FMPC_TILED_GENERIC");                 // experiments: the instance with the block structure at run time
+    return (e && e[0] == '1') ? -1 : n - 16 * (NB - 1);
+}
+hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes) {
+    const int nlast = ft_nlast(n, NB);
+    FT_DISPATCH(ft_prepare, lds_bytes)
+}
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream) {
+    const int nlast = ft_nlast(P.M.n, NB);
     FT_DISPATCH(ft_launch, P, grid, lds_bytes, stream)
 }

@@ -13,7 +13,6 @@
 
 #define FT_TILE 256                      // elements of a 16 x 16 tile, row-major, no padding
 #define FT_MAX_NB 5                      // n <= 79
-#define FT_GCH 2                         // stages per chunk of the G pre-pass
 #define FT_WLD 17                        // leading dimension of the transposed inverse diagonal factor in LDS
 
 // The factor stream (HBM workspace) is a sequence of fixed-size RECORDS, one per 16-row block (i, kb), 3 NB tiles each,
@@ -80,10 +79,10 @@ __host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, in
     if (nu_bytes > o) o = nu_bytes;
     o = (o + 15) & ~(size_t)15;
     // outside the shared region: the x vectors of the backward sweep (live while d_nu is written to the staging area),
-    // the Phi^-1 diagonal of FT_GCH stages during the G pre-pass
+    // the Phi^-1 diagonal of NW stages during the S pre-pass
     L.xv = o;   o += 3 * (size_t)16 * NB * real_bytes;
     L.part = o; o += (size_t)(NW / 4 > 0 ? NW / 4 : 1) * 16 * real_bytes;
-    L.wl = o;   o += (size_t)FT_GCH * mb * 16 * real_bytes;
+    L.wl = o;   o += (size_t)NW * mb * 16 * real_bytes;     // the pre-pass works on NW block rows (one per wave) at a time
     o = (o + 15) & ~(size_t)15;
     L.red = o;  o += 16 * sizeof(double);
     L.flag = o; o += 16;
@@ -105,5 +104,5 @@ struct FtParams {
 // supported (type, NB) pairs
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out);
 size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb);
-hipError_t fmpc_tiled_prepare(int NB, int NW, int is_float, size_t lds_bytes);
+hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes);
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream);

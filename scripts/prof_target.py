@@ -1,0 +1,38 @@
+"""One workload, a few launches, for rocprofv3 (scripts/prof_round2.sh):  python3 scripts/prof_target.py <target> [reps]
+  headline        configs[1]: 2000 problems, cold start, n_newton 1 (panel path)
+  general_wave    2000 problems from an explicit start, n_newton 1: fmpc_newton_wave<27>
+  general_tiled   the same through fmpc_newton_tiled<double,2,NW>
+  tiled_f32       the same with the fp32 factor
+  configs4        n = 65, T = 60, batch 1024, fp32 factor: fmpc_newton_tiled<float,5,8>
+  batch512        configs[2]: 512 problems, cold start"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+target = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if target in ("general_tiled", "tiled_f32"):
+    os.environ["FMPC_TILED"] = "1"
+import numpy as np, torch
+pkg = importlib.import_module("mpc-sensorlessao_amd")
+dev = torch.device("cuda:0")
+n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target == "batch512" else 2000)
+model = pkg.synthetic.make_model(n, m, T)
+data = pkg.synthetic.make_replay_batch(model, r=0, steps=B)
+h = pkg.FastMPCHandle(model["A1"], model["A2"], model["B"], model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"],
+                      model["x_min"], model["x_max"], T)
+if target == "tiled_f32":
+    h.set_precision("f32")
+x0 = torch.from_numpy(data["x0"]).to(dev); x0p = torch.from_numpy(data["x0_pre"]).to(dev); nu0 = torch.from_numpy(data["nu0"]).to(dev)
+zi = None
+if target in ("general_wave", "general_tiled", "tiled_f32"):
+    zc = np.tile(np.concatenate([(model["u_min"] + model["u_max"]) / 2, (model["x_min"] + model["x_max"]) / 2]), T)
+    zi = torch.from_numpy(np.tile(zc, (B, 1))).to(dev)
+z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
+st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev)
+u0 = torch.empty((B, m), dtype=torch.float64, device=dev)
+for _ in range(reps):
+    h.solve_device(x0, x0p, None, zi, nu0, 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
+torch.cuda.synchronize()
+assert int((st < 0).sum()) == 0
+print(target, "path", h.last_dispatch(), "iters", int(it.sum()))
+h.close()
