@@ -263,7 +263,7 @@ def main():
         fl_unit = flops_per_problem_factor(n, m, T)
         cand = {}
         for name, env, prec in (("fmpc_newton_wave<27>", {}, None),
-                                ("fmpc_newton_tiled<double,2,2>", {"FMPC_TILED": "1"}, None)):
+                                ("fmpc_newton_tiled<double,2,2,11>", {"FMPC_TILED": "1"}, None)):
             hg = make_handle(env=env, prec=prec)
             rp = Replay(hg, x0, x0p, nu0, 1, z_init=zi)                  # one Newton step: every problem factors exactly once
             e_, s_, k_ = timed(rp.step, max(5, args.steps // 20), 2)

@@ -60,11 +60,22 @@ def test_tiled_fp64_demo_sizes(pkg, gpu, tiled_env, n, m, T, xf, var):
     _compare64(pkg, model, data, 5, 0.01)
 
 
+@pytest.mark.parametrize("waves", [2, 4])
 @pytest.mark.parametrize("T,nw", [(2, 1), (10, 5), (30, 1), (30, 5)])
-def test_tiled_fp64_ao_config(pkg, gpu, tiled_env, T, nw):
-    model = pkg.synthetic.make_model(27, 144, T)
-    data = pkg.synthetic.make_replay_batch(model, r=1, steps=40)
-    _compare64(pkg, model, data, nw, 1e-2)
+def test_tiled_fp64_ao_config(pkg, gpu, tiled_env, T, nw, waves):
+    """n = 27 (compile-time block structure 16 + 11) with 2 and with 4 wavefronts per problem: different instances of the
+    kernel (FMPC_TILED_NW is read when the handle is created)."""
+    old = os.environ.get("FMPC_TILED_NW")
+    os.environ["FMPC_TILED_NW"] = str(waves)
+    try:
+        model = pkg.synthetic.make_model(27, 144, T)
+        data = pkg.synthetic.make_replay_batch(model, r=1, steps=40)
+        _compare64(pkg, model, data, nw, 1e-2)
+    finally:
+        if old is None:
+            os.environ.pop("FMPC_TILED_NW", None)
+        else:
+            os.environ["FMPC_TILED_NW"] = old
 
 
 def test_tiled_fp64_tight_bounds_and_warm_start(pkg, gpu, tiled_env):
@@ -128,9 +139,11 @@ def test_tiled_fp32_ao_config(pkg, gpu, nw):
     print(f"fp32 factor, n=27 T=30 nw={nw}: max rel err on z {err:.2e}")
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("nw", [1, 3])
-def test_tiled_fp32_config4_n65_T60(pkg, gpu, nw):
+def test_tiled_fp32_config4_n65_T60(pkg, gpu, nw, waves, monkeypatch):
     """BASELINE configs[4]: VAR(2), n = 65 (radial order 10), T = 60, fp32 mixed precision."""
+    monkeypatch.setenv("FMPC_TILED_NW", str(waves))
     model = pkg.synthetic.make_model(65, 144, 60)
     data = pkg.synthetic.make_replay_batch(model, r=4, steps=6)
     h = handle_from_model(pkg, model)
