@@ -177,3 +177,19 @@ def test_precision_switch_errors(pkg, gpu):
     with pytest.raises(pkg.FastMPCError) as e:
         handle_from_model(pkg, model)
     assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+
+
+def test_tiled_repeated_solves_alternating_wave_counts(pkg, gpu, tiled_env, monkeypatch):
+    """Fresh handles (fresh, dirty workspaces) again and again, alternating the kernel instance: every solve must agree with
+    the oracle -- catches state carried between launches and sporadic races that one solve per test would miss."""
+    for T in (2, 10):
+        model = pkg.synthetic.make_model(27, 144, T)
+        data = pkg.synthetic.make_replay_batch(model, r=1, steps=40)
+        zo, _, ito, sto, _ = oracle_batch(model, data, 2, 1e-2)
+        for rep in range(4):
+            for waves in ("2", "4"):
+                monkeypatch.setenv("FMPC_TILED_NW", waves)
+                z, info, path = _solve(pkg, model, data, 2, 1e-2)
+                assert path == pkg._lib.FMPC_PATH_TILED
+                assert np.array_equal(info["status"], sto) and np.array_equal(info["iters"], ito), (T, rep, waves)
+                assert max(rel_err(z[p], zo[p]) for p in range(40)) <= TOL64, (T, rep, waves)
