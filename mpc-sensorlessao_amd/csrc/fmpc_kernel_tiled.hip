@@ -243,6 +243,156 @@ __device__ __forceinline__ bool ft_potrf16_ct(const typename FtT<R>::v4& P, int 
 // upper-triangular tile enumeration (row-major, I <= J)
 __device__ __forceinline__ int ft_lt_index(int NB, int I, int J) { return I * NB - (I * (I - 1)) / 2 + (J - I); }
 
+// P4 as a function of its own (not inlined): the backward sweep needs few registers, but inside the kernel body it
+// inherits the register pressure of the factor phase and its loads get spilled addresses with full waits in front.
+template <typename R, int NB, int NW>
+__device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV, R* sPART, double* sNU, int n, int nb, int NUROWS) {
+    constexpr int NT = NW * 64, NP = 16 * NB, NQ = NB * NB, REC_TILES = 3 * NB, LDN = 16 * NB + 1;
+    (void)NQ;
+    const int tid = threadIdx.x;
+    constexpr int NG = NT >= 256 ? NT / 256 : 1;           // tile groups working on different tiles
+    constexpr int RPT = NT >= 256 ? 1 : 256 / NT;          // tile rows per thread (128 threads: rows ta, ta + 8)
+    constexpr int RSTEP = 16 / RPT;
+    constexpr int MAXT = (REC_TILES - 1 + NG - 1) / NG;    // tiles 1 .. 3 NB - 1 of a record, dealt to the groups
+    const int tg = tid >> 8, ta = (tid >> 4) & (RSTEP - 1), tb = tid & 15;
+    for (int q = tid; q < 3 * NP; q += NT) sXV[q] = (R)0;
+    for (int q = tid; q < NUROWS * LDN; q += NT) sNU[q] = 0.0;   // d_nu as [stage][state] for P5 (the U slots are dead)
+    __syncthreads();
+    if (NB > 2) {
+        // one record (block row) per iteration.  (This plain form is what the compiler handles best for the large
+        // blocks: 0.96 M cycles per problem at (65, 144, 60) against 1.4 - 3.7 M for the grouped loop below.)
+        for (int blk = nb * NB - 1; blk >= 0; --blk) {
+            const int i = blk / NB, kb = blk - i * NB;
+            const R* rec = fac + (size_t)blk * REC_TILES * FT_TILE + ta * 16 + tb;
+            R tv[MAXT][RPT], riv[RPT];
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                const int t = 1 + tg + q * NG;
+                const int tc = t < REC_TILES ? t : REC_TILES - 1;
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) tv[q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
+            }
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) riv[h] = rec[RSTEP * h * 16];
+            const int yrow = 16 * kb + tb;
+            const R ybv = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
+            R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+            R accv[RPT];
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                const int t = 1 + tg + q * NG;
+                const int tc = t < REC_TILES ? t : REC_TILES - 1;
+                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                const bool use = t < REC_TILES && (t >= NB || t > kb);
+                const R xraw = xvv[tb];
+                const R xb = use ? xraw : (R)0;
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) accv[h] += (use ? tv[q][h] : (R)0) * xb;
+            }
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) {
+                accv[h] = ft_row16_sum<R>(accv[h]);
+                if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
+            }
+            ft_lds_barrier();
+            if (tg == 0) {
+                R sb = yrow < n ? ybv : (R)0;
+#pragma unroll
+                for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) {
+                    const R xv = ft_row16_sum<R>(riv[h] * sb);
+                    if (tb == 0) {
+                        const int lr = ta + RSTEP * h;
+                        XC[16 * kb + lr] = xv;
+                        if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
+                    }
+                }
+            }
+            ft_lds_barrier();
+        }
+    } else {
+    // KBB records (block rows) are requested together: the whole stage for small blocks (one memory round trip per
+    // stage instead of one per block row), one at a time where a stage's tiles would not fit the registers
+    constexpr int KBB = NB <= 2 ? NB : 1;
+    for (int grp = nb * (NB / KBB) - 1; grp >= 0; --grp) {
+        const int i = grp / (NB / KBB), kb0 = (grp - i * (NB / KBB)) * KBB;
+        // every load unconditional, at a constant offset from the record: tile 1 + tg + q NG (clamped), RI = tile 0
+        R tv[KBB][MAXT][RPT], riv[KBB][RPT], ybv[KBB];
+#pragma unroll
+        for (int kk = 0; kk < KBB; ++kk) {
+            const int kb = kb0 + kk;
+            // (the element offset is made opaque: left to itself the compiler strength-reduces one 64-bit address per
+            //  load into loop-carried registers, spills them, and reloads each -- with a full wait -- before its load)
+            unsigned off = (unsigned)(i * NB + kb) * (unsigned)(REC_TILES * FT_TILE) + (unsigned)(ta * 16 + tb);
+            asm volatile("" : "+v"(off));
+            const R* rec = fac + off;
+            const R* rtg = rec + tg * FT_TILE;               // this thread group's first tile is 1 + tg: constant strides from here
+            constexpr bool EXACT = (REC_TILES - 1) % NG == 0;   // no group runs past the record: no clamping
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                if (EXACT) {
+#pragma unroll
+                    for (int h = 0; h < RPT; ++h) tv[kk][q][h] = rtg[(1 + q * NG) * FT_TILE + RSTEP * h * 16];
+                } else {
+                    const int t = 1 + tg + q * NG;
+                    const int tc = t < REC_TILES ? t : REC_TILES - 1;
+#pragma unroll
+                    for (int h = 0; h < RPT; ++h) tv[kk][q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) riv[kk][h] = rec[RSTEP * h * 16];
+            const int yrow = 16 * kb + tb;
+            ybv[kk] = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
+        }
+        R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+#pragma unroll
+        for (int kk = KBB - 1; kk >= 0; --kk) {
+            const int kb = kb0 + kk;
+            R accv[RPT];
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                const int t = 1 + tg + q * NG;         // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
+                const int tc = t < REC_TILES ? t : REC_TILES - 1;
+                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
+                const R xraw = xvv[tb];                // (unconditional: always a valid LDS address)
+                const R xb = use ? xraw : (R)0;
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) accv[h] += (use ? tv[kk][q][h] : (R)0) * xb;
+            }
+#pragma unroll
+            for (int h = 0; h < RPT; ++h) {
+                accv[h] = ft_row16_sum<R>(accv[h]);
+                if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
+            }
+            ft_lds_barrier();
+            if (tg == 0) {
+                R sb = 16 * kb + tb < n ? ybv[kk] : (R)0;
+#pragma unroll
+                for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) {
+                    const R xv = ft_row16_sum<R>(riv[kk][h] * sb);
+                    if (tb == 0) {
+                        const int lr = ta + RSTEP * h;
+                        XC[16 * kb + lr] = xv;
+                        if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
+                    }
+                }
+            }
+            ft_lds_barrier();
+        }
+    }
+    }
+
+}
+
 // NL: live rows of the last 16-row block of a stage, n - 16 (NB - 1), when known at compile time (the AO sizes), else -1
 template <typename R, int NB, int NW, int NL>
 __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
@@ -312,6 +462,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
         __syncthreads();
         FT_T0();
         // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
+#pragma unroll 8
         for (int idx = tid; idx < Nz; idx += NT) {
             const int e = idx % s;
             zp[idx] = P.zinit ? P.zinit[(size_t)p * Nz + idx] : (e < m ? M.umid[e] : M.xmid[e - m]);
@@ -321,10 +472,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             const int i = idx / n, r = idx - i * n;
             double v = (i < T && P.w) ? P.w[(size_t)p * T * n + idx] : 0.0;
             if (i == 0) {
+#pragma unroll 9
                 for (int q = 0; q < n; ++q) v += M.A1t[q * n + r] * x0v[q];
-                if (var2 && x0pv)
+                if (var2 && x0pv) {
+#pragma unroll 9
                     for (int q = 0; q < n; ++q) v += M.A2t[q * n + r] * x0pv[q];
+                }
             } else if (i == 1 && i < T && var2) {
+#pragma unroll 9
                 for (int q = 0; q < n; ++q) v += M.A2t[q * n + r] * x0v[q];
             }
             if (i == T) v = M.xf[r];
@@ -525,6 +680,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         }
                         if (i < T) {
                             const R* wl = sWL + wv * mb * 16;
+#pragma unroll 3
                             for (int kb = 0; kb < mb; ++kb) {
                                 R x[NB][4], zw[NB][4];
 #pragma unroll
@@ -765,75 +921,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // block at a time from the bottom: x_kb = RI(kb) (y_kb - sum of tile x vector products).  16 consecutive threads
             // read a tile row (coalesced) and sum over it by DPP; the tiles of the NEXT block row are requested before the
             // current one is reduced.  x of stage i lives in buffer i % 3.
-            {
-                constexpr int NG = NT >= 256 ? NT / 256 : 1;           // tile groups working on different tiles
-                constexpr int RPT = NT >= 256 ? 1 : 256 / NT;          // tile rows per thread (128 threads: rows ta, ta + 8)
-                constexpr int RSTEP = 16 / RPT;
-                constexpr int MAXT = (REC_TILES - 1 + NG - 1) / NG;    // tiles 1 .. 3 NB - 1 of a record, dealt to the groups
-                const int tg = tid >> 8, ta = (tid >> 4) & (RSTEP - 1), tb = tid & 15;
-                for (int q = tid; q < 3 * NP; q += NT) sXV[q] = (R)0;
-                for (int q = tid; q < NUROWS * LDN; q += NT) sNU[q] = 0.0;   // d_nu as [stage][state] for P5 (the U slots are dead)
-                __syncthreads();
-                for (int i = nb - 1; i >= 0; --i) {
-                    // all NB records of the stage are requested up front: one memory round trip per stage, not per block row.
-                    // Every load is unconditional, at a constant offset from the record: tile 1 + tg + q NG (clamped), RI = tile 0
-                    R tv[NB][MAXT][RPT], riv[NB][RPT], ybv[NB];
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) {
-                        const R* rec = fac + ((size_t)i * NB + kb) * REC_TILES * FT_TILE + ta * 16 + tb;
-#pragma unroll
-                        for (int q = 0; q < MAXT; ++q) {
-                            const int t = 1 + tg + q * NG;
-                            const int tc = t < REC_TILES ? t : REC_TILES - 1;
-#pragma unroll
-                            for (int h = 0; h < RPT; ++h) tv[kb][q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
-                        }
-#pragma unroll
-                        for (int h = 0; h < RPT; ++h) riv[kb][h] = rec[RSTEP * h * 16];
-                        const int yrow = 16 * kb + tb;
-                        ybv[kb] = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
-                    }
-                    R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
-#pragma unroll
-                    for (int kb = NB - 1; kb >= 0; --kb) {
-                        R accv[RPT];
-#pragma unroll
-                        for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
-#pragma unroll
-                        for (int q = 0; q < MAXT; ++q) {
-                            const int t = 1 + tg + q * NG;         // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
-                            const int tc = t < REC_TILES ? t : REC_TILES - 1;
-                            const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
-                            const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
-                            const R xraw = xvv[tb];                // (unconditional: always a valid LDS address)
-                            const R xb = use ? xraw : (R)0;
-#pragma unroll
-                            for (int h = 0; h < RPT; ++h) accv[h] += (use ? tv[kb][q][h] : (R)0) * xb;
-                        }
-#pragma unroll
-                        for (int h = 0; h < RPT; ++h) {
-                            accv[h] = ft_row16_sum<R>(accv[h]);
-                            if (tb == 0) sPART[tg * 16 + ta + RSTEP * h] = accv[h];
-                        }
-                        ft_lds_barrier();
-                        if (tg == 0) {
-                            R sb = 16 * kb + tb < n ? ybv[kb] : (R)0;
-#pragma unroll
-                            for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
-#pragma unroll
-                            for (int h = 0; h < RPT; ++h) {
-                                const R xv = ft_row16_sum<R>(riv[kb][h] * sb);
-                                if (tb == 0) {
-                                    const int lr = ta + RSTEP * h;
-                                    XC[16 * kb + lr] = xv;
-                                    if (16 * kb + lr < n) sNU[i * LDN + 16 * kb + lr] = (double)xv;
-                                }
-                            }
-                        }
-                        ft_lds_barrier();
-                    }
-                }
-            }
+            ft_backward<R, NB, NW>(fac, yv, sXV, sPART, sNU, n, nb, NUROWS);
             __syncthreads();
             FT_TICK(7);
 
@@ -902,9 +990,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     if (++halv >= FT_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
             }
+#pragma unroll 8
             for (int idx = tid; idx < Nz; idx += NT) {
                 const int j = idx / s, e = idx - j * s;
-                zp[idx] += t * (e < m ? rdu[j * m + e] : rdx[j * n + e - m]);
+                const double dv = e < m ? rdu[j * m + e] : rdx[j * n + (e < m ? 0 : e - m)];
+                zp[idx] += t * dv;
             }
             for (int idx = tid; idx < nbn; idx += NT) { const int j = idx / n; nu[idx] += t * sNU[j * LDN + idx - j * n]; }
             if (P.step && tid == 0 && it < P.step_ld) P.step[(size_t)p * P.step_ld + it] = t;
