@@ -110,6 +110,8 @@ struct fmpc_handle_s {
     double* tl_ws; size_t tl_ws_doubles;
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
+    int denseQ;                          // Q or Qf not diagonal: tiled kernel only
+    std::vector<double> hm_q2m, hm_qf2m, hm_xm, hm_xfm;   // 2Q, 2Qf, (2Q)^-1, (2Qf)^-1 row-major
     // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
     double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
     double* ramp_ws; size_t ramp_ws_doubles;
@@ -169,6 +171,58 @@ void add_AxBt(std::vector<double>& out, const std::vector<double>& A, const std:
         }
 }
 
+// inverse of a symmetric positive definite matrix (row-major n x n) by Cholesky in extended precision; false: not PD
+bool spd_inverse(const std::vector<double>& A, int n, std::vector<double>& inv) {
+    typedef long double ld;
+    std::vector<ld> L((size_t)n * n, 0.0L), Li((size_t)n * n, 0.0L);
+    for (int c = 0; c < n; ++c) {
+        ld d = A[c * n + c];
+        for (int k = 0; k < c; ++k) d -= L[c * n + k] * L[c * n + k];
+        if (!(d > 0.0L)) return false;
+        const ld l = sqrtl(d);
+        L[c * n + c] = l;
+        for (int r = c + 1; r < n; ++r) {
+            ld t = A[r * n + c];
+            for (int k = 0; k < c; ++k) t -= L[r * n + k] * L[c * n + k];
+            L[r * n + c] = t / l;
+        }
+    }
+    for (int c = 0; c < n; ++c) {                    // Li = L^-1
+        Li[c * n + c] = 1.0L / L[c * n + c];
+        for (int r = c + 1; r < n; ++r) {
+            ld t = 0.0L;
+            for (int k = c; k < r; ++k) t += L[r * n + k] * Li[k * n + c];
+            Li[r * n + c] = -t / L[r * n + r];
+        }
+    }
+    inv.assign((size_t)n * n, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b <= a; ++b) {
+            ld t = 0.0L;
+            for (int k = a; k < n; ++k) t += Li[k * n + a] * Li[k * n + b];
+            inv[a * n + b] = inv[b * n + a] = (double)t;
+        }
+    return true;
+}
+
+// out (row-major n x n) += sign * A X B'   with A, B, X row-major n x n (X dense)
+void add_AXBt(std::vector<double>& out, const std::vector<double>& A, const std::vector<double>& X,
+              const std::vector<double>& B, int n, double sign) {
+    std::vector<double> AX((size_t)n * n, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int c = 0; c < n; ++c) {
+            double t = 0.0;
+            for (int k = 0; k < n; ++k) t += A[a * n + k] * X[k * n + c];
+            AX[a * n + c] = t;
+        }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double t = 0.0;
+            for (int c = 0; c < n; ++c) t += AX[a * n + c] * B[b * n + c];
+            out[a * n + b] += sign * t;
+        }
+}
+
 }  // namespace
 
 extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
@@ -184,15 +238,22 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     if (!A1 || !B || (var_order == 2 && !A2)) return FMPC_E_NULL;   // fast_mpc_eq_const.m:19-25
     if (!Q || !R || !Qf || !x_min || !x_max || !u_min || !u_max) return FMPC_E_NULL;
     if (device < 0) return FMPC_E_NO_DEVICE;
-    if (!is_diag(Q, n) || !is_diag(Qf, n) || !is_diag(R, m)) return FMPC_E_UNSUPPORTED;
+    if (!is_diag(R, m)) return FMPC_E_UNSUPPORTED;                  // dense R: a per-stage m x m factorisation, not built
+    // dense (symmetric positive definite) Q, Qf: fast_mpc_objective.m:52-55 takes any square Q, Qf.  Handled by the
+    // tiled kernel only (the other kernels keep the state weights as diagonals).
+    const bool denseQ = !is_diag(Q, n) || !is_diag(Qf, n);
     for (int i = 0; i < n; ++i)
         if (!(cm(Q, n, i, i) > 0.0) || !(cm(Qf, n, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
     for (int i = 0; i < m; ++i)
         if (!(cm(R, m, i, i) > 0.0)) return FMPC_E_NOT_PD_PHI;
+    if (denseQ)
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < a; ++b)
+                if (cm(Q, n, a, b) != cm(Q, n, b, a) || cm(Qf, n, a, b) != cm(Qf, n, b, a)) return FMPC_E_NOT_PD_PHI;
     // per-problem-factor paths: the generic kernel (n <= 64 and its tiles fit the LDS), else the tiled kernel in fp64
     // (n <= 47), else the tiled kernel with an fp32 factor (n <= 79: "fp32 mixed precision", BASELINE configs[4])
     size_t lds = fmpc_generic_lds_bytes(n, m);
-    const bool generic_ok = n <= 64 && lds <= FMPC_LDS_LIMIT;
+    const bool generic_ok = !denseQ && n <= 64 && lds <= FMPC_LDS_LIMIT;
     const int nb_ = T + (xf ? 1 : 0);
     const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr);
     if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
@@ -241,13 +302,17 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         }
     for (int rr = 0; rr < n; ++rr)
         for (int c = 0; c < m; ++c) bt[(size_t)c * n + rr] = cm(B, n, rr, c);
-    std::vector<double> R2(m), Q2(n), Qf2(n), X(n), Xf(n);
+    std::vector<double> R2(m), Q2(n), Qf2(n);
     for (int i = 0; i < m; ++i) R2[i] = 2.0 * cm(R, m, i, i);
-    for (int i = 0; i < n; ++i) {
-        Q2[i] = 2.0 * cm(Q, n, i, i);
-        Qf2[i] = 2.0 * cm(Qf, n, i, i);
-        X[i] = 1.0 / Q2[i];
-        Xf[i] = 1.0 / Qf2[i];
+    for (int i = 0; i < n; ++i) { Q2[i] = 2.0 * cm(Q, n, i, i); Qf2[i] = 2.0 * cm(Qf, n, i, i); }
+    // X = (2Q)^-1, Xf = (2Qf)^-1 as dense row-major matrices (diagonal weights: diagonal matrices)
+    std::vector<double> Q2m(nn, 0.0), Qf2m(nn, 0.0), X(nn, 0.0), Xf(nn, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) { Q2m[a * n + b] = 2.0 * cm(Q, n, a, b); Qf2m[a * n + b] = 2.0 * cm(Qf, n, a, b); }
+    if (denseQ) {
+        if (!spd_inverse(Q2m, n, X) || !spd_inverse(Qf2m, n, Xf)) { delete h; return FMPC_E_NOT_PD_PHI; }
+    } else {
+        for (int i = 0; i < n; ++i) { X[i * n + i] = 1.0 / Q2[i]; Xf[i * n + i] = 1.0 / Qf2[i]; }
     }
     // ---- iteration-invariant Y blocks, deduplicated
     //   Yd_i = X_{i+1} + [i>=1] A1 X_i A1' + [i>=2] A2 X_{i-1} A2'
@@ -264,29 +329,26 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     };
     auto Xj = [&](int j) -> const std::vector<double>& { return j == T ? Xf : X; };
     for (int i = 0; i < T; ++i) {
-        std::vector<double> d(nn, 0.0);
-        for (int a = 0; a < n; ++a) d[a * n + a] = Xj(i + 1)[a];
-        if (i >= 1) add_AxBt(d, a1, Xj(i), a1, n, 1.0);
-        if (i >= 2 && var2) add_AxBt(d, a2, Xj(i - 1), a2, n, 1.0);
+        std::vector<double> d = Xj(i + 1);
+        if (i >= 1) add_AXBt(d, a1, Xj(i), a1, n, 1.0);
+        if (i >= 2 && var2) add_AXBt(d, a2, Xj(i - 1), a2, n, 1.0);
         idxD[i] = intern(d);
+        std::vector<double> eye(nn, 0.0);
+        for (int a = 0; a < n; ++a) eye[a * n + a] = 1.0;
         if (i + 1 < T) {
             std::vector<double> o(nn, 0.0);
-            for (int a = 0; a < n; ++a)
-                for (int b = 0; b < n; ++b) o[a * n + b] = -Xj(i + 1)[a] * a1[b * n + a];
-            if (i >= 1 && var2) add_AxBt(o, a1, Xj(i), a2, n, 1.0);
+            add_AXBt(o, eye, Xj(i + 1), a1, n, -1.0);              // -X_{i+1} A1'
+            if (i >= 1 && var2) add_AXBt(o, a1, Xj(i), a2, n, 1.0);
             idx1[i] = intern(o);
         }
         if (i + 2 < T && var2) {
             std::vector<double> o(nn, 0.0);
-            for (int a = 0; a < n; ++a)
-                for (int b = 0; b < n; ++b) o[a * n + b] = -Xj(i + 1)[a] * a2[b * n + a];
+            add_AXBt(o, eye, Xj(i + 1), a2, n, -1.0);              // -X_{i+1} A2'
             idx2[i] = intern(o);
         }
     }
     if (xf) {
-        std::vector<double> d(nn, 0.0);
-        for (int a = 0; a < n; ++a) d[a * n + a] = Xf[a];
-        idxD[T] = intern(d);
+        idxD[T] = intern(Xf);
         idx1[T - 1] = idxD[T];
     }
     // ---- pack the pool
@@ -369,6 +431,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
     h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
     h->hm_a1f = a1; h->hm_a2f = a2;
+    h->denseQ = denseQ ? 1 : 0; h->hm_q2m = Q2m; h->hm_qf2m = Qf2m; h->hm_xm = X; h->hm_xfm = Xf;
     h->hm_b.resize((size_t)n * m);
     for (int rr = 0; rr < n; ++rr)
         for (int c = 0; c < m; ++c) h->hm_b[(size_t)rr * m + c] = cm(B, n, rr, c);
@@ -376,7 +439,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // ---- wave kernel: MFMA-layout images of the constant blocks (+ a zero block), padded B'
     const char* force = getenv("FMPC_FORCE_GENERIC");
     const int mp = fmpc_wave_mp(m);
-    if (fmpc_wave_supports(n) && !(force && force[0] == '1') &&
+    if (!denseQ && fmpc_wave_supports(n) && !(force && force[0] == '1') &&
         fmpc_wave_lds_bytes(n, mp) <= FMPC_LDS_LIMIT) {
         const int stride = fmpc_wave_img_stride(n);
         const int nblk = (int)blocks.size();
@@ -913,7 +976,8 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     // zero-padded fp64 images of B', B, A1, A2, A1', A2' for the residual GEMMs
     const int NP = 16 * NB, MP = 16 * mb;
     const size_t oBt = 0, oBm = oBt + (size_t)MP * NP, oA1 = oBm + (size_t)NP * MP, oA2 = oA1 + (size_t)NP * NP,
-                 oA1t = oA2 + (size_t)NP * NP, oA2t = oA1t + (size_t)NP * NP, ptot = oA2t + (size_t)NP * NP;
+                 oA1t = oA2 + (size_t)NP * NP, oA2t = oA1t + (size_t)NP * NP, oQ2 = oA2t + (size_t)NP * NP,
+                 oQf2 = oQ2 + (size_t)NP * NP, oX = oQf2 + (size_t)NP * NP, oXf = oX + (size_t)NP * NP, ptot = oXf + (size_t)NP * NP;
     std::vector<double> pad(ptot, 0.0);
     for (int c = 0; c < m; ++c)
         for (int r = 0; r < n; ++r) {
@@ -924,6 +988,8 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
         for (int b = 0; b < n; ++b) {
             pad[oA1 + (size_t)a * NP + b] = h->hm_a1f[(size_t)a * n + b]; pad[oA1t + (size_t)b * NP + a] = h->hm_a1f[(size_t)a * n + b];
             pad[oA2 + (size_t)a * NP + b] = h->hm_a2f[(size_t)a * n + b]; pad[oA2t + (size_t)b * NP + a] = h->hm_a2f[(size_t)a * n + b];
+            pad[oQ2 + (size_t)a * NP + b] = h->hm_q2m[(size_t)a * n + b]; pad[oQf2 + (size_t)a * NP + b] = h->hm_qf2m[(size_t)a * n + b];
+            pad[oX + (size_t)a * NP + b] = h->hm_xm[(size_t)a * n + b]; pad[oXf + (size_t)a * NP + b] = h->hm_xfm[(size_t)a * n + b];
         }
     if (hipMalloc(&X.pool, img.size() * sizeof(R)) != hipSuccess ||
         hipMalloc((void**)&X.ipool, ids.size() * sizeof(int)) != hipSuccess ||
@@ -938,6 +1004,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
     X.V.iD = X.ipool; X.V.i1 = X.ipool + nb; X.V.i2 = X.ipool + 2 * nb;
     X.V.BtP = X.bm + oBt; X.V.BmP = X.bm + oBm; X.V.A1P = X.bm + oA1; X.V.A2P = X.bm + oA2; X.V.A1tP = X.bm + oA1t; X.V.A2tP = X.bm + oA2t;
+    X.V.denseQ = h->denseQ; X.V.Q2P = X.bm + oQ2; X.V.Qf2P = X.bm + oQf2; X.V.XP = X.bm + oX; X.V.XfP = X.bm + oXf;
     X.ready = 1;
     return FMPC_OK;
 }
@@ -1025,7 +1092,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
     if (batch == 0) return FMPC_OK;
     const int max_iter = n_newton > 0 ? n_newton : 1000;
     hipError_t e;
-    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || (!h->use_wave && !h->generic_ok))
+    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || (!h->use_wave && !h->generic_ok))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
     if (h->use_wave) {
@@ -1215,7 +1282,7 @@ extern "C" int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* 
     for (int c = 0; c < h->m; ++c)
         if (!(du_min[c] < du_max[c])) return FMPC_E_DIM;
     const size_t lds = fmpc_ramp_lds_bytes(h->n, h->m);
-    if (h->n > 64 || lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+    if (h->n > 64 || lds > FMPC_LDS_LIMIT || h->denseQ) return FMPC_E_UNSUPPORTED;   // (the ramp kernel keeps Q, Qf as diagonals)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->ramp_du) {
         if (hipMalloc((void**)&h->ramp_du, 2 * (size_t)h->m * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;

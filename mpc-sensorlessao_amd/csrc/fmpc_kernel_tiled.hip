@@ -550,16 +550,28 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
                                         [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
                                         [&](int k) { return V.A2P[k * NP + r]; });
+                        ft_d4 accq = {0, 0, 0, 0};                       // dense state weights: 2Q_j x_j as a product (Qf at the last stage)
+                        if (V.denseQ) {
+                            const double* xj = zp + (size_t)(jj < T ? jj : T - 1) * s + m;
+                            const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
+                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
+                                        [&](int k) { return xj[k < n ? k : n - 1] * fq; },
+                                        [&](int k) { return V.Q2P[k * NP + r]; });
+                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
+                                        [&](int k) { return xj[k < n ? k : n - 1] * fqf; },
+                                        [&](int k) { return V.Qf2P[k * NP + r]; });
+                        }
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int jo = 16 * A + g + 4 * rr;
                             if (jo < T && rok) {
                                 const bool last = jo + 1 == T;
                                 const double q2 = last ? M.Qf2[r] : M.Q2[r];
-                                double v = q2 * zp[jo * s + m + r] + (last ? M.qfl[r] : M.ql[r]) + sNU[jo * LDN + r] - acc[rr];
+                                const double qx = V.denseQ ? accq[rr] : q2 * zp[jo * s + m + r];
+                                double v = qx + (last ? M.qfl[r] : M.ql[r]) + sNU[jo * LDN + r] - acc[rr];
                                 if (last && M.has_xf) v += sNU[T * LDN + r];
                                 rdx[jo * n + r] = v;
-                                phx[jo * n + r] = v * ft_rcp(q2);              // Phi^-1 r_d on x_j
+                                phx[jo * n + r] = v * ft_rcp(q2);              // Phi^-1 r_d on x_j (dense weights: redone below)
                                 acc_d += v * v;
                             }
                         }
@@ -596,6 +608,28 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
             if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
+            if (V.denseQ) {
+                // Phi^-1 r_d on the states with dense weights: phx_j = (2Q_j)^-1 r_d[x_j], one more stage-batched product
+                for (int item = wv; item < NB * TA; item += NW) {
+                    const int Jr = item / TA, A = item - Jr * TA;
+                    const int jj = 16 * A + c, r = 16 * Jr + c;
+                    const double* rj = rdx + (size_t)(jj < T ? jj : T - 1) * n;
+                    const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
+                    ft_d4 acc = {0, 0, 0, 0};
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return rj[k < n ? k : n - 1] * fq; },
+                                [&](int k) { return V.XP[k * NP + r]; });
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return rj[k < n ? k : n - 1] * fqf; },
+                                [&](int k) { return V.XfP[k * NP + r]; });
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int jo = 16 * A + g + 4 * rr;
+                        if (jo < T && r < n) phx[jo * n + r] = acc[rr];
+                    }
+                }
+                __syncthreads();
+            }
             FT_TICK(1);
 
             // ================= P2: rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into yv)
@@ -949,7 +983,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             const bool last = jo + 1 == T;
                             double v = -rdx[jo * n + r] - sNU[jo * LDN + r] + acc[rr];
                             if (last && M.has_xf) v -= sNU[T * LDN + r];
-                            rdx[jo * n + r] = v * ft_rcp(last ? M.Qf2[r] : M.Q2[r]);   // reuse as d_x
+                            if (V.denseQ) phx[jo * n + r] = v;                                  // dense weights: d_x = (2Q_j)^-1 v below
+                            else rdx[jo * n + r] = v * ft_rcp(last ? M.Qf2[r] : M.Q2[r]);       // reuse as d_x
                         }
                     }
                 } else {
@@ -972,6 +1007,27 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             e2 += e * e;
                             rdu[idx] = du;                              // reuse as d_u
                         }
+                    }
+                }
+            }
+            if (V.denseQ) {
+                __syncthreads();
+                for (int item = wv; item < NB * TA; item += NW) {
+                    const int Jr = item / TA, A = item - Jr * TA;
+                    const int jj = 16 * A + c, r = 16 * Jr + c;
+                    const double* vj = phx + (size_t)(jj < T ? jj : T - 1) * n;
+                    const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
+                    ft_d4 acc = {0, 0, 0, 0};
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return vj[k < n ? k : n - 1] * fq; },
+                                [&](int k) { return V.XP[k * NP + r]; });
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return vj[k < n ? k : n - 1] * fqf; },
+                                [&](int k) { return V.XfP[k * NP + r]; });
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int jo = 16 * A + g + 4 * rr;
+                        if (jo < T && r < n) rdx[jo * n + r] = acc[rr];                       // d_x
                     }
                 }
             }

@@ -38,6 +38,10 @@ struct FtModel {
     const double* BmP;      // [16 NB][16 mb]: BmP[r*MP + c] = B[r][c]
     const double* A1P; const double* A2P;       // [16 NB][16 NB] row-major A1, A2
     const double* A1tP; const double* A2tP;     // and their transposes
+    int denseQ;             // Q or Qf not diagonal (fast_mpc_objective.m:52-55 takes any square Q, Qf): the state part of Phi and of
+                            // Phi^-1 are then applied as products with these symmetric [16 NB][16 NB] images
+    const double* Q2P; const double* Qf2P;      // 2Q, 2Qf
+    const double* XP; const double* XfP;        // (2Q)^-1, (2Qf)^-1
 };
 
 // Per-workgroup scratch in HBM.  Vectors in doubles, then the factor stream in REAL.

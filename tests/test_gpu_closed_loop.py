@@ -61,6 +61,32 @@ def test_closed_loop_with_ramp_rows(pkg, gpu, n, m, T, nw, var_order):
     h.close()
 
 
+def test_config0_200_sequential_steps_with_ramp_rows(pkg, gpu):
+    """BASELINE configs[0] as the reference runs it: VAR(1), n = 27, m = 144, T = 10, ramp-rate rows on, 200 SEQUENTIAL
+    timesteps of one realisation (every step's u_prev is the previous first move).  Oracle: the dense restatement step by
+    step (about 0.5 s of host BLAS per step)."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10, var_order=1)
+    steps = 200
+    a = pkg.synthetic.make_realisation(md, r=0, steps=steps)[1:steps + 1][:, None, :]
+    du = 0.2121 * np.ones(144)
+    h = handle_from_model(pkg, md)
+    h.set_ramp(-du, du)
+    loop = pkg.ClosedLoop(h, 1, n_newton=1, k=1e-2, ramp=True)
+    U0, X0 = loop.run(torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    U0, X0 = U0.cpu().numpy()[:, 0], X0.cpu().numpy()[:, 0]
+    assert int((loop.status < 0).sum()) == 0 and h.last_dispatch()[0] == pkg.FMPC_PATH_RAMP
+    ref = closed_loop(md, a[:, 0], 1, 1e-2, ramp=(-du, du))
+    # per step (the loop feeds its own first moves back, so the comparison is over the whole trajectory).  Steps whose line
+    # search collapses (quirk D2: the reference ends at t ~ 2^-50, the device at exactly 0 with FMPC_W_LINESEARCH) leave
+    # u0 at the mid-box start on both sides up to ~1e-16: absolute floor 1e-9 rad
+    errs = [np.abs(U0[s] - ref["u0"][s]).max() / max(np.abs(ref["u0"][s]).max(), 1e-2) for s in range(steps)]
+    assert max(errs) <= 1e-7, (int(np.argmax(errs)), max(errs))
+    assert rel_err(X0, ref["x0"]) <= 1e-8
+    h.close()
+
+
 @pytest.mark.parametrize("n,m,T", [(27, 144, 30), (27, 97, 7), (8, 5, 6)])
 def test_loop_inputs_kernel_against_numpy(pkg, gpu, n, m, T):
     """fmpc_loop_inputs_device alone (several 16-problem tiles, a ragged last one; matrix-core kernel for n = 27, the

@@ -193,3 +193,49 @@ def test_tiled_repeated_solves_alternating_wave_counts(pkg, gpu, tiled_env, monk
                 assert path == pkg._lib.FMPC_PATH_TILED
                 assert np.array_equal(info["status"], sto) and np.array_equal(info["iters"], ito), (T, rep, waves)
                 assert max(rel_err(z[p], zo[p]) for p in range(40)) <= TOL64, (T, rep, waves)
+
+
+# ------------------------------------------------------------------ dense state weights (fast_mpc_objective.m:52-55)
+def _spd(n, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, n))
+    return scale * (G @ G.T / n + np.eye(n))
+
+
+@pytest.mark.parametrize("n,m,T,xf,nw,umax", [(8, 5, 10, False, 5, 2.0), (8, 5, 10, True, 5, 2.0), (8, 5, 10, False, 8, 0.3),
+                                              (27, 144, 10, False, 3, None), (20, 33, 5, False, 4, 2.0)])
+def test_dense_spd_state_weights(pkg, gpu, n, m, T, xf, nw, umax):
+    """Random symmetric positive definite Q and Qf (R diagonal): Phi and Phi^-1 on the states are dense blocks, the
+    constant Y blocks carry (2Q)^-1; handled by the tiled kernel whatever n.  Oracle: the structured restatement with the
+    same dense weights (pinned to the dense one in tests/test_oracle_banded.py)."""
+    if umax is None:
+        model = pkg.synthetic.make_model(n, m, T)
+        data = pkg.synthetic.make_replay_batch(model, r=6, steps=5)
+        model["Q"] = _spd(n, 1, 1.5e4); model["Qf"] = _spd(n, 2, 1.5e4)
+    else:
+        model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + T, umax=umax, xf=xf, batch=5)
+        model["Q"] = _spd(n, 1); model["Qf"] = _spd(n, 2, 50.0)
+    z, info, path = _solve(pkg, model, data, nw, 0.01)
+    assert path == pkg._lib.FMPC_PATH_TILED
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, 0.01)
+    assert np.array_equal(info["status"], sto) and np.array_equal(info["iters"], ito)
+    for p in range(5):
+        assert rel_err(z[p], zo[p]) <= TOL64, (p, rel_err(z[p], zo[p]))
+        assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p]))
+
+
+def test_dense_weights_error_codes(pkg, gpu):
+    model, data = pkg.synthetic.make_test_problem(8, 5, 4, seed=1, batch=1)
+    bad = dict(model); bad["R"] = _spd(5, 3)
+    with pytest.raises(pkg.FastMPCError) as e:
+        handle_from_model(pkg, bad)                      # dense R: a per-stage m x m factorisation, not built
+    assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    bad = dict(model); bad["Q"] = -_spd(8, 4)
+    with pytest.raises(pkg.FastMPCError) as e:
+        handle_from_model(pkg, bad)
+    assert e.value.code == pkg._lib.FMPC_E_NOT_PD_PHI
+    ind = _spd(8, 5); ind[0, 0] = 1e-3; ind[0, 1] = ind[1, 0] = 5.0      # symmetric, positive diagonal, indefinite
+    bad = dict(model); bad["Qf"] = ind
+    with pytest.raises(pkg.FastMPCError) as e:
+        handle_from_model(pkg, bad)
+    assert e.value.code == pkg._lib.FMPC_E_NOT_PD_PHI
