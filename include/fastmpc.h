@@ -253,6 +253,20 @@ int fmpc_set_precision(fmpc_handle h, int mode);
 #define FMPC_PATH_TILED_F32 6 /* tiled kernel, fp32 factor + fp64 residuals */
 int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
 
+/* FMPC_PATH_PANEL has two forms of the cold-start dual solve nu+ = Y^-1 (ct - b) (inf_newton_solver.m:27-32 at the
+ * constant start of fast_mpc_init.m:19-20): the two sweeps through the shared block factor (one CU per 16 problems,
+ * a chain of ~31 dependent steps), and the DENSE FORM nu+ = nuc + J [x0; x0_pre; w] as one product on the matrix
+ * cores, J = d nu+ / d data built once per (handle, k) from the same factor.  The dense form is taken when w == NULL
+ * (only the 56 columns of [x0; x0_pre] remain) and, with w, for batches of at most max_batch_with_w problems
+ * (default 1024; environment FMPC_INV_MAX_BATCH, FMPC_NO_INV=1 switches the form off).  Both forms agree to
+ * round-off (tests/test_gpu_dense_form.py); a result does not depend on the batch it was solved in as long as the
+ * form is the same.
+ *   fmpc_set_dense_form: enabled 0/1, max_batch_with_w < 0 keeps the bound.  FMPC_E_UNSUPPORTED if the handle has
+ *                        no panel path (n != 27).
+ *   fmpc_last_dual_form: 1 if the last solve took the dense form, 0 otherwise. */
+int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
+int fmpc_last_dual_form(fmpc_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ SIGNATURES = {
     "fmpc_solve_once": (C.c_int, [C.c_int] * 4 + [_vp] * 23 + [C.c_int, C.c_double, C.c_int, _vp, _vp]),
     "fmpc_solve_once_cache_clear": (C.c_int, []),
     "fmpc_last_dispatch": (C.c_int, [_vp, _ip, _ip]),
+    "fmpc_set_dense_form": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "fmpc_last_dual_form": (C.c_int, [_vp]),
     "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
     "fmpc_solve_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),

@@ -98,6 +98,9 @@ struct fmpc_handle_s {
     size_t pn_o_dz; int pn_dz_len;
     size_t pn_dz_lds;
     double pn_rd2_0, pn_rp2c;
+    // dense form of the cold-start dual solve (fmpc_kernel_inv.hip): nu+ = nuc + J d, built per (handle, k) on first use
+    int inv_enabled, inv_valid, inv_jks, inv_max_batch, inv_last; double inv_k;
+    double* inv_jimg; double* inv_nuc; double* inv_eimg;
     std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf, hm_blocks;
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
@@ -279,6 +282,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 1024; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -523,6 +527,17 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                 h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
                 if (xf) h->hm_xf.assign(xf, xf + n);
                 h->pn_mp = pmp; h->pn_lds = plds; h->pn_enabled = 1;
+                {   // the dense form: FMPC_NO_INV=1 switches it off, FMPC_INV_MAX_BATCH bounds its use when w is given
+                    const char* noinv = getenv("FMPC_NO_INV");
+                    const char* mb = getenv("FMPC_INV_MAX_BATCH");
+                    h->inv_enabled = !(noinv && noinv[0] == '1');
+                    if (mb && mb[0]) h->inv_max_batch = atoi(mb);
+                    h->inv_jks = FP_XKS + (T * n + 3) / 4;
+                    const size_t nrt = ((size_t)h->nb * n + 15) / 16;
+                    if (h->inv_enabled && (hipMalloc((void**)&h->inv_jimg, nrt * (size_t)(16 * ((h->inv_jks + 15) / 16 + 3)) * 64 * sizeof(double)) != hipSuccess ||
+                                           hipMalloc((void**)&h->inv_nuc, nrt * 16 * sizeof(double)) != hipSuccess ||
+                                           hipMalloc((void**)&h->inv_eimg, 4 * FP_XKS * 64 * sizeof(double)) != hipSuccess)) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                }
             }
         }
     }
@@ -542,6 +557,9 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->sh_ok) (void)hipFree(h->sh_ok);
     if (h->sh_scratch) (void)hipFree(h->sh_scratch);
     if (h->cold_d) (void)hipFree(h->cold_d);
+    if (h->inv_jimg) (void)hipFree(h->inv_jimg);
+    if (h->inv_nuc) (void)hipFree(h->inv_nuc);
+    if (h->inv_eimg) (void)hipFree(h->inv_eimg);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
     if (h->pn_sched) (void)hipFree(h->pn_sched);
@@ -1079,6 +1097,94 @@ static void fmpc_guard_end(fmpc_handle h, hipStream_t stream) {
     if (h->ev && hipEventRecord(h->ev, stream) == hipSuccess) { h->ev_valid = 1; h->last_stream = stream; }
 }
 
+// The parameter block of the panel-path kernels (constants of the handle; the per-call fields are the caller's).
+static void fmpc_panel_params(fmpc_handle h, double k, FpParams& Q) {
+    memset(&Q, 0, sizeof(Q));
+    Q.m = h->m; Q.mp = h->pn_mp; Q.T = h->T; Q.nb = h->nb; Q.has_xf = h->has_xf; Q.var2 = h->var_order == 2 ? 1 : 0;
+    Q.simg = h->pn_pool + h->pn_o_simg; Q.limg = h->pn_pool + h->pn_o_limg;
+    Q.sched_f = h->pn_sched; Q.sched_b = h->pn_sched + (size_t)FP_MAX_STEPS(h->nb) * FP_STEP_INTS; Q.nsf = h->pn_nsf; Q.nsb = h->pn_nsb;
+    Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
+    Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
+    Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
+    Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
+    Q.kbar = k;
+    Q.jimg = h->inv_jimg; Q.nuc = h->inv_nuc; Q.jks = h->inv_jks; Q.jksp = 16 * ((h->inv_jks + 15) / 16 + 3); Q.eimg = h->inv_eimg;
+}
+
+// J and nuc of the dense form (fmpc_kernel_inv.hip) for barrier weight k: the panel kernel itself solves for the unit
+// vectors of d = [x0 ; x0_pre ; w] (scaled by 2^20: the constant part of the right-hand side then costs no digits), so
+// both forms of the dual solve rest on one factorisation.  Once per (handle, k), ~5 ms; synchronises the stream.
+static int fmpc_build_inverse(fmpc_handle h, double k, hipStream_t stream) {
+    const int n = h->n, T = h->T, nb = h->nb, TN = T * n, nrow = nb * n;
+    const int ncol = 2 * n + TN, np = 1 + ncol, npanels = (np + FP_NP - 1) / FP_NP;
+    const double scale = 1048576.0;
+    h->inv_valid = 0;
+    std::vector<double> hx0((size_t)np * n, 0.0), hx0p((size_t)np * n, 0.0), hw((size_t)np * TN, 0.0);
+    for (int j = 0; j < n; ++j) { hx0[(size_t)(1 + j) * n + j] = scale; hx0p[(size_t)(1 + n + j) * n + j] = scale; }
+    for (int j = 0; j < TN; ++j) hw[(size_t)(1 + 2 * n + j) * TN + j] = scale;
+    double* d = nullptr;
+    const size_t o_x0 = 0, o_x0p = o_x0 + hx0.size(), o_w = o_x0p + hx0p.size(), o_gate = o_w + hw.size(),
+                 o_nu = o_gate + 2 * (size_t)np, total = o_nu + (size_t)npanels * nrow * FP_NP;
+    if (hipMalloc((void**)&d, total * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+    int rc = FMPC_OK;
+    std::vector<double> nu((size_t)npanels * nrow * FP_NP);
+    if (hipMemcpyAsync(d + o_x0, hx0.data(), hx0.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(d + o_x0p, hx0p.data(), hx0p.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(d + o_w, hw.data(), hw.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK) {
+        FpParams Q;
+        fmpc_panel_params(h, k, Q);
+        Q.batch = np; Q.npanels = npanels; Q.step_ld = 1;
+        Q.x0 = d + o_x0; Q.x0p = d + o_x0p; Q.w = d + o_w; Q.nu0 = nullptr;
+        Q.nuws = d + o_nu; Q.gate = d + o_gate; Q.handed = nullptr;
+        const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
+        if (fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), stream) != hipSuccess ||
+            hipMemcpyAsync(nu.data(), d + o_nu, nu.size() * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) rc = FMPC_E_HIP;
+    }
+    (void)hipFree(d);
+    if (rc != FMPC_OK) return rc;
+    auto at = [&](int p, int row) { return nu[((size_t)(p / FP_NP) * nrow + row) * FP_NP + (p % FP_NP)]; };
+    const int nrt = (nrow + 15) / 16, jks = h->inv_jks, jksp = 16 * ((jks + 15) / 16 + 3);
+    std::vector<double> img((size_t)nrt * jksp * 64, 0.0), nuc((size_t)nrt * 16, 0.0);
+    for (int r = 0; r < nrow; ++r) {
+        nuc[r] = at(0, r);
+        if (!std::isfinite(nuc[r])) return FMPC_OK;                  // the panel path reports what is wrong; this form stays off
+    }
+    const bool var2 = h->var_order == 2;
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int ks = 0; ks < jks; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * rt + (l & 15), kk = 4 * ks + (l >> 4);
+                int col = -1;                                        // column of d -> index of the unit-vector problem
+                if (kk < n) col = kk;
+                else if (kk < 2 * n) col = var2 ? kk : -1;           // VAR(1): x0_pre does not enter
+                else if (kk >= 4 * FP_XKS && kk - 4 * FP_XKS < TN) col = 2 * n + (kk - 4 * FP_XKS);
+                if (row < nrow && col >= 0) {
+                    const double v = (at(1 + col, row) - nuc[row]) / scale;
+                    if (!std::isfinite(v)) return FMPC_OK;
+                    img[((size_t)rt * jksp + ks) * 64 + l] = v;
+                }
+            }
+    // E = [A1 A2 ; A2 0] (fast_mpc_eq_const.m:39-44), rows 0..53, columns [x0 ; x0_pre]
+    std::vector<double> eimg((size_t)4 * FP_XKS * 64, 0.0);
+    for (int I = 0; I < 4; ++I)
+        for (int ks = 0; ks < FP_XKS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * I + (l & 15), kk = 4 * ks + (l >> 4);
+                double v = 0.0;
+                if (row < n && kk < n) v = h->hm_a1[row * n + kk];
+                else if (row < n && kk < 2 * n) v = var2 ? h->hm_a2[row * n + kk - n] : 0.0;
+                else if (row < 2 * n && kk < n) v = var2 ? h->hm_a2[(row - n) * n + kk] : 0.0;
+                eimg[((size_t)I * FP_XKS + ks) * 64 + l] = v;
+            }
+    if (hipMemcpy(h->inv_eimg, eimg.data(), eimg.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->inv_jimg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->inv_nuc, nuc.data(), nuc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    h->inv_valid = 1; h->inv_k = k;
+    return FMPC_OK;
+}
+
 // fmpc_solve_device (u0_out == NULL) / fmpc_solve_u0_device: the first moves are written by the solve's last kernel
 // where that kernel visits every problem anyway (the wave kernel), by the unpack kernel otherwise
 static int fmpc_solve_device_inner(fmpc_handle h, int batch,
@@ -1146,23 +1252,27 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 h->pn_cap = batch;
             }
             FpParams Q;
-            Q.m = h->m; Q.mp = h->pn_mp; Q.T = h->T; Q.nb = h->nb; Q.has_xf = h->has_xf; Q.var2 = h->var_order == 2 ? 1 : 0;
+            fmpc_panel_params(h, k, Q);
             Q.batch = batch; Q.npanels = npanels; Q.step_ld = fmpc_step_ld(n_newton);
             Q.x0 = x0; Q.x0p = x0_pre; Q.w = w; Q.nu0 = nu0;
             Q.zout = z_out; Q.status = status; Q.iters = iters; Q.step = step;
             Q.nuws = h->pn_nuws; Q.nuout = nu_out;
-            Q.simg = h->pn_pool + h->pn_o_simg; Q.limg = h->pn_pool + h->pn_o_limg;
-            Q.sched_f = h->pn_sched; Q.sched_b = h->pn_sched + (size_t)FP_MAX_STEPS(h->nb) * FP_STEP_INTS; Q.nsf = h->pn_nsf; Q.nsb = h->pn_nsb;
-            Q.btimg = h->pn_pool + h->pn_o_bt; Q.aimg = h->pn_pool + h->pn_o_aimg;
-            Q.vec = h->pn_pool + h->pn_o_vec; Q.ucon = h->pn_pool + h->pn_o_ucon;
-            Q.rd2_0 = h->pn_rd2_0; Q.rp2c = h->pn_rp2c; Q.dump = h->pn_pool + h->pn_o_dump;
             Q.gate = h->pn_gate; Q.epsp = h->pn_epsp; Q.handed = h->pn_cnt;
-            Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
-            Q.kbar = k; Q.rnp = h->pn_rnp;
+            Q.rnp = h->pn_rnp;
+            // The dual solve in its dense form (no dependency chain, fmpc_kernel_inv.hip): always without w (56 columns),
+            // with w while the product is cheaper than the two sweeps of a panel (few panels leave the chip empty)
+            const bool dense_form = h->inv_enabled && (w == nullptr || batch <= h->inv_max_batch);
+            if (dense_form && (!h->inv_valid || h->inv_k != k)) {
+                if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;   // earlier solves may still read J
+                const int rcb = fmpc_build_inverse(h, k, (hipStream_t)stream);
+                if (rcb != FMPC_OK) return rcb;
+            }
             const int split = max_iter > 1;                           // budgets > 1: decide, compact, continue (two launches)
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
-            e = fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), (hipStream_t)stream);
+            h->inv_last = dense_form && h->inv_valid;
+            if (h->inv_last) e = fmpc_launch_inv(Q, (hipStream_t)stream);
+            else e = fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;
             const int ntasks = npanels * h->T;
             // one task per wave, 8 per workgroup; workgroups b, b + 8, ... take the panels b % 8, b % 8 + 8, ...
@@ -1259,6 +1369,21 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
     if (!u0_out) return FMPC_E_NULL;
     return fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                   u0_out, stream);
+}
+
+extern "C" int fmpc_last_dual_form(fmpc_handle h) {
+    if (!h) return FMPC_E_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return h->last_path == FMPC_PATH_PANEL ? h->inv_last : 0;
+}
+
+extern "C" int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w) {
+    if (!h) return FMPC_E_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (enabled && !h->inv_jimg) return FMPC_E_UNSUPPORTED;
+    h->inv_enabled = enabled ? 1 : 0;
+    if (max_batch_with_w >= 0) h->inv_max_batch = max_batch_with_w;
+    return FMPC_OK;
 }
 
 extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {

@@ -19,6 +19,10 @@
 // lane are contiguous, 4 x 16-byte loads instead of 7 x 8-byte ones (the sweeps are bound by the ISSUE of their
 // operand loads).  Image id i < nb: Linv_i'; id nb: all zero; then one image per edge of the two sweeps.
 #define FP_IMGL (2 * 64 * 8)
+// Dense form of the same dual solve (fmpc_kernel_inv.hip): nu+ = nuc + J d with d = [x0 ; x0_pre ; 0 0 ; w].
+// FpParams::jimg: A-operand image of J by 16-row tile, element [(rt * jksp + ks) * 64 + l] = J[16 rt + (l & 15)][4 ks + (l >> 4)],
+// jks = FP_XKS + ceil(T n / 4) k-steps, rows padded with zero k-steps to jksp = 16 (ceil(jks / 16) + 3): the k groups of a workgroup may run past the end; the first FP_XKS k-steps are the columns of [x0 ; x0_pre ; 0 0].
+#define FP_XKS 14
 // Sweep schedules (host: fmpc_upload_panel).  The block Cholesky factor of Y is computed on the host in an
 // elimination order chosen for a short dependency chain; a sweep is then a list of EDGES  y_tgt += IMG y_src
 // executed in steps with one workgroup barrier per step.  Per step and wave (8 waves; wave 2p + I does row
@@ -89,12 +93,16 @@ struct FpParams {
     double* rnp;                        // per (panel, stage, problem): partial ||r_d(z+, nu+)||^2, barrier terms re-evaluated
     int* handed;                        // number of problems the exact path had to solve (diagnostic), zeroed here
     double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
+    const double* jimg; const double* nuc; int jks, jksp;        // dense form (fmpc_cold_inv): image of J (jks k-steps, rows padded with zeros to jksp), nu+ at d = 0
+    const double* eimg;                                          // image of E = [A1 A2 ; A2 0] (4 row tiles x FP_XKS k-steps): b_0, b_1
 };
 
 size_t fmpc_panel_lds_bytes(int nb, int mp);
 size_t fmpc_panel_lds_used(int nb, int mp, int nsteps);
 hipError_t fmpc_panel_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_panel(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
+int fmpc_inv_variant(int npanels, int has_w);
+hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream);
 size_t fmpc_dz_lds_bytes(int mp, int next);
 hipError_t fmpc_dz_prepare(int mp);
 hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream);

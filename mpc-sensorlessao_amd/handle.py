@@ -159,6 +159,17 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_last_dispatch")
         return path.value, cnt.value
 
+    def set_dense_form(self, enabled, max_batch_with_w=-1):
+        """fmpc_set_dense_form: the cold-start dual solve as one product with J = d nu+ / d [x0; x0_pre; w] (always
+        without w; with w up to `max_batch_with_w` problems) instead of the two sweeps through the block factor."""
+        rc = self._lib.fmpc_set_dense_form(self._h, int(bool(enabled)), int(max_batch_with_w))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_set_dense_form")
+
+    def last_dual_form(self):
+        """1 if the last solve took the dense form of the dual solve (fmpc_last_dual_form)."""
+        return int(self._lib.fmpc_last_dual_form(self._h))
+
     # ------------------------------------------------------------------ device tensors
     def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
                      z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None, u0_out=None):
