@@ -192,6 +192,18 @@ int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const d
                             double* x0, double* x0_pre, double* w, void* stream);
 
 /*
+ * One closed-loop step in one call: fmpc_loop_inputs_device followed by fmpc_solve_u0_device on the inputs it produced
+ * (same arguments, same results; x0, x0_pre, w are written as before).  Knowing that w = -M1 (B u1) - M2 (B u2) has
+ * only 2 n degrees of freedom, the dense form of the cold-start dual solve (see fmpc_set_dense_form) takes
+ * [B u1 ; B u2] in place of the T n entries of w: 28 instead of 217 k-steps per tile at (27, 144, 30), at any batch.
+ */
+int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                          const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
+                          const double* nu0, int n_newton, double k,
+                          double* z_out, double* nu_out, int* status, int* iters, double* step,
+                          double* u0_out, void* stream);
+
+/*
  * Ramp-rate rows of the VAR_1 variant (VAR_1/Fast_MPC2.m:26-27 arguments dumin, dumax, u_prev;
  * VAR_1/fast_mpc_ineq_const.m:58-76): per stage j   du_min <= u_j - u_{j-1} <= du_max,  u_{-1} = u_prev.
  * fmpc_set_ramp stores the bounds (m each, du_min < du_max) in the handle; fmpc_solve_ramp[_device] is

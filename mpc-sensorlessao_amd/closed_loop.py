@@ -10,8 +10,9 @@ the caller's residual-free turbulence coefficients a[k]:
     z = Fast_MPC2(..., w, [], []).mpc_fixed_log_newton(n_fix, k_fix)      README.md:547-555
     u[k] = U(1:nu)                            README.md:589
 
-Everything stays in HBM between the steps: two calls per step on torch's current stream
-(`fmpc_loop_inputs_device`, `fmpc_solve_u0_device`), no host round trip.
+Everything stays in HBM between the steps: one call per step on torch's current stream (`fmpc_loop_step_device` =
+`fmpc_loop_inputs_device` + `fmpc_solve_u0_device`; the two separate calls with `fused=False` or ramp rows), no host
+round trip.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ class ClosedLoop:
     """ramp=True (after `handle.set_ramp`): every solve carries the VAR_1 variant's ramp-rate rows against the
     previous first move, u_prev = U(1:nu) (README.md:589; VAR_1/fast_mpc_ineq_const.m:58-76), zeros at the first step."""
 
-    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None, ramp=False):
+    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None, ramp=False, fused=True):
         import torch
         self.h, self.batch, self.n_newton, self.k = handle, int(batch), int(n_newton), float(k)
         dev = torch.device("cuda", handle.device) if device is None else device
@@ -35,16 +36,22 @@ class ClosedLoop:
         self.iters = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.steps_done = 0
         self.ramp = bool(ramp)
+        self.fused = bool(fused)        # one C call per step (fmpc_loop_step_device) instead of two
 
     def step(self, a_k, nu0=None):
         """One closed-loop step for all realisations.  a_k: (batch, n) device tensor.  Returns u[k] (batch, m),
         a view into the loop's ring buffer (valid until two further steps)."""
         s = self.steps_done
         u_new, u1, u2 = self.u[s % 3], self.u[(s - 1) % 3], self.u[(s - 2) % 3]
-        self.h.loop_inputs_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
-                                  self.x0, self.x0_pre, self.w)
-        self.h.solve_device(self.x0, self.x0_pre, self.w, None, nu0, self.n_newton, self.k, z_out=self.z,
-                            status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new)
+        if self.ramp or not self.fused:
+            self.h.loop_inputs_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
+                                      self.x0, self.x0_pre, self.w)
+            self.h.solve_device(self.x0, self.x0_pre, self.w, None, nu0, self.n_newton, self.k, z_out=self.z,
+                                status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new)
+        else:
+            self.h.loop_step_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
+                                    self.x0, self.x0_pre, self.w, nu0, self.n_newton, self.k, z_out=self.z,
+                                    status=self.status, iters=self.iters, u0_out=u_new)
         self.steps_done = s + 1
         return u_new
 

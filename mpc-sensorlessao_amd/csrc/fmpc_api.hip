@@ -35,7 +35,7 @@ hipError_t fmpc_launch_unpack(int n, int m, int T, int batch, const double* z, d
                               double* X, double* u0, hipStream_t stream);
 hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
                                    const double* a, const double* x0_last, const double* u1, const double* u2,
-                                   double* x0, double* x0_pre, double* w, hipStream_t stream);
+                                   double* x0, double* x0_pre, double* w, hipStream_t stream, double* lv = nullptr);
 
 // one-wave-per-problem MFMA kernel (fmpc_kernel_wave.hip)
 size_t fmpc_wave_lds_bytes(int n, int mp);
@@ -101,6 +101,9 @@ struct fmpc_handle_s {
     // dense form of the cold-start dual solve (fmpc_kernel_inv.hip): nu+ = nuc + J d, built per (handle, k) on first use
     int inv_enabled, inv_valid, inv_jks, inv_max_batch, inv_last; double inv_k;
     double* inv_jimg; double* inv_nuc; double* inv_eimg;
+    double* inv_jimg2; int inv_jks2;     // J' = [J_x | -J_w M1 | -J_w M2]: closed-loop steps, w = -M1 B u1 - M2 B u2 (fmpc_loop_step_device)
+    double* lp_v; size_t lp_cap; int lp_hint;                    // [B u1 ; B u2] per problem of the running loop step
+    std::vector<double> hm_m1, hm_m2;
     std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf, hm_blocks;
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
@@ -282,7 +285,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 1024; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr;
+    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 1024; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -401,6 +404,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         }
     }
     const size_t oM1 = push(lm1.data(), lm1.size()), oM2 = push(lm2.data(), lm2.size());
+    h->hm_m1 = lm1; h->hm_m2 = lm2;
     // blocks are indexed as Yblk + idx*n*n by the kernels: pack them without padding
     std::vector<double> yall;
     for (auto& bk : blocks) yall.insert(yall.end(), bk.begin(), bk.end());
@@ -533,10 +537,12 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                     h->inv_enabled = !(noinv && noinv[0] == '1');
                     if (mb && mb[0]) h->inv_max_batch = atoi(mb);
                     h->inv_jks = FP_XKS + (T * n + 3) / 4;
+                    h->inv_jks2 = 2 * FP_XKS;                       // [x0 ; x0_pre ; 0 0 ; B u1 ; B u2 ; 0 0]
                     const size_t nrt = ((size_t)h->nb * n + 15) / 16;
                     if (h->inv_enabled && (hipMalloc((void**)&h->inv_jimg, nrt * (size_t)(16 * ((h->inv_jks + 15) / 16 + 3)) * 64 * sizeof(double)) != hipSuccess ||
                                            hipMalloc((void**)&h->inv_nuc, nrt * 16 * sizeof(double)) != hipSuccess ||
-                                           hipMalloc((void**)&h->inv_eimg, 4 * FP_XKS * 64 * sizeof(double)) != hipSuccess)) { fmpc_destroy(h); return FMPC_E_ALLOC; }
+                                           hipMalloc((void**)&h->inv_eimg, 4 * FP_XKS * 64 * sizeof(double)) != hipSuccess ||
+                                           hipMalloc((void**)&h->inv_jimg2, nrt * (size_t)(16 * ((2 * FP_XKS + 15) / 16 + 3)) * 64 * sizeof(double)) != hipSuccess)) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 }
             }
         }
@@ -560,6 +566,8 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->inv_jimg) (void)hipFree(h->inv_jimg);
     if (h->inv_nuc) (void)hipFree(h->inv_nuc);
     if (h->inv_eimg) (void)hipFree(h->inv_eimg);
+    if (h->inv_jimg2) (void)hipFree(h->inv_jimg2);
+    if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
     if (h->pn_sched) (void)hipFree(h->pn_sched);
@@ -1109,6 +1117,7 @@ static void fmpc_panel_params(fmpc_handle h, double k, FpParams& Q) {
     Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
     Q.kbar = k;
     Q.jimg = h->inv_jimg; Q.nuc = h->inv_nuc; Q.jks = h->inv_jks; Q.jksp = 16 * ((h->inv_jks + 15) / 16 + 3); Q.eimg = h->inv_eimg;
+    Q.gw = nullptr; Q.gwn = h->T * h->n;                          // (set per call)
 }
 
 // J and nuc of the dense form (fmpc_kernel_inv.hip) for barrier weight k: the panel kernel itself solves for the unit
@@ -1116,12 +1125,17 @@ static void fmpc_panel_params(fmpc_handle h, double k, FpParams& Q) {
 // both forms of the dual solve rest on one factorisation.  Once per (handle, k), ~5 ms; synchronises the stream.
 static int fmpc_build_inverse(fmpc_handle h, double k, hipStream_t stream) {
     const int n = h->n, T = h->T, nb = h->nb, TN = T * n, nrow = nb * n;
-    const int ncol = 2 * n + TN, np = 1 + ncol, npanels = (np + FP_NP - 1) / FP_NP;
+    const int ncol = 2 * n + TN, np = 1 + ncol + 2 * n, npanels = (np + FP_NP - 1) / FP_NP;      // + w = -M1 e_j, -M2 e_j
     const double scale = 1048576.0;
     h->inv_valid = 0;
     std::vector<double> hx0((size_t)np * n, 0.0), hx0p((size_t)np * n, 0.0), hw((size_t)np * TN, 0.0);
     for (int j = 0; j < n; ++j) { hx0[(size_t)(1 + j) * n + j] = scale; hx0p[(size_t)(1 + n + j) * n + j] = scale; }
     for (int j = 0; j < TN; ++j) hw[(size_t)(1 + 2 * n + j) * TN + j] = scale;
+    for (int j = 0; j < n; ++j)                                       // w = -M1 (B u1) - M2 (B u2): the columns of [B u1 ; B u2]
+        for (int e = 0; e < TN; ++e) {
+            hw[(size_t)(1 + ncol + j) * TN + e] = -scale * h->hm_m1[(size_t)e * n + j];
+            hw[(size_t)(1 + ncol + n + j) * TN + e] = -scale * h->hm_m2[(size_t)e * n + j];
+        }
     double* d = nullptr;
     const size_t o_x0 = 0, o_x0p = o_x0 + hx0.size(), o_w = o_x0p + hx0p.size(), o_gate = o_w + hw.size(),
                  o_nu = o_gate + 2 * (size_t)np, total = o_nu + (size_t)npanels * nrow * FP_NP;
@@ -1166,6 +1180,22 @@ static int fmpc_build_inverse(fmpc_handle h, double k, hipStream_t stream) {
                     img[((size_t)rt * jksp + ks) * 64 + l] = v;
                 }
             }
+    // J' = [J_x | d nu+ / d (B u1) | d nu+ / d (B u2)]
+    const int jks2 = h->inv_jks2, jksp2 = 16 * ((jks2 + 15) / 16 + 3);
+    std::vector<double> img2((size_t)nrt * jksp2 * 64, 0.0);
+    for (int rt = 0; rt < nrt; ++rt)
+        for (int ks = 0; ks < jks2; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * rt + (l & 15), kk = 4 * ks + (l >> 4);
+                if (ks < FP_XKS) { img2[((size_t)rt * jksp2 + ks) * 64 + l] = img[((size_t)rt * jksp + ks) * 64 + l]; continue; }
+                const int c = kk - 4 * FP_XKS;
+                if (row < nrow && c < 2 * n) {
+                    const double v = (at(1 + ncol + c, row) - nuc[row]) / scale;
+                    if (!std::isfinite(v)) return FMPC_OK;
+                    img2[((size_t)rt * jksp2 + ks) * 64 + l] = v;
+                }
+            }
+    if (hipMemcpy(h->inv_jimg2, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     // E = [A1 A2 ; A2 0] (fast_mpc_eq_const.m:39-44), rows 0..53, columns [x0 ; x0_pre]
     std::vector<double> eimg((size_t)4 * FP_XKS * 64, 0.0);
     for (int I = 0; I < 4; ++I)
@@ -1261,7 +1291,9 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             Q.rnp = h->pn_rnp;
             // The dual solve in its dense form (no dependency chain, fmpc_kernel_inv.hip): always without w (56 columns),
             // with w while the product is cheaper than the two sweeps of a panel (few panels leave the chip empty)
-            const bool dense_form = h->inv_enabled && (w == nullptr || batch <= h->inv_max_batch);
+            // (a closed-loop step hands over [B u1 ; B u2], the 2 n numbers its w depends on: 28 k-steps at any batch)
+            const bool lowrank = h->lp_hint && w != nullptr && h->lp_v != nullptr;
+            const bool dense_form = h->inv_enabled && (w == nullptr || lowrank || batch <= h->inv_max_batch);
             if (dense_form && (!h->inv_valid || h->inv_k != k)) {
                 if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;   // earlier solves may still read J
                 const int rcb = fmpc_build_inverse(h, k, (hipStream_t)stream);
@@ -1271,6 +1303,10 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
             h->inv_last = dense_form && h->inv_valid;
+            if (h->inv_last) {
+                if (lowrank) { Q.gw = h->lp_v; Q.gwn = 2 * h->n; Q.jimg = h->inv_jimg2; Q.jks = h->inv_jks2; Q.jksp = 16 * ((h->inv_jks2 + 15) / 16 + 3); }
+                else { Q.gw = w; Q.gwn = h->T * h->n; }
+            }
             if (h->inv_last) e = fmpc_launch_inv(Q, (hipStream_t)stream);
             else e = fmpc_launch_panel(Q, pgrid, fmpc_panel_lds_used(h->nb, h->pn_mp, h->pn_nsf + h->pn_nsb), (hipStream_t)stream);
             if (e != hipSuccess) return FMPC_E_HIP;
@@ -1369,6 +1405,40 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
     if (!u0_out) return FMPC_E_NULL;
     return fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                   u0_out, stream);
+}
+
+// One closed-loop step: fmpc_loop_inputs_device + fmpc_solve_u0_device under one lock, with the knowledge that
+// w = -M1 (B u1) - M2 (B u2) has only 2 n degrees of freedom.
+extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                                     const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
+                                     const double* nu0, int n_newton, double k,
+                                     double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                     double* u0_out, void* stream) {
+    if (!h || !a_k || !x0 || !x0_pre || !w || !z_out || !u0_out) return FMPC_E_NULL;
+    if (batch < 0) return FMPC_E_DIM;
+    if (batch == 0) return FMPC_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = fmpc_guard_begin(h, (hipStream_t)stream);
+    if (rc != FMPC_OK) return rc;
+    const bool lr = h->inv_enabled && h->inv_jimg2 != nullptr && h->n == FP_N;
+    if (lr && (size_t)batch > h->lp_cap) {
+        (void)hipDeviceSynchronize();
+        if (h->lp_v) (void)hipFree(h->lp_v);
+        h->lp_v = nullptr; h->lp_cap = 0;
+        if (hipMalloc((void**)&h->lp_v, (size_t)batch * 2 * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->lp_cap = batch;
+    }
+    if (fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_k, x0_last, u1, u2,
+                                x0, x0_pre, w, (hipStream_t)stream, lr ? h->lp_v : nullptr) != hipSuccess) rc = FMPC_E_HIP;
+    if (rc == FMPC_OK) {
+        h->lp_hint = lr ? 1 : 0;
+        rc = fmpc_solve_device_inner(h, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                     u0_out, stream);
+        h->lp_hint = 0;
+    }
+    fmpc_guard_end(h, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int fmpc_last_dual_form(fmpc_handle h) {

@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256, 2)
 fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restrict__ Bt, const double* __restrict__ M1,
                         const double* __restrict__ M2, const double* __restrict__ a, const double* x0_last,
                         const double* __restrict__ u1, const double* __restrict__ u2,
-                        double* x0, double* __restrict__ x0_pre, double* __restrict__ w) {
+                        double* x0, double* __restrict__ x0_pre, double* __restrict__ w, double* __restrict__ lv) {
     constexpr int n = 27;
     extern __shared__ double sh[];                      // B' (m x n), u1 and u2 of the tile (LI_PT x (m + 1) each)
     double* sBt = sh; double* su = sh + (size_t)m * n;
@@ -709,6 +709,9 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
                     const double xl = x0_last ? x0_last[g] : 0.0;    // (x0 may alias x0_last: read before the write below)
                     x0_pre[g] = xl;
                     x0[g] = a[g] + bu[0][I][r];
+                    // [B u1 ; B u2]: the 2 n numbers w depends on (fmpc_loop_step_device: the dense form of the dual solve
+                    // takes them instead of the T n entries of w)
+                    if (lv) { lv[(size_t)(p0 + li) * 2 * n + q] = bu[0][I][r]; lv[(size_t)(p0 + li) * 2 * n + n + q] = bu[1][I][r]; }
                 }
             }
     }
@@ -746,7 +749,7 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
 
 hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
                                    const double* a, const double* x0_last, const double* u1, const double* u2,
-                                   double* x0, double* x0_pre, double* w, hipStream_t stream) {
+                                   double* x0, double* x0_pre, double* w, hipStream_t stream, double* lv) {
     if (n > LI_NMAX) return hipErrorInvalidValue;
     if (n == 27) {
         const int Tn = T * n, rs = (Tn + 63) / 64, rows = (Tn + rs - 1) / rs;      // <= 64 rows = 4 tiles per workgroup
@@ -755,7 +758,7 @@ hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double*
         hipError_t ea = hipFuncSetAttribute((const void*)fmpc_loop_inputs_mfma27, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return ea;
         hipLaunchKernelGGL(fmpc_loop_inputs_mfma27, dim3((batch + LI_PT - 1) / LI_PT, rs), dim3(256), lds, stream,
-                           m, T, batch, rows, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w);
+                           m, T, batch, rows, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w, lv);
         return hipGetLastError();
     }
     const auto kern = fmpc_loop_inputs_kernel<0>;

@@ -16,11 +16,12 @@
 // their partial tiles in LDS in a fixed order (results do not depend on the launch shape).  A operand: one coalesced
 // 512-byte load per k-step from the image of J; B operand: d straight from the caller's arrays (lane = (k, problem)).
 // Items are dealt so that the workgroups of one XCD share a few row tiles of J (its L2 holds them) and sweep the panels.
-// The last workgroups of the grid compute what the step-length decision needs per problem: ||r_p||^2 and a lower bound of
+// The first workgroups of the grid compute what the step-length decision needs per problem: ||r_p||^2 and a lower bound of
 // rho^2 (as S1 of the panel kernel does).  Output: nu+ in PANEL layout and `gate`, exactly what fmpc_cold_dz and the
 // decision pass read.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "fmpc_device.h"
 #include "fmpc_panel.h"
 #include "../../include/fastmpc.h"
@@ -175,17 +176,22 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
     const int qcount = rt8 * npg;
     const int gemm_blocks = 8 * ((qcount + IPW - 1) / IPW);
     if (blockIdx.x == 0 && tid == 0 && P->handed) { P->handed[0] = 0; P->handed[1] = 0; }   // counters of the exact-path launches
-    if ((int)blockIdx.x >= gemm_blocks) {
-        fi_gate(P, (int)blockIdx.x - gemm_blocks, red);
+    // the FIRST workgroups of the grid (a multiple of 8: the XCD of the others is unchanged) are the gate tasks: behind the
+    // products they would wait for a free CU and then run alone
+    const int ngate = (npanels + 7) & ~7;
+    if ((int)blockIdx.x < ngate) {
+        if ((int)blockIdx.x < npanels) fi_gate(P, (int)blockIdx.x, red);
         return;
     }
+    const int bid = (int)blockIdx.x - ngate;
+    if (bid >= gemm_blocks) return;
     // XCD x = block & 7 works on the row tiles x, x + 8, ...: one row tile at a time, all panel groups
-    const int x = blockIdx.x & 7;
-    const int q = (int)(blockIdx.x >> 3) * IPW + (KSPLIT == 1 ? wv : 0);
+    const int x = bid & 7;
+    const int q = (bid >> 3) * IPW + (KSPLIT == 1 ? wv : 0);
     const int rtq = x + 8 * (q / npg), pg = q % npg;
     const bool live = q < qcount && rtq < nrt;                     // uniform per wave (per workgroup when the k range is split)
     const int rt = live ? rtq : 0;
-    const bool has_w = P->w != nullptr;
+    const bool has_w = P->gw != nullptr;
     const int kend = has_w ? P->jks : FP_XKS;
     const int per = (kend + KSPLIT - 1) / KSPLIT;
     const int part = KSPLIT == 1 ? 0 : wv;
@@ -200,7 +206,8 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
     const double* jrow = P->jimg + (size_t)rt * P->jksp * 64 + lane;
     const double* x0 = P->x0;
     const double* x0p = P->x0p;
-    const double* w = P->w;
+    const double* w = P->gw;                       // the columns of d behind [x0 ; x0_pre ; 0 0]: w, or [B u1 ; B u2]
+    const int WN = P->gwn;
     struct Set { double a[FI_CH]; double b[PB][FI_CH]; };
     auto load = [&](Set& S, int kb) {                               // requests only; zeros are applied in mma()
 #pragma unroll
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
             ks = ks < 0 ? 0 : ks;
             S.a[u] = jrow[(size_t)ks * 64];
 #pragma unroll
-            for (int j = 0; j < PB; ++j) S.b[j][u] = *fi_addr(x0, x0p, w, pc[j], 4 * ks + g, TN);
+            for (int j = 0; j < PB; ++j) S.b[j][u] = *fi_addr(x0, x0p, w, pc[j], 4 * ks + g, WN);
         }
     };
     d4 acc[PB];
@@ -294,11 +301,14 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     const int nrt = (nrow + 15) / 16, nrg = (nrt + RT - 1) / RT, npg = (npanels + PB - 1) / PB, rg8 = (nrg + 7) / 8;
     const int gemm_blocks = 8 * rg8 * npg;
     if (blockIdx.x == 0 && tid == 0 && P->handed) { P->handed[0] = 0; P->handed[1] = 0; }
-    if ((int)blockIdx.x >= gemm_blocks) {
-        fi_gate(P, (int)blockIdx.x - gemm_blocks, lds);
+    const int ngate = (npanels + 7) & ~7;                           // gate tasks first (see fmpc_cold_inv)
+    if ((int)blockIdx.x < ngate) {
+        if ((int)blockIdx.x < npanels) fi_gate(P, (int)blockIdx.x, lds);
         return;
     }
-    const int x = blockIdx.x & 7, q = (int)(blockIdx.x >> 3);
+    const int bid = (int)blockIdx.x - ngate;
+    if (bid >= gemm_blocks) return;
+    const int x = bid & 7, q = bid >> 3;
     const int rg = x + 8 * (q / npg), pg = q % npg;
     if (rg >= nrg) return;
     const int rtq = RT * rg + wv;
@@ -317,12 +327,13 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
         const long p = (long)pg * NP + wv * PPW + i;
         pr[i] = (size_t)(p < batch ? p : batch - 1);
     }
-    const double* x0 = P->x0; const double* x0p = P->x0p; const double* w = P->w;
+    const double* x0 = P->x0; const double* x0p = P->x0p; const double* w = P->gw;
+    const int WN = P->gwn;                                          // row length of the data behind [x0 ; x0_pre ; 0 0]: T n, or 2 n
     auto gload_w = [&](int ch, double v[PPW]) {                     // chunk ch >= 1: columns of w only
         int wi = 64 * ch + lane - 4 * FP_XKS;                       // beyond T n: a finite value times a zero column of J
-        wi = wi < TN ? wi : TN - 1;
+        wi = wi < WN ? wi : WN - 1;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) v[i] = w[pr[i] * (size_t)TN + wi];
+        for (int i = 0; i < PPW; ++i) v[i] = w[pr[i] * (size_t)WN + wi];
     };
     auto aload = [&](int ch, double a[KC]) {
 #pragma unroll
@@ -355,7 +366,7 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     };
     double bv[PPW], a0[KC];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) bv[i] = *fi_addr(x0, x0p, HAS_W ? w : nullptr, pr[i], 64 * cbase + lane, TN);
+    for (int i = 0; i < PPW; ++i) bv[i] = *fi_addr(x0, x0p, HAS_W ? w : nullptr, pr[i], 64 * cbase + lane, WN);
     aload(cbase, a0);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) bv[i] = fi_zero(x0p != nullptr, HAS_W, 64 * cbase + lane) ? 0.0 : bv[i];
@@ -417,8 +428,12 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
 // Launch shapes.  0: without w (one chunk): 4 row tiles x 2 panels.  With w --  1: <= 4 panels: 16 wavefronts split k, d read
 // straight into registers;  2: <= 16 panels: one row tile, k over the 4 SIMDs;  3: <= 64 panels: 2 row tiles x 2 k groups;
 // 4: beyond (only when the bound is raised): 4 row tiles x 2 k groups x 2 panels.
-int fmpc_inv_variant(int npanels, int has_w) {
+int fmpc_inv_variant(int npanels, int has_w, int jks) {
     if (!has_w) return 0;
+    if (jks <= 64 && npanels > 4) return 6;                         // [B u1 ; B u2] instead of w: two chunks
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("FMPC_INV_VARIANT"); forced = e && e[0] ? atoi(e) : -1; }   // experiments
+    if (forced > 0) return forced;
     if (npanels <= 4) return 1;
     if (npanels <= 16) return 2;
     return npanels <= 64 ? 3 : 4;
@@ -426,13 +441,15 @@ int fmpc_inv_variant(int npanels, int has_w) {
 
 hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream) {
     const int nrow = P.nb * FP_N, nrt = (nrow + 15) / 16;
-    const int variant = fmpc_inv_variant(P.npanels, P.w != nullptr);
-    auto grid_for = [&](int RT, int PB) { return 8 * (((nrt + RT - 1) / RT + 7) / 8) * ((P.npanels + PB - 1) / PB) + P.npanels; };
+    const int variant = fmpc_inv_variant(P.npanels, P.gw != nullptr, P.jks);
+    auto grid_for = [&](int RT, int PB) { return 8 * (((nrt + RT - 1) / RT + 7) / 8) * ((P.npanels + PB - 1) / PB) + ((P.npanels + 7) & ~7); };
     switch (variant) {
     case 0: hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 4, 1, false>), dim3(grid_for(4, 2)), dim3(256), 0, stream, P); break;
-    case 1: hipLaunchKernelGGL((fmpc_cold_inv<16, 1>), dim3(8 * ((nrt + 7) / 8) * P.npanels + P.npanels), dim3(1024), 0, stream, P); break;
+    case 1: hipLaunchKernelGGL((fmpc_cold_inv<16, 1>), dim3(8 * ((nrt + 7) / 8) * P.npanels + ((P.npanels + 7) & ~7)), dim3(1024), 0, stream, P); break;
     case 2: hipLaunchKernelGGL((fmpc_cold_inv_rg<1, 1, 4, true>), dim3(grid_for(1, 1)), dim3(256), 0, stream, P); break;
     case 3: hipLaunchKernelGGL((fmpc_cold_inv_rg<1, 2, 2, true>), dim3(grid_for(2, 1)), dim3(256), 0, stream, P); break;
+    case 5: hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 2, 2, true>), dim3(grid_for(2, 2)), dim3(256), 0, stream, P); break;
+    case 6: hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 4, 1, true>), dim3(grid_for(4, 2)), dim3(256), 0, stream, P); break;
     default: hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 4, 2, true>), dim3(grid_for(4, 2)), dim3(512), 0, stream, P); break;
     }
     return hipGetLastError();

@@ -94,6 +94,8 @@ struct FpParams {
     int* handed;                        // number of problems the exact path had to solve (diagnostic), zeroed here
     double* dump;                       // T (n+m) + nb n doubles: target of the lanes beyond the batch
     const double* jimg; const double* nuc; int jks, jksp;        // dense form (fmpc_cold_inv): image of J (jks k-steps, rows padded with zeros to jksp), nu+ at d = 0
+    const double* gw; int gwn;                                   // the data behind [x0 ; x0_pre ; 0 0] in d and its row length: w (T n), or
+                                                                 // [B u1 ; B u2] (2 n) with the image J' = [J_x | -J_w M1 | -J_w M2] (fmpc_loop_step_device)
     const double* eimg;                                          // image of E = [A1 A2 ; A2 0] (4 row tiles x FP_XKS k-steps): b_0, b_1
 };
 
@@ -101,7 +103,7 @@ size_t fmpc_panel_lds_bytes(int nb, int mp);
 size_t fmpc_panel_lds_used(int nb, int mp, int nsteps);
 hipError_t fmpc_panel_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_panel(const FpParams& P, int grid, size_t lds_bytes, hipStream_t stream);
-int fmpc_inv_variant(int npanels, int has_w);
+int fmpc_inv_variant(int npanels, int has_w, int jks);
 hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream);
 size_t fmpc_dz_lds_bytes(int mp, int next);
 hipError_t fmpc_dz_prepare(int mp);

@@ -240,6 +240,29 @@ class FastMPCHandle:
         if rc != _lib.FMPC_OK:
             raise FastMPCError(rc, "fmpc_loop_inputs_device")
 
+    def loop_step_device(self, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0=None, n_newton=1, k=1e-2,
+                         z_out=None, status=None, iters=None, u0_out=None):
+        """fmpc_loop_step_device: loop inputs + solve with first-move output in one call (same results as
+        `loop_inputs_device` followed by `solve_device(..., u0_out=...)`)."""
+        import torch
+        batch = a_k.shape[0]
+        for t, cols, name in ((a_k, self.n, "a_k"), (x0_last, self.n, "x0_last"), (u1, self.m, "u1"), (u2, self.m, "u2"),
+                              (x0, self.n, "x0"), (x0_pre, self.n, "x0_pre"), (w, self.T * self.n, "w"),
+                              (nu0, self.nu_len, "nu0"), (z_out, self.nz, "z_out"), (u0_out, self.m, "u0_out")):
+            if t is None:
+                continue
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (batch, cols)):
+                raise ValueError(f"{name}: need a contiguous float64 CUDA tensor of shape ({batch}, {cols})")
+        for t, name in ((status, "status"), (iters, "iters")):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and tuple(t.shape) == (batch,)):
+                raise ValueError(f"{name}: need a contiguous int32 CUDA tensor of shape ({batch},)")
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(a_k.device).cuda_stream)
+        rc = self._lib.fmpc_loop_step_device(self._h, batch, p(a_k), p(x0_last), p(u1), p(u2), p(x0), p(x0_pre), p(w), p(nu0),
+                                             int(n_newton), float(k), p(z_out), None, p(status), p(iters), None, p(u0_out), stream)
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_loop_step_device")
+
     def unpack_device(self, z, U=None, X=None, u0=None):
         import torch
         batch = z.shape[0]

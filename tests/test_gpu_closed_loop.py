@@ -112,3 +112,30 @@ def test_loop_inputs_kernel_against_numpy(pkg, gpu, n, m, T):
         w_ref = -(M1 @ bu1.T).T - (M2 @ bu2.T).T
         assert np.abs(w.cpu().numpy() - w_ref).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
     h.close()
+
+
+@pytest.mark.parametrize("R,T", [(5, 30), (40, 30), (3, 10)])
+def test_loop_step_equals_inputs_plus_solve(pkg, gpu, R, T):
+    """fmpc_loop_step_device (one call; the dense form of the dual solve takes [B u1; B u2] in place of w) against the two
+    separate calls with the sweeps of the panel kernel: same trajectories to 1e-10 over 6 fed-back steps, w bit for bit."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, T)
+    steps = 6
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    dev = torch.device("cuda:0")
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nu0 = torch.from_numpy(np.random.default_rng(1).random((steps, R, T * 27))).to(dev)
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    h2.set_dense_form(False)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, fused=False)
+    Ua, Xa = la.run(at, nu0)
+    assert h1.last_dual_form() == 1 and h1.last_dispatch()[0] == pkg.FMPC_PATH_PANEL
+    Ub, Xb = lb.run(at, nu0)
+    assert h2.last_dual_form() == 0
+    torch.cuda.synchronize()
+    assert int(la.status.abs().sum()) == 0 and int(lb.status.abs().sum()) == 0
+    assert rel_err(Ua.cpu().numpy(), Ub.cpu().numpy()) <= 1e-10 and rel_err(Xa.cpu().numpy(), Xb.cpu().numpy()) <= 1e-10
+    assert rel_err(la.z.cpu().numpy(), lb.z.cpu().numpy()) <= 1e-10
+    assert rel_err(la.w.cpu().numpy(), lb.w.cpu().numpy()) <= 1e-10
+    h1.close(); h2.close()
