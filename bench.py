@@ -65,9 +65,15 @@ def bytes_streamed_factor(n, m, T, word=8):
     return bytes_compulsory(n, m, T, 8) + word * 2 * T * 3 * n * n
 
 
-def executed_mfma_flops_panel(m, T):
-    """What the two panel kernels issue per PROBLEM: MFMAs of 2048 flop on 16-problem panels."""
-    mfma = 2 * (2 * T - 3) * 14 + T * 14 + T * (7 * ((m + 15) // 16) + 28) + 63
+def executed_mfma_flops_panel(m, T, dense_form=False, n=27):
+    """What the kernels of the panel path issue per PROBLEM: MFMAs of 2048 flop on 16-problem panels.
+    Sweep form: edges of the two sweeps + S3 + d_z + S1.  Dense form without w (fmpc_cold_inv_rg): 14 k-steps per
+    16-row tile of nu+, the gate's product E [x0; x0_pre], d_z."""
+    dz = T * (7 * ((m + 15) // 16) + 28)
+    if dense_form:
+        mfma = ((n * T + 15) // 16) * 14 + 4 * 14 + dz
+    else:
+        mfma = 2 * (2 * T - 3) * 14 + T * 14 + dz + 63
     return mfma * 2048.0 / 16.0
 
 
@@ -252,6 +258,7 @@ def main():
         lanes.close()
     iters_head = head.check()
     path, handed = h.last_dispatch()
+    dense = bool(h.last_dual_form()) if path == pkg._lib.FMPC_PATH_PANEL else False
     shared = path in (pkg._lib.FMPC_PATH_PANEL, pkg._lib.FMPC_PATH_SHARED)
 
     extra = {}
@@ -389,7 +396,7 @@ def main():
             cl["realisations_%d" % R_] = {"value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3,
                                           "sequential_steps": nsteps_}
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
-                                         "depends on the previous first move, so only realisations batch", **cl)
+                                         "depends on the previous first move, so only realisations batch; one fmpc_loop_step_device call per step", **cl)
         # ------------------------------------------------------------------ configs[0] on the device: VAR(1), T = 10, ramp rows
         T0 = 10
         m0 = pkg.synthetic.make_model(n, m, T0, var_order=1)
@@ -473,7 +480,7 @@ def main():
         b_first = bytes_compulsory(n, m, T) if shared else bytes_streamed_factor(n, m, T)
         ach_tf = f_first * units / (kern_ms * 1e-3) / 1e12
         ach_gbs = b_first * units / (kern_ms * 1e-3) / 1e9
-        ex_fl = executed_mfma_flops_panel(m, T) if path == pkg._lib.FMPC_PATH_PANEL else None
+        ex_fl = executed_mfma_flops_panel(m, T, dense) if path == pkg._lib.FMPC_PATH_PANEL else None
         # measured HBM traffic of one solve: from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS workload
         # (scripts/profile_round.sh writes profiles/traffic_latest.json); not measured inside this run, and only
         # reported when it is consistent with the compulsory bytes
@@ -489,14 +496,18 @@ def main():
                 traffic = None
         roof_cold = {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("fmpc_cold_panel + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
+                     "kernel": (("fmpc_cold_inv_rg<2,4,1,false> (dense form of the dual solve: nu+ = nuc + J [x0; x0_pre], w = NULL)" if dense else "fmpc_cold_panel")
+                                + " + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
                                if path == pkg._lib.FMPC_PATH_PANEL else "path %d" % path,
                      "kernel_ms": kern_ms, "flops_per_unit": f_first, "units_per_launch": units,
                      "executed": None if ex_fl is None else {"mfma_flops_per_unit": ex_fl, "tflops": ex_fl * units / (kern_ms * 1e-3) / 1e12,
                                                               "frac_of_peak": ex_fl * units / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                      "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_unit": b_first},
                      "note": "the headline's own kernels: SURVEY 8d's shared-factor figure (1.60 MFLOP, 48 KB per unit) x units / device time "
-                             "of one solve (all its kernels, HIP events); `executed` = MFMAs actually issued on padded tiles"}
+                             "of one solve (all its kernels, HIP events); `executed` = MFMAs actually issued on padded tiles. With w = NULL "
+                             "the dual solve is a product with the 56 columns of d nu+ / d [x0; x0_pre]: most of the survey's 1.60 MFLOP "
+                             "(the banded substitutions) are never executed, so `frac` measures speed in the survey's unit of work, not "
+                             "matrix-core utilisation -- `executed.frac_of_peak` does"}
         out = {
             "metric": "MPC steps/sec (n=27, VAR(2), T=30)",
             "value": world * B * steps_done / elapsed,
@@ -511,6 +522,8 @@ def main():
                        "batch_per_gpu": B, "n_newton": args.n_newton, "k": K_BAR,
                        "newton_iters_per_problem": iters_head / B, "in_flight": depth,
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)" if shared else "per problem",
+                       "cold_start_dual_solve": ("dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
+                                                 if shared and dense else "two sweeps through the shared block factor (panels of 16 problems)") if shared else None,
                        "gather": "all-gather of the first moves u0 (RCCL) every step, two buffers in turn" if dist_on else "none (1 GPU)",
                        "steps_requested": args.steps},
             "roofline": roof_pp if roof_pp is not None else roof_cold,

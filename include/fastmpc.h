@@ -270,7 +270,7 @@ int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
  * a chain of ~31 dependent steps), and the DENSE FORM nu+ = nuc + J [x0; x0_pre; w] as one product on the matrix
  * cores, J = d nu+ / d data built once per (handle, k) from the same factor.  The dense form is taken when w == NULL
  * (only the 56 columns of [x0; x0_pre] remain) and, with w, for batches of at most max_batch_with_w problems
- * (default 1024; environment FMPC_INV_MAX_BATCH, FMPC_NO_INV=1 switches the form off).  Both forms agree to
+ * (default 768; environment FMPC_INV_MAX_BATCH, FMPC_NO_INV=1 switches the form off).  Both forms agree to
  * round-off (tests/test_gpu_dense_form.py); a result does not depend on the batch it was solved in as long as the
  * form is the same.
  *   fmpc_set_dense_form: enabled 0/1, max_batch_with_w < 0 keeps the bound.  FMPC_E_UNSUPPORTED if the handle has

@@ -41,9 +41,12 @@ for c, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             per[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     res[name] = {k: {"launches": len(v), "KiB_per_launch": sum(v) / len(v)} for k, v in per.items()}
 kern = {}
+most = max([v["launches"] for k, v in res["FETCH_SIZE"].items() if k.startswith("fmpc")] or [0])
 for k in res["FETCH_SIZE"]:
     if not k.startswith("fmpc"):
         continue                                      # (prefix match: template arguments and torch fill kernels differ)
+    if 2 * res["FETCH_SIZE"][k]["launches"] < most:
+        continue                                      # one-off launches (factor export, the panel kernel building J): not part of a solve
     f = res["FETCH_SIZE"][k]["KiB_per_launch"] * 1024 * 2.0
     w = res["WRITE_SIZE"].get(k, {"KiB_per_launch": 0.0})["KiB_per_launch"] * 1024
     kern[k] = {"hbm_bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w}
