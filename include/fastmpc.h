@@ -48,7 +48,7 @@ extern "C" {
                                      fast_mpc_ineq_const.m:4-9, fast_mpc_objective.m:17-47,
                                      fast_mpc_init.m:13-14)                                    */
 #define FMPC_E_UNSUPPORTED   -3   /* valid for the reference, not implemented on the device
-                                     yet (non-diagonal R, n > 79, sizes beyond the LDS budget) */
+                                     yet (n > 79, sizes beyond the LDS budget, dense R with n > 47) */
 #define FMPC_E_NOT_PD_PHI    -4   /* chol(KKT_H) would fail (inf_newton_solver.m:24)          */
 #define FMPC_E_NOT_PD_SCHUR  -5   /* chol(Schur) would fail (inf_newton_solver.m:30)          */
 #define FMPC_E_HIP           -6   /* HIP runtime error                                         */
@@ -68,10 +68,13 @@ const char* fmpc_strerror(int code);
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
  *   n          <= 79 (n <= 64: fp64 kernels; 64 < n <= 79: fp32 factor + fp64 residuals, see fmpc_set_precision).
- *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:52-55).  Q, Qf: any symmetric positive definite matrix
- *              (dense Q or Qf: solved by the tiled kernel, n <= 47 in fp64, <= 79 with the fp32 factor); R must be
- *              diagonal (else FMPC_E_UNSUPPORTED).  Not positive definite / not symmetric: FMPC_E_NOT_PD_PHI
- *              (the reference's chol(KKT_H) error, inf_newton_solver.m:24).
+ *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices.  Dense Q or Qf:
+ *              solved by the tiled kernel, n <= 47 in fp64, <= 79 with the fp32 factor.  Dense R: the u block of Phi is
+ *              then a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS by the
+ *              tiled kernel in fp64 (n <= 47, m (m + 1) / 2 + m (n + 2) doubles of LDS: m = 144 fits); a generality
+ *              path, ~20 x slower than a diagonal R.  Ramp rows (fmpc_set_ramp) need diagonal weights.
+ *              Not positive definite / not symmetric: FMPC_E_NOT_PD_PHI (the reference's chol(KKT_H) error,
+ *              inf_newton_solver.m:24).
  *   q,r,qf     NULL = zeros (fast_mpc_objective.m:26-47).
  *   x_min/max  only used for the cold start (state bounds are not constraints,
  *              fast_mpc_ineq_const.m:25-40).

@@ -117,6 +117,8 @@ struct fmpc_handle_s {
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
     int denseQ;                          // Q or Qf not diagonal: tiled kernel only
+    int denseR;                          // R not diagonal: tiled kernel, fp64
+    std::vector<double> hm_r2full;       // 2R, m x m row-major
     std::vector<double> hm_q2m, hm_qf2m, hm_xm, hm_xfm;   // 2Q, 2Qf, (2Q)^-1, (2Qf)^-1 row-major
     // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
     double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
@@ -244,7 +246,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     if (!A1 || !B || (var_order == 2 && !A2)) return FMPC_E_NULL;   // fast_mpc_eq_const.m:19-25
     if (!Q || !R || !Qf || !x_min || !x_max || !u_min || !u_max) return FMPC_E_NULL;
     if (device < 0) return FMPC_E_NO_DEVICE;
-    if (!is_diag(R, m)) return FMPC_E_UNSUPPORTED;                  // dense R: a per-stage m x m factorisation, not built
+    // dense (symmetric positive definite) R: fast_mpc_objective.m:51-54 takes any square R.  Handled by the tiled kernel in
+    // fp64 (a per-stage m x m factorisation in LDS): n <= 47 and m (m + 1) / 2 + m (n + 2) doubles of LDS.
+    const bool denseR = !is_diag(R, m);
     // dense (symmetric positive definite) Q, Qf: fast_mpc_objective.m:52-55 takes any square Q, Qf.  Handled by the
     // tiled kernel only (the other kernels keep the state weights as diagonals).
     const bool denseQ = !is_diag(Q, n) || !is_diag(Qf, n);
@@ -256,12 +260,23 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
         for (int a = 0; a < n; ++a)
             for (int b = 0; b < a; ++b)
                 if (cm(Q, n, a, b) != cm(Q, n, b, a) || cm(Qf, n, a, b) != cm(Qf, n, b, a)) return FMPC_E_NOT_PD_PHI;
+    std::vector<double> R2full;
+    if (denseR) {
+        R2full.assign((size_t)m * m, 0.0);
+        for (int a = 0; a < m; ++a)
+            for (int b = 0; b < m; ++b) {
+                if (cm(R, m, a, b) != cm(R, m, b, a)) return FMPC_E_NOT_PD_PHI;
+                R2full[(size_t)a * m + b] = 2.0 * cm(R, m, a, b);
+            }
+        std::vector<double> tmp;
+        if (!spd_inverse(R2full, m, tmp)) return FMPC_E_NOT_PD_PHI;      // (the inverse itself is not used: a positive definiteness test)
+    }
     // per-problem-factor paths: the generic kernel (n <= 64 and its tiles fit the LDS), else the tiled kernel in fp64
     // (n <= 47), else the tiled kernel with an fp32 factor (n <= 79: "fp32 mixed precision", BASELINE configs[4])
     size_t lds = fmpc_generic_lds_bytes(n, m);
-    const bool generic_ok = !denseQ && n <= 64 && lds <= FMPC_LDS_LIMIT;
+    const bool generic_ok = !denseQ && !denseR && n <= 64 && lds <= FMPC_LDS_LIMIT;
     const int nb_ = T + (xf ? 1 : 0);
-    const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr);
+    const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr, denseR), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr, denseR);
     if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
     if (!generic_ok) lds = 0;
 
@@ -439,6 +454,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
     h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
     h->hm_a1f = a1; h->hm_a2f = a2;
+    h->denseR = denseR ? 1 : 0; h->hm_r2full = R2full;
     h->denseQ = denseQ ? 1 : 0; h->hm_q2m = Q2m; h->hm_qf2m = Qf2m; h->hm_xm = X; h->hm_xfm = Xf;
     h->hm_b.resize((size_t)n * m);
     for (int rr = 0; rr < n; ++rr)
@@ -447,7 +463,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // ---- wave kernel: MFMA-layout images of the constant blocks (+ a zero block), padded B'
     const char* force = getenv("FMPC_FORCE_GENERIC");
     const int mp = fmpc_wave_mp(m);
-    if (!denseQ && fmpc_wave_supports(n) && !(force && force[0] == '1') &&
+    if (!denseQ && !denseR && fmpc_wave_supports(n) && !(force && force[0] == '1') &&
         fmpc_wave_lds_bytes(n, mp) <= FMPC_LDS_LIMIT) {
         const int stride = fmpc_wave_img_stride(n);
         const int nblk = (int)blocks.size();
@@ -983,7 +999,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     fmpc_handle_s::Tiled& X = h->tl[t];
     const int n = h->n, m = h->m, nb = h->nb, nn = n * n;
     int NB = 0, NW = 0;
-    if (!fmpc_tiled_supports(n, m, nb, t, &NB, &NW)) return FMPC_E_UNSUPPORTED;
+    if (!fmpc_tiled_supports(n, m, nb, t, &NB, &NW, h->denseR)) return FMPC_E_UNSUPPORTED;
     const int mb = (m + 15) / 16, NQ = NB * NB;
     const int nblk = (int)(h->hm_blocks.size() / nn);
     std::vector<R> img((size_t)(nblk + 1) * NQ * FT_TILE + (size_t)mb * NB * FT_TILE, (R)0);
@@ -1003,7 +1019,8 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
     const int NP = 16 * NB, MP = 16 * mb;
     const size_t oBt = 0, oBm = oBt + (size_t)MP * NP, oA1 = oBm + (size_t)NP * MP, oA2 = oA1 + (size_t)NP * NP,
                  oA1t = oA2 + (size_t)NP * NP, oA2t = oA1t + (size_t)NP * NP, oQ2 = oA2t + (size_t)NP * NP,
-                 oQf2 = oQ2 + (size_t)NP * NP, oX = oQf2 + (size_t)NP * NP, oXf = oX + (size_t)NP * NP, ptot = oXf + (size_t)NP * NP;
+                 oQf2 = oQ2 + (size_t)NP * NP, oX = oQf2 + (size_t)NP * NP, oXf = oX + (size_t)NP * NP, oR2 = oXf + (size_t)NP * NP,
+                 ptot = oR2 + (h->denseR ? (size_t)MP * MP : 0);
     std::vector<double> pad(ptot, 0.0);
     for (int c = 0; c < m; ++c)
         for (int r = 0; r < n; ++r) {
@@ -1017,6 +1034,9 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
             pad[oQ2 + (size_t)a * NP + b] = h->hm_q2m[(size_t)a * n + b]; pad[oQf2 + (size_t)a * NP + b] = h->hm_qf2m[(size_t)a * n + b];
             pad[oX + (size_t)a * NP + b] = h->hm_xm[(size_t)a * n + b]; pad[oXf + (size_t)a * NP + b] = h->hm_xfm[(size_t)a * n + b];
         }
+    if (h->denseR)
+        for (int a = 0; a < m; ++a)
+            for (int b = 0; b < m; ++b) pad[oR2 + (size_t)a * MP + b] = h->hm_r2full[(size_t)a * m + b];
     if (hipMalloc(&X.pool, img.size() * sizeof(R)) != hipSuccess ||
         hipMalloc((void**)&X.ipool, ids.size() * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&X.bm, pad.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
@@ -1024,12 +1044,13 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
         hipMemcpy(X.ipool, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(X.bm, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     X.NB = NB; X.NW = NW;
-    X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t, nb);
-    if (fmpc_tiled_prepare(n, NB, NW, t, X.lds) != hipSuccess) return FMPC_E_HIP;
+    X.lds = fmpc_tiled_lds_bytes(NB, mb, NW, t, nb, h->denseR ? ft_pr_doubles(n, m) : 0);
+    if (fmpc_tiled_prepare(n, NB, NW, t, X.lds, h->denseR) != hipSuccess) return FMPC_E_HIP;
     X.V.NB = NB; X.V.mb = mb; X.V.cn = n / 16; X.V.nl = n % 16; X.V.nblk = nblk;
     X.V.yimg = X.pool; X.V.btimg = (const R*)X.pool + obt;
     X.V.iD = X.ipool; X.V.i1 = X.ipool + nb; X.V.i2 = X.ipool + 2 * nb;
     X.V.BtP = X.bm + oBt; X.V.BmP = X.bm + oBm; X.V.A1P = X.bm + oA1; X.V.A2P = X.bm + oA2; X.V.A1tP = X.bm + oA1t; X.V.A2tP = X.bm + oA2t;
+    X.V.denseR = h->denseR; X.V.R2P = h->denseR ? X.bm + oR2 : nullptr;
     X.V.denseQ = h->denseQ; X.V.Q2P = X.bm + oQ2; X.V.Qf2P = X.bm + oQf2; X.V.XP = X.bm + oX; X.V.XfP = X.bm + oXf;
     X.ready = 1;
     return FMPC_OK;
@@ -1049,7 +1070,7 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     if (wgs * X.NW > 8) wgs = 8 / X.NW > 0 ? 8 / X.NW : 1;             // two waves per SIMD (the kernel's launch bound)
     const int cap = h->num_cu * wgs;
     const int grid = batch < cap ? batch : cap;
-    const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8);
+    const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8, h->denseR);
     const size_t need = L.total * (size_t)cap;
     if (need > h->tl_ws_doubles) {
         if (h->tl_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->tl_ws); h->tl_ws = nullptr; h->tl_ws_doubles = 0; }
@@ -1069,7 +1090,7 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
 extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
     if (!h) return FMPC_E_NULL;
     if (mode != FMPC_PREC_F64 && mode != FMPC_PREC_F32_MIXED) return FMPC_E_DIM;
-    if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, h->nb, 1, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
+    if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, h->nb, 1, nullptr, nullptr, h->denseR)) return FMPC_E_UNSUPPORTED;
     if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(h->mu);
     h->prec = mode;
@@ -1228,7 +1249,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
     if (batch == 0) return FMPC_OK;
     const int max_iter = n_newton > 0 ? n_newton : 1000;
     hipError_t e;
-    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || (!h->use_wave && !h->generic_ok))
+    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
     if (h->use_wave) {
@@ -1477,7 +1498,7 @@ extern "C" int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* 
     for (int c = 0; c < h->m; ++c)
         if (!(du_min[c] < du_max[c])) return FMPC_E_DIM;
     const size_t lds = fmpc_ramp_lds_bytes(h->n, h->m);
-    if (h->n > 64 || lds > FMPC_LDS_LIMIT || h->denseQ) return FMPC_E_UNSUPPORTED;   // (the ramp kernel keeps Q, Qf as diagonals)
+    if (h->n > 64 || lds > FMPC_LDS_LIMIT || h->denseQ || h->denseR) return FMPC_E_UNSUPPORTED;   // (the ramp kernel keeps Q, Qf as diagonals)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->ramp_du) {
         if (hipMalloc((void**)&h->ramp_du, 2 * (size_t)h->m * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;

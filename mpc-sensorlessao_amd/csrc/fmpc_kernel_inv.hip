@@ -444,7 +444,16 @@ hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream) {
     const int variant = fmpc_inv_variant(P.npanels, P.gw != nullptr, P.jks);
     auto grid_for = [&](int RT, int PB) { return 8 * (((nrt + RT - 1) / RT + 7) / 8) * ((P.npanels + PB - 1) / PB) + ((P.npanels + 7) & ~7); };
     switch (variant) {
-    case 0: hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 4, 1, false>), dim3(grid_for(4, 2)), dim3(256), 0, stream, P); break;
+    case 0: {
+        static int shape = -2;
+        if (shape == -2) { const char* e = getenv("FMPC_INV_SHAPE0"); shape = e && e[0] ? atoi(e) : 0; }     // experiments
+        if (shape == 1) hipLaunchKernelGGL((fmpc_cold_inv_rg<4, 4, 1, false>), dim3(grid_for(4, 4)), dim3(256), 0, stream, P);
+        else if (shape == 2) hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 2, 1, false>), dim3(grid_for(2, 2)), dim3(128), 0, stream, P);
+        else if (shape == 3) hipLaunchKernelGGL((fmpc_cold_inv_rg<1, 4, 1, false>), dim3(grid_for(4, 1)), dim3(256), 0, stream, P);
+        else if (shape == 4) hipLaunchKernelGGL((fmpc_cold_inv_rg<4, 2, 1, false>), dim3(grid_for(2, 4)), dim3(128), 0, stream, P);
+        else hipLaunchKernelGGL((fmpc_cold_inv_rg<2, 4, 1, false>), dim3(grid_for(4, 2)), dim3(256), 0, stream, P);
+        break;
+    }
     case 1: hipLaunchKernelGGL((fmpc_cold_inv<16, 1>), dim3(8 * ((nrt + 7) / 8) * P.npanels + ((P.npanels + 7) & ~7)), dim3(1024), 0, stream, P); break;
     case 2: hipLaunchKernelGGL((fmpc_cold_inv_rg<1, 1, 4, true>), dim3(grid_for(1, 1)), dim3(256), 0, stream, P); break;
     case 3: hipLaunchKernelGGL((fmpc_cold_inv_rg<1, 2, 2, true>), dim3(grid_for(2, 1)), dim3(256), 0, stream, P); break;

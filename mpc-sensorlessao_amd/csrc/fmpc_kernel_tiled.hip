@@ -393,8 +393,72 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
 
 }
 
+// Dense R (fast_mpc_objective.m:51-54 takes any square R; inf_newton_KKT_H.m:13, inf_newton_solver.m:24): the u block of
+// Phi at stage j, Rt_j = 2R + k diag(1/s+^2 + 1/s-^2), is a dense symmetric positive definite m x m matrix.  Per stage, the
+// whole workgroup: Cholesky in LDS on the packed lower triangle (columns kept UNSCALED, L[i][k] = a[i][k] d[k] with
+// d[k] = 1/sqrt(pivot): one barrier per column), then the two substitutions on the m x (n + 1) right-hand sides
+// [B' | r_d[u_j]] in right-looking form (one barrier per row).  Out: zt[j][q][0..n] = [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]] -- what
+// the Schur complement (B Rt_j^-1 B'), the right-hand side and d_u need.  Returns 1 if a pivot is not positive.
+// (A generality path: ~4 m barriers and m^3/3 + 2 m^2 (n + 1) flops on the vector units per stage.)
+__device__ __noinline__ int ft_dense_r(double* sL, const double* R2P, int MP, const double* Bt, const double* hess,
+                                       const double* rdu, double* zt, int n, int m, int T) {
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int ZLD = n + 1;
+    double* sX = sL + (size_t)m * (m + 1) / 2;
+    double* sD = sX + (size_t)m * ZLD;
+    const int ty = tid >> 4, tx = tid & 15, NY = NT >> 4;          // triangle work: rows by ty, columns by tx
+    const int cy = tid >> 5, cx = tid & 31, NC = NT >> 5;          // right-hand sides: rows by cy, columns by cx (< ZLD)
+    int bad = 0;
+    for (int j = 0; j < T; ++j) {
+        __syncthreads();
+        for (int i = ty; i < m; i += NY)
+            for (int k = tx; k <= i; k += 16)
+                sL[(size_t)i * (i + 1) / 2 + k] = R2P[(size_t)i * MP + k] + (i == k ? hess[(size_t)j * m + i] : 0.0);
+        for (int e = tid; e < m * ZLD; e += NT) {
+            const int q = e / ZLD, c = e - q * ZLD;
+            sX[e] = c < n ? Bt[(size_t)q * n + c] : rdu[(size_t)j * m + q];
+        }
+        // ---- factor: a[i][jj] -= a[i][k] a[jj][k] / a[k][k]  for k < jj <= i
+        for (int k = 0; k < m; ++k) {
+            __syncthreads();
+            double dkk = sL[(size_t)k * (k + 1) / 2 + k];
+            if (!(dkk > 0.0) || isinf(dkk)) { bad = 1; dkk = 1.0; }
+            const double inv2 = 1.0 / dkk;
+            if (tid == 0) sD[k] = 1.0 / sqrt(dkk);
+            for (int i = k + 1 + ty; i < m; i += NY) {
+                const double aik = sL[(size_t)i * (i + 1) / 2 + k] * inv2;
+                for (int jj = k + 1 + tx; jj <= i; jj += 16)
+                    sL[(size_t)i * (i + 1) / 2 + jj] -= aik * sL[(size_t)jj * (jj + 1) / 2 + k];
+            }
+        }
+        // ---- forward: x[i] -= a[i][k] x[k] / a[k][k]  (i > k); then y[k] = x[k] d[k]
+        for (int k = 0; k < m; ++k) {
+            __syncthreads();
+            if (cx < ZLD) {
+                const double d = sD[k];
+                const double xk = sX[k * ZLD + cx] * d * d;
+                for (int i = k + 1 + cy; i < m; i += NC) sX[i * ZLD + cx] -= sL[(size_t)i * (i + 1) / 2 + k] * xk;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < m * ZLD; e += NT) sX[e] *= sD[e / ZLD];
+        // ---- backward: z[k] = v[k] d[k];  v[i] -= L[k][i] z[k] = a[k][i] d[i] z[k]  (i < k)
+        for (int k = m - 1; k >= 0; --k) {
+            __syncthreads();
+            if (cx < ZLD) {
+                const double zk = sX[k * ZLD + cx] * sD[k];
+                for (int i = cy; i < k; i += NC) sX[i * ZLD + cx] -= sL[(size_t)k * (k + 1) / 2 + i] * sD[i] * zk;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < m * ZLD; e += NT) zt[(size_t)j * m * ZLD + e] = sX[e] * sD[e / ZLD];
+    }
+    __syncthreads();
+    return bad;
+}
+
 // NL: live rows of the last 16-row block of a stage, n - 16 (NB - 1), when known at compile time (the AO sizes), else -1
-template <typename R, int NB, int NW, int NL>
+template <typename R, int NB, int NW, int NL, bool DR = false>
 __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     typedef FtT<R> TT;
     typedef typename TT::v4 v4;
@@ -411,7 +475,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     const bool var2 = M.var2 != 0;
     const int mb = V.mb, cn = V.cn, nl = V.nl;
 
-    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb);
+    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb, DR ? ft_pr_doubles(n, m) : 0);
     R* sBT = (R*)(smem + LL.bt);
     R* sSLOT = (R*)(smem + LL.slot);
     R* sLT = (R*)(smem + LL.lt);
@@ -428,8 +492,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     constexpr int LDN = 16 * NB + 1;
     const int TA = (nb + 15) / 16, NUROWS = 16 * TA + 2, MP = 16 * mb;
 
-    const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R));
+    const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R), DR ? 1 : 0);
     double* wsp = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    double* ztw = wsp + L.zt;                                       // dense R: [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]] per stage
+    const int ZLD = n + 1;
     double* b = wsp + L.b;
     double* nu = wsp + L.nu;
     double* hess = wsp + L.hess;
@@ -583,6 +649,13 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                         ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
                                     [&](int k) { return sNU[j * LDN + k]; },
                                     [&](int k) { return V.BmP[(size_t)k * MP + q]; });
+                        ft_d4 accr = {0, 0, 0, 0};
+                        if (DR) {                                           // dense R: (2R u_j)[q], one more stage-batched product
+                            const double* uj = zp + (size_t)(j < T ? j : T - 1) * s;
+                            ft_vec_gemm<12>(accr, MP, g,
+                                        [&](int k) { return uj[k < m ? k : m - 1]; },
+                                        [&](int k) { return V.R2P[(size_t)k * MP + q]; });
+                        }
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int jo = 16 * A + g + 4 * rr;
@@ -591,8 +664,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                                 const double dp = ft_rcp(M.umax[q] - u), dm = ft_rcp(u - M.umin[q]);
                                 const double hs = P.kbar * (dp * dp + dm * dm);
                                 const double rt = M.R2[q] + hs;
-                                if (!(rt > 0.0) || isinf(rt)) bad = 1;
-                                const double rd = M.R2[q] * u + M.rl[q] + P.kbar * (dp - dm) - acc[rr];
+                                if (!DR && (!(rt > 0.0) || isinf(rt))) bad = 1;     // (dense R: the factorisation below finds a bad pivot)
+                                if (DR && !(hs >= 0.0 && !isinf(hs))) bad = 1;
+                                const double rd = (DR ? accr[rr] : M.R2[q] * u) + M.rl[q] + P.kbar * (dp - dm) - acc[rr];
                                 hess[jo * m + q] = hs;
                                 winv[jo * m + q] = ft_rcp(rt);
                                 rdu[jo * m + q] = rd;
@@ -630,6 +704,13 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 }
                 __syncthreads();
             }
+            if (DR) {
+                // ================= dense R: factor Rt_j, [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]] of every stage (the LDS copy of nu is overwritten:
+                // nobody reads it before P4 writes d_nu there)
+                __syncthreads();
+                const int badr = ft_dense_r((double*)smem, V.R2P, MP, M.Bt, hess, rdu, ztw, n, m, T);
+                if (badr) { st = FMPC_E_NOT_PD_PHI; break; }
+            }
             FT_TICK(1);
 
             // ================= P2: rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into yv)
@@ -642,9 +723,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 const double* ph1 = phx + (size_t)((i >= 1 && i < T) ? i - 1 : 0) * n;
                 const double* ph2 = phx + (size_t)((i >= 2 && i < T) ? i - 2 : 0) * n;
                 const double f1 = (i >= 1 && i < T) ? 1.0 : 0.0, f2 = (i >= 2 && i < T) ? 1.0 : 0.0;
-                ft_vec_gemm<12>(acc, MP, g,
-                            [&](int k) { const int kc = k < m ? k : m - 1; return rdu[iu + kc] * winv[iu + kc]; },
-                            [&](int k) { return V.BtP[(size_t)k * NP + r]; });
+                if (DR)
+                    ft_vec_gemm<12>(acc, MP, g,
+                                [&](int k) { const int kc = k < m ? k : m - 1; return ztw[(iu + kc) * ZLD + n]; },
+                                [&](int k) { return V.BtP[(size_t)k * NP + r]; });
+                else
+                    ft_vec_gemm<12>(acc, MP, g,
+                                [&](int k) { const int kc = k < m ? k : m - 1; return rdu[iu + kc] * winv[iu + kc]; },
+                                [&](int k) { return V.BtP[(size_t)k * NP + r]; });
                 ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
                             [&](int k) { return ph1[k < n ? k : n - 1] * f1; },
                             [&](int k) { return V.A1tP[k * NP + r]; });
@@ -720,10 +806,17 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const R wk = wl[16 * kb + 4 * r + g];
+                                    const int qz = 16 * kb + 4 * r + g < m ? 16 * kb + 4 * r + g : m - 1;   // dense R: row of Z_i = Rt_i^-1 B'
 #pragma unroll
                                     for (int J = 0; J < NB; ++J) {
                                         x[J][r] = sBT[(size_t)(kb * NB + J) * FT_TILE + 64 * r + lane];
-                                        zw[J][r] = x[J][r] * wk;
+                                        if (DR) {
+                                            const int cz = 16 * J + c;
+                                            const double zv = ztw[((size_t)i * m + qz) * ZLD + (cz < n ? cz : n - 1)];
+                                            zw[J][r] = cz < n ? (R)zv : (R)0;                 // (column n of a tile row is the rhs)
+                                        } else {
+                                            zw[J][r] = x[J][r] * wk;
+                                        }
                                     }
                                 }
 #pragma unroll
@@ -961,7 +1054,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 
             // ================= P5: d_z, line-search scalars, update (the same stage-batched GEMMs with d_nu)
             double be = 0.0, e2 = 0.0;
-            for (int item = wv; item < NB * TA + mb * TA; item += NW) {          // (d_nu is in the staging area: written by P4)
+            for (int item = wv; item < NB * TA + (DR ? 0 : mb * TA); item += NW) {   // (d_nu is in the staging area: written by P4)
                 ft_d4 acc = {0, 0, 0, 0};
                 if (item < NB * TA) {
                     // ---- d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1' d_nu_j + A2' d_nu_{j+1}  [- d_nu_T])
@@ -1008,6 +1101,20 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             rdu[idx] = du;                              // reuse as d_u
                         }
                     }
+                }
+            }
+            if (DR) {
+                // ---- dense R: d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) = Z_j d_nu_j - t_j
+                for (int idx = tid; idx < T * m; idx += NT) {
+                    const int j = idx / m;
+                    const double* zr = ztw + (size_t)idx * ZLD;
+                    double du = -zr[n];
+                    for (int r = 0; r < n; ++r) du = fma(zr[r], sNU[j * LDN + r], du);
+                    const double rd = rdu[idx];
+                    const double e = hess[idx] * du;
+                    be += rd * e;
+                    e2 += e * e;
+                    rdu[idx] = du;                                      // reuse as d_u
                 }
             }
             if (V.denseQ) {
@@ -1071,18 +1178,26 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 }
 
 // ---------------------------------------------------------------- host side
-template <typename R, int NB, int NW, int NL = -1>
+template <typename R, int NB, int NW, int NL = -1, bool DR = false>
 static hipError_t ft_launch(const FtParams& P, int grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((fmpc_newton_tiled<R, NB, NW, NL>), dim3(grid), dim3(NW * 64), lds, stream, P);
+    hipLaunchKernelGGL((fmpc_newton_tiled<R, NB, NW, NL, DR>), dim3(grid), dim3(NW * 64), lds, stream, P);
     return hipGetLastError();
 }
-template <typename R, int NB, int NW, int NL = -1>
+template <typename R, int NB, int NW, int NL = -1, bool DR = false>
 static hipError_t ft_prepare(size_t lds) {
-    return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW, NL, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 // instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5); NW wavefronts per problem
 #define FT_DISPATCH(fn, ...)                                                                   \
+    /* dense R: fp64, four wavefronts (the per-stage m x m factorisation is workgroup-wide vector work) */                  \
+    if (denseR) {                                                                              \
+        if (is_float || NW != 4) return hipErrorInvalidValue;                                  \
+        if (NB == 1) return fn<double, 1, 4, -1, true>(__VA_ARGS__);                           \
+        if (NB == 2) return fn<double, 2, 4, -1, true>(__VA_ARGS__);                           \
+        if (NB == 3) return fn<double, 3, 4, -1, true>(__VA_ARGS__);                           \
+        return hipErrorInvalidValue;                                                           \
+    }                                                                                          \
     /* the AO sizes (n = 27 Zernike modes; n = 65: radial order 10) with their block structure at compile time, for the   \
        default wavefront counts only.  (<double, 2, 4, 11> is deliberately absent: that instance came out wrong in several  \
        builds -- deterministically, and differently from build to build -- while the same source with the block structure  \
@@ -1123,26 +1238,28 @@ static int ft_default_nw(int NB, int is_float) {
     return NW;
 }
 
-bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out) {
+bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR) {
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
     if (NB > (is_float ? 5 : 3)) return false;
-    const int NW = ft_default_nw(NB, is_float);
+    if (denseR && is_float) return false;
+    const int NW = denseR ? 4 : ft_default_nw(NB, is_float);
     const int mb = (m + 15) / 16;
-    if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total > 160 * 1024) return false;
+    if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb, denseR ? ft_pr_doubles(n, m) : 0).total > 160 * 1024) return false;
     if (NB_out) *NB_out = NB;
     if (NW_out) *NW_out = NW;
     return true;
 }
-size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb).total; }
+size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb, size_t pr_doubles) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb, pr_doubles).total; }
 static int ft_nlast(int n, int NB) {
     const char* e = getenv("FMPC_TILED_GENERIC");                 // experiments: the instance with the block structure at run time
     return (e && e[0] == '1') ? -1 : n - 16 * (NB - 1);
 }
-hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes) {
+hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes, int denseR) {
     const int nlast = ft_nlast(n, NB);
     FT_DISPATCH(ft_prepare, lds_bytes)
 }
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream) {
     const int nlast = ft_nlast(P.M.n, NB);
+    const int denseR = P.V.denseR;
     FT_DISPATCH(ft_launch, P, grid, lds_bytes, stream)
 }

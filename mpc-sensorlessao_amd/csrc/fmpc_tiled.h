@@ -42,18 +42,22 @@ struct FtModel {
                             // Phi^-1 are then applied as products with these symmetric [16 NB][16 NB] images
     const double* Q2P; const double* Qf2P;      // 2Q, 2Qf
     const double* XP; const double* XfP;        // (2Q)^-1, (2Qf)^-1
+    int denseR;             // R not diagonal (fast_mpc_objective.m:51-54 takes any square R): Rt_j = 2R + k diag(1/s+^2 + 1/s-^2) is a dense
+                            // m x m matrix per stage, factored in LDS; [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]] goes to the workspace (FtWs::zt)
+    const double* R2P;      // [16 mb][16 mb]: 2R, zero padded
 };
 
 // Per-workgroup scratch in HBM.  Vectors in doubles, then the factor stream in REAL.
 struct FtWs {
-    size_t b, nu, hess, winv, rdu, rdx, phx, rp, y, dnu, gt, fac, total;   // offsets in doubles
+    size_t b, nu, hess, winv, rdu, rdx, phx, rp, y, dnu, zt, gt, fac, total;   // offsets in doubles
 };
-__host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb, int NB, int real_bytes) {
+__host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb, int NB, int real_bytes, int denseR = 0) {
     FtWs L; size_t o = 0;
     const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
     auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 1) & ~(size_t)1; return r; };
     L.b = take(nbn); L.nu = take(nbn); L.hess = take(Tm); L.winv = take(Tm); L.rdu = take(Tm);
     L.rdx = take(Tn); L.phx = take(Tn); L.rp = take(nbn); L.y = take(nbn); L.dnu = take(nbn);
+    L.zt = take(denseR ? Tm * (size_t)(n + 1) : 0);             // dense R: [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]], m x (n + 1) per stage
     o = (o + 31) & ~(size_t)31;
     L.gt = o;                                                    // Y_ii const + B W_i B' (+ rhs column) of every block row, REAL
     o += ((size_t)nb * (NB * (NB + 1) / 2) * FT_TILE * real_bytes + 7) / 8;
@@ -69,7 +73,9 @@ __host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb,
 //   G pre-pass        the B' tiles [mb][NB] (B W_i B' for all stages, ahead of the serial factorisation)
 //   factor + sweeps   three U slots (NB^2 tiles each), the R tiles of the stage, W' of the diagonal tile, small vectors
 struct FtLds { size_t bt, slot, lt, wt, ysh, xv, part, wl, red, flag, total; };
-__host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes, int nb) {
+// pr_doubles: dense R only -- the packed lower triangle of Rt_j, the m x (n + 1) right-hand sides, m reciprocal pivots
+__host__ __device__ static inline size_t ft_pr_doubles(int n, int m) { return (size_t)m * (m + 1) / 2 + (size_t)m * (n + 1) + m; }
+__host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes, int nb, size_t pr_doubles = 0) {
     FtLds L; size_t o = 0;
     const size_t tile = (size_t)FT_TILE * real_bytes;
     L.bt = 0; L.slot = 0;
@@ -81,6 +87,7 @@ __host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, in
     const size_t nu_bytes = (size_t)(16 * ((nb + 15) / 16) + 2) * (16 * NB + 1) * sizeof(double);
     if (bt_bytes > o) o = bt_bytes;
     if (nu_bytes > o) o = nu_bytes;
+    if (pr_doubles * sizeof(double) > o) o = pr_doubles * sizeof(double);
     o = (o + 15) & ~(size_t)15;
     // outside the shared region: the x vectors of the backward sweep (live while d_nu is written to the staging area),
     // the Phi^-1 diagonal of NW stages during the S pre-pass
@@ -106,7 +113,7 @@ struct FtParams {
 };
 
 // supported (type, NB) pairs
-bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out);
-size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb);
-hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes);
+bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR = 0);
+size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb, size_t pr_doubles = 0);
+hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes, int denseR = 0);
 hipError_t fmpc_launch_tiled(const FtParams& P, int NB, int NW, int is_float, int grid, size_t lds_bytes, hipStream_t stream);

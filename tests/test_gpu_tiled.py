@@ -224,12 +224,51 @@ def test_dense_spd_state_weights(pkg, gpu, n, m, T, xf, nw, umax):
         assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p]))
 
 
+@pytest.mark.parametrize("n,m,T,xf,nw,umax,denseq", [(8, 5, 10, False, 5, 2.0, False), (8, 5, 10, True, 5, 2.0, True),
+                                                     (8, 5, 10, False, 8, 0.3, False), (27, 144, 10, False, 3, None, False),
+                                                     (27, 144, 4, False, 2, None, True), (20, 33, 5, False, 4, 2.0, False)])
+def test_dense_spd_input_weight(pkg, gpu, n, m, T, xf, nw, umax, denseq):
+    """Random symmetric positive definite R (fast_mpc_objective.m:51-54 takes any square R): the u block of Phi,
+    2R + k diag(1/s+^2 + 1/s-^2), is a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS
+    by the tiled kernel; alone and together with dense Q, Qf.  Oracle: the structured restatement with the same weights."""
+    if umax is None:
+        model = pkg.synthetic.make_model(n, m, T)
+        data = pkg.synthetic.make_replay_batch(model, r=6, steps=5)
+        model["R"] = _spd(m, 7)
+        if denseq:
+            model["Q"] = _spd(n, 1, 1.5e4); model["Qf"] = _spd(n, 2, 1.5e4)
+    else:
+        model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + T, umax=umax, xf=xf, batch=5)
+        model["R"] = _spd(m, 7)
+        if denseq:
+            model["Q"] = _spd(n, 1); model["Qf"] = _spd(n, 2, 50.0)
+    z, info, path = _solve(pkg, model, data, nw, 0.01)
+    assert path == pkg._lib.FMPC_PATH_TILED
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, 0.01)
+    assert np.array_equal(info["status"], sto) and np.array_equal(info["iters"], ito)
+    for p in range(5):
+        assert rel_err(z[p], zo[p]) <= TOL64, (p, rel_err(z[p], zo[p]))
+        assert rel_err(info["nu"][p], nuo[p]) <= 1e-7
+        assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p]))
+
+
 def test_dense_weights_error_codes(pkg, gpu):
     model, data = pkg.synthetic.make_test_problem(8, 5, 4, seed=1, batch=1)
-    bad = dict(model); bad["R"] = _spd(5, 3)
+    bad = dict(model); bad["R"] = _spd(5, 3); bad["R"][0, 1] += 1e-3          # not symmetric
     with pytest.raises(pkg.FastMPCError) as e:
-        handle_from_model(pkg, bad)                      # dense R: a per-stage m x m factorisation, not built
+        handle_from_model(pkg, bad)
+    assert e.value.code == pkg._lib.FMPC_E_NOT_PD_PHI
+    ind = _spd(5, 5); ind[0, 0] = 1e-3; ind[0, 1] = ind[1, 0] = 5.0          # symmetric, positive diagonal, indefinite
+    bad = dict(model); bad["R"] = ind
+    with pytest.raises(pkg.FastMPCError) as e:
+        handle_from_model(pkg, bad)
+    assert e.value.code == pkg._lib.FMPC_E_NOT_PD_PHI
+    ok = dict(model); ok["R"] = _spd(5, 3)
+    h = handle_from_model(pkg, ok)
+    with pytest.raises(pkg.FastMPCError) as e:
+        h.set_precision("f32")                           # dense R is solved in fp64 only
     assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    h.close()
     bad = dict(model); bad["Q"] = -_spd(8, 4)
     with pytest.raises(pkg.FastMPCError) as e:
         handle_from_model(pkg, bad)

@@ -60,10 +60,14 @@ def test_create_argument_checks(pkg):
     args = [one] * 14
     args[1] = nul                                     # A2 missing for VAR(2): fast_mpc_eq_const.m:21-22
     assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NULL
-    full = (C.c_double * 4)(1, 0.5, 0.5, 1)           # non-diagonal R: not on the device (dense Q, Qf are)
+    skewr = (C.c_double * 4)(1, 0.5, 0.25, 1)         # R not symmetric (dense symmetric positive definite R is solved)
     args = [one] * 14
-    args[4] = full
-    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_UNSUPPORTED
+    args[4] = skewr
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NOT_PD_PHI
+    indef = (C.c_double * 4)(1, 2, 2, 1)              # symmetric, positive diagonal, indefinite
+    args = [one] * 14
+    args[4] = indef
+    assert lib.fmpc_create(C.byref(h), 2, 2, 1, 2, *args, 0) == pkg.FMPC_E_NOT_PD_PHI
     skew = (C.c_double * 4)(1, 0.5, 0.25, 1)          # Q not symmetric: chol(KKT_H) of the reference would not see a PD matrix
     args = [one] * 14
     args[3] = skew
