@@ -18,7 +18,7 @@
 size_t fmpc_generic_lds_bytes(int n, int m);
 hipError_t fmpc_generic_prepare(size_t lds_bytes);
 // fmpc_kernel_ramp.hip
-size_t fmpc_ramp_lds_bytes(int n, int m);
+size_t fmpc_ramp_lds_bytes(int n, int m, int nbn);
 size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb);
 hipError_t fmpc_ramp_prepare(size_t lds_bytes);
 hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const double* dumax, int batch, int grid,
@@ -1497,7 +1497,7 @@ extern "C" int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* 
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
     for (int c = 0; c < h->m; ++c)
         if (!(du_min[c] < du_max[c])) return FMPC_E_DIM;
-    const size_t lds = fmpc_ramp_lds_bytes(h->n, h->m);
+    const size_t lds = fmpc_ramp_lds_bytes(h->n, h->m, h->nb * h->n);
     if (h->n > 64 || lds > FMPC_LDS_LIMIT || h->denseQ || h->denseR) return FMPC_E_UNSUPPORTED;   // (the ramp kernel keeps Q, Qf as diagonals)
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->ramp_du) {
@@ -1527,8 +1527,9 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
     const size_t stride = fmpc_ramp_ws_doubles(h->n, h->m, h->T, h->nb);
     // up to one problem per CU: 512-thread workgroups (latency: 0.61 instead of 0.82 ms per Newton step at n = 27,
     // m = 144, T = 10); beyond: 256-thread workgroups, 3 per CU (throughput: 4.3e5 instead of 3.6e5 problems/s)
-    const int threads = batch <= h->num_cu ? 512 : 256;
-    int cap = (threads == 512 ? 1 : 3) * h->num_cu;
+    int threads = 512;      // (8 wavefronts per problem, one problem per CU: faster than 3 x 256 threads per CU at every batch size)
+    { const char* e = getenv("FMPC_RAMP_THREADS"); if (e && e[0]) { const int t = atoi(e); if (t == 256 || t == 512 || t == 1024) threads = t; } }   // experiments
+    int cap = (threads == 256 ? 3 : 1) * h->num_cu;
     const size_t budget = (size_t)2 << 30;                         // doubles (16 GB) for all workgroups together
     if ((size_t)cap * stride > budget) cap = (int)(budget / stride);
     if (cap < 1) return FMPC_E_ALLOC;

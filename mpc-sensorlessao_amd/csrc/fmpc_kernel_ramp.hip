@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fmpc_device.h"
+#include "fmpc_tile_ops.h"
 #include "../../include/fastmpc.h"
 
 #define FR_MAX_HALVINGS 64
@@ -74,22 +75,139 @@ __host__ __device__ static inline FrWsLayout fr_ws_layout(int n, int m, int T, i
     L.rdu = o; o += Tm;  L.rdx = o; o += Tn;  L.phx = o; o += Tn;  L.phu = o; o += Tm;
     L.rp = o; o += nbn;  L.y = o; o += nbn;   L.dnu = o; o += nbn;
     L.G = o; o += (size_t)T * (T + 1) / 2 * m;
-    L.Y = o; o += (nbn + 1) * nbn;          // dense Y / its factor, row-major, plus the rhs as row nbn
-    L.W = o; o += (size_t)nb * n * n;       // L_JJ^-1 per diagonal block
+    const size_t NTl = (nbn + 1 + 15) / 16;  // 16 x 16 tiles covering [Y | rhs] (the rhs is column nbn)
+    L.Y = o; o += NTl * NTl * 256;          // dense Y / its factor R (Y = R'R), tile (I, J) at (I NTl + J) 256, upper triangle used
+    L.W = o; o += NTl * 256;                // R(kb,kb)^-1 per diagonal tile
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
 
 // Solve the tridiagonal system of actuator c in place (LDL' factors dg = pivots, lo = multipliers), stride m.
 __device__ __forceinline__ void fr_tri_solve(const double* dg, const double* lo, double* f, int T, int m, int c) {
-    for (int j = 1; j < T; ++j) f[j * m + c] -= lo[(j - 1) * m + c] * f[(j - 1) * m + c];
-    f[(T - 1) * m + c] /= dg[(T - 1) * m + c];
-    for (int j = T - 2; j >= 0; --j) f[j * m + c] = f[j * m + c] / dg[j * m + c] - lo[j * m + c] * f[(j + 1) * m + c];
+    // (the running value is carried in a register: a load of what the previous step stored would wait for that store)
+    double prev = f[c];
+    for (int j = 1; j < T; ++j) { const double cur = f[j * m + c] - lo[(j - 1) * m + c] * prev; f[j * m + c] = cur; prev = cur; }
+    prev = prev / dg[(T - 1) * m + c];
+    f[(T - 1) * m + c] = prev;
+    for (int j = T - 2; j >= 0; --j) { const double cur = f[j * m + c] / dg[j * m + c] - lo[j * m + c] * prev; f[j * m + c] = cur; prev = cur; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Dense Cholesky of Y in 16 x 16 tiles on the matrix cores, in the R form Y = R'R of the tiled kernel (fmpc_tile_ops.h):
+// Yt holds the upper tile triangle of [Y | rhs] (rhs = column nbn, so y = R^-T rhs appears in that column of the factor),
+// row-major tiles in HBM/L2, read as MFMA operands 64 consecutive elements at a time (every product is an X'Z).
+// Per 16-row block kb (left-looking):  P(kb,J) = Y(kb,J) - sum_{k<kb} R(k,kb)' R(k,J)  for the tiles J >= kb dealt to the
+// wavefronts; the owner of the diagonal tile factors it by 16 rank-1 updates (ft_potrf16: R(kb,kb) and W = R(kb,kb)^-T);
+// then R(kb,J) = W P(kb,J).  Two workgroup barriers per block row.  Afterwards the backward substitution R d_nu = y, one block
+// row at a time from the bottom (tile x vector products, 16 lanes per tile row, DPP row sums).
+// sh: 16 x 17 + 16 NTl + 16 NW + 16 doubles of LDS.  Returns 1 if a pivot is not positive.
+__device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, double* RIt, double* dnu, double* sh) {
+    typedef FtT<double> TT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6, c = lane & 15, g = lane >> 4;
+    double* sW = sh;                         // W' of the current diagonal tile, leading dimension 17
+    double* xs = sW + 16 * 17;               // d_nu, padded to 16 NTl
+    double* part = xs + 16 * NTl;            // [NW][16] partial sums of the backward substitution
+    double* tsh = part + 16 * NW;            // [16]
+    __shared__ int sfail;
+    if (tid == 0) sfail = 0;
+    __syncthreads();
+    for (int kb = 0; kb < NTl; ++kb) {
+        const int cnt = nbn - 16 * kb < 16 ? nbn - 16 * kb : 16;          // live rows of this block row
+        // ---- pass A: products with the block rows already done; the diagonal tile is factored, the others wait unscaled
+        for (int J = kb + wv; J < NTl; J += NW) {
+            double* tp = Yt + ((size_t)kb * NTl + J) * 256;
+            ft_d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = tp[TT::row(g, r) * 16 + c];
+#pragma unroll 2
+            for (int k = 0; k < kb; ++k) {
+                const double* X = Yt + ((size_t)k * NTl + kb) * 256;
+                const double* Z = Yt + ((size_t)k * NTl + J) * 256;
+                double xv[4], zv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { xv[r] = X[64 * r + lane]; zv[r] = Z[64 * r + lane]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = TT::mfma_sub(xv[r], zv[r], acc);
+            }
+            if (J == kb) {
+                ft_d4 Ro, Wo;
+                const bool ok = ft_potrf16<double>(acc, cnt, c, g, Ro, Wo);
+                if (!ok && lane == 0) sfail = 1;
+                double* ri = RIt + (size_t)kb * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sW[c * 17 + TT::row(g, r)] = Wo[r];
+                    ri[c * 16 + TT::row(g, r)] = Wo[r];
+                    tp[TT::row(g, r) * 16 + c] = Ro[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[TT::row(g, r) * 16 + c] = acc[r];
+            }
+        }
+        __syncthreads();
+        if (sfail) return 1;                                                // uniform
+        // ---- pass B: R(kb, J) = W P(kb, J)
+        {
+            double wop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wop[r] = sW[TT::row(g, r) * 17 + c];
+            for (int J = kb + wv; J < NTl; J += NW) {
+                if (J == kb) continue;
+                double* tp = Yt + ((size_t)kb * NTl + J) * 256;
+                ft_d4 pv, o = {0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = tp[TT::row(g, r) * 16 + c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[TT::row(g, r) * 16 + c] = o[r];
+            }
+        }
+        __syncthreads();                                                    // (the tiles of this block row are read by every wave from here on)
+    }
+    // ---- backward substitution: x_kb = R(kb,kb)^-1 (y_kb - sum_{J>kb} R(kb,J) x_J), y = column nbn of the factor
+    for (int i = tid; i < 16 * NTl; i += blockDim.x) xs[i] = 0.0;
+    const int yc = nbn & 15, yt = nbn >> 4;
+    for (int kb = NTl - 1; kb >= 0; --kb) {
+        __syncthreads();
+        double ps[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int J = kb + 1 + wv; J < NTl; J += NW) {
+            const double* tp = Yt + ((size_t)kb * NTl + J) * 256;
+            const double xv = xs[16 * J + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps[r] = fma(tp[64 * r + lane], xv, ps[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = ft_row16_sum<double>(ps[r]);
+            if (c == 0) part[wv * 16 + 4 * r + g] = v;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            double sacc = 0.0;
+            for (int q = 0; q < NW; ++q) sacc += part[q * 16 + tid];
+            tsh[tid] = Yt[((size_t)kb * NTl + yt) * 256 + tid * 16 + yc] - sacc;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int row = tid >> 4;
+            double v = RIt[(size_t)kb * 256 + row * 16 + c] * tsh[c];
+            v = ft_row16_sum<double>(v);
+            if (c == 0) {
+                const int e = 16 * kb + row;
+                xs[e] = e < nbn ? v : 0.0;
+                if (e < nbn) dnu[e] = v;
+            }
+        }
+    }
+    __syncthreads();
+    return 0;
 }
 
 // NT threads per workgroup: 256 (3 workgroups per CU, throughput) or 512 (one problem spread over twice the waves, latency)
 template <int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 2)
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : (NT == 512 ? 2 : 1))
 fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double* __restrict__ dumax, int batch,
                  const double* __restrict__ x0, const double* __restrict__ x0p, const double* __restrict__ w,
                  const double* __restrict__ uprev, const double* zinit, const double* __restrict__ nu0,
@@ -112,6 +230,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
     double* srs = sv + n;                 // n     1/sqrt(pivot)
     double* sred = srs + n;               // NW x 64 partial sums of the backward substitution
     double* red = sred + NW * 64;   // NW
+    double* sCh = red + 16;         // scratch of fr_tile_cholesky: 16 x 17 + 16 NTl + 16 NW + 16
 
     for (int i = tid; i < m * n; i += NT) sBt[i] = M.Bt[i];
 
@@ -241,18 +360,22 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                 }
                 for (int j = 0; j < T; ++j) phu[j * m + c] = rdu[j * m + c];
                 fr_tri_solve(dg, lo, phu, T, m, c);
-                // inverse, pairs (i <= j) at index i*T - i(i-1)/2 + (j - i):  inv[j][k] = -l_j inv[j+1][k] (k > j),
-                // inv[j][j] = 1/d_j + l_j^2 inv[j+1][j+1]
-                for (int j = T - 1; j >= 0; --j) {
-                    const size_t rowj = (size_t)j * T - (size_t)j * (j - 1) / 2;
-                    if (j == T - 1) {
-                        G[rowj * m + c] = 1.0 / dg[j * m + c];
-                    } else {
-                        const size_t rown = (size_t)(j + 1) * T - (size_t)(j + 1) * j / 2;
-                        const double lj = lo[j * m + c];
-                        for (int k2 = j + 1; k2 < T; ++k2)
-                            G[(rowj + (k2 - j)) * m + c] = -lj * G[(rown + (k2 - j - 1)) * m + c];
-                        G[rowj * m + c] = 1.0 / dg[j * m + c] + lj * lj * G[rown * m + c];
+                // inverse, pairs (i <= j) at index i*T - i(i-1)/2 + (j - i):  inv[j][j] = 1/d_j + l_j^2 inv[j+1][j+1] ,
+                // inv[j][k] = -l_j inv[j+1][k] (k > j) = (-l_j)(-l_{j+1}) ... (-l_{k-1}) inv[k][k]: the diagonal as one chain carried in
+                // a register, then every column k upwards from its diagonal entry -- no load of a value this thread has just stored
+                {
+                    double dprev = 0.0;
+                    for (int j = T - 1; j >= 0; --j) {
+                        const size_t rowj = (size_t)j * T - (size_t)j * (j - 1) / 2;
+                        const double lj = j + 1 < T ? lo[j * m + c] : 0.0;
+                        const double dv = 1.0 / dg[j * m + c] + lj * lj * dprev;
+                        G[rowj * m + c] = dv;
+                        double v = dv;
+                        for (int i = j - 1; i >= 0; --i) {            // column j: rows i < j
+                            v *= -lo[i * m + c];
+                            G[((size_t)i * T - (size_t)i * (i - 1) / 2 + (j - i)) * m + c] = v;
+                        }
+                        dprev = dv;
                     }
                 }
             }
@@ -282,13 +405,89 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             __syncthreads();
             FR_TICK(1);
 
-            // ================= P3: Y (lower block triangle, dense) into the workspace; the rhs as an extra ROW (nbn)
-            // Y_IJ = Yx_IJ + B diag(g^{JI}) B' on the matrix cores: a wave per 16 x 16 output tile, k = 4 actuators per
-            // MFMA; A operand B[a][c] g_c (row a = lane % 16, c = 4 ks + lane / 16), B operand B[b][c]; result
-            // register r of lane (lk, li) is element (4 r + lk, li) of the tile.
-            for (int idx = tid; idx < nbn; idx += NT) Yd[(size_t)nbn * nbn + idx] = y[idx];
-            // (no workgroup barrier in this phase: every wave walks its own (block, tile) tasks)
-            {
+            // ================= P3: [Y | rhs] into the workspace as 16 x 16 tiles (upper tile triangle; fr_tile_cholesky).
+            // Y_IJ = Yx_IJ + B diag(g^{JI}) B' on the matrix cores: a wave per 16 x 16 piece of a block, k = 4 actuators per
+            // MFMA; A operand B[a][c] g_c (row a = lane % 16, c = 4 ks + lane / 16), B operand B[b][c]; result register r of
+            // lane (lk, li) is element (4 r + lk, li) of the piece.  The blocks (n x n) and the tiles (16 x 16) do not line up:
+            // every element goes to its tile on its own; a diagonal tile receives both halves.
+            const int NTl = (nbn + 1 + 15) >> 4;
+            for (size_t idx = tid; idx < (size_t)NTl * NTl * 256; idx += NT) Yd[idx] = 0.0;
+            __syncthreads();
+            auto put = [&](int gr_, int gc_, double v) {                    // element (gr_, gc_), tile row <= tile column
+                Yd[((size_t)(gr_ >> 4) * NTl + (gc_ >> 4)) * 256 + (gr_ & 15) * 16 + (gc_ & 15)] = v;
+            };
+            for (int idx = tid; idx < nbn; idx += NT) put(idx, nbn, y[idx]);
+            // (no workgroup barrier in this phase: every wave walks its own blocks)
+            if (ntile <= 2) {
+                // n <= 32: a wave takes a whole block (I, J) with its (up to) four 16 x 16 pieces in registers: per k-step
+                // (4 actuators) two LDS reads and two multiplications by g feed four products.
+                const int nblk = nb * (nb + 1) / 2;
+                const int ra0 = li < n ? li : n - 1, ra1 = 16 + li < n ? 16 + li : n - 1;
+                for (int blk = wv; blk < nblk; blk += NW) {
+                    int I = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);          // blk = I (I + 1) / 2 + J , J <= I
+                    while (I * (I + 1) / 2 > blk) --I;
+                    while ((I + 1) * (I + 2) / 2 <= blk) ++I;
+                    const int J = blk - I * (I + 1) / 2;
+                    const bool hasu = I < T;                         // (J <= I): both stages carry u
+                    const double* Yc = nullptr; bool tr = false;
+                    if (I == J) Yc = M.Yblk + (size_t)M.idxD[I] * n * n;
+                    else if (I == J + 1 && M.idx1[J] >= 0) { Yc = M.Yblk + (size_t)M.idx1[J] * n * n; tr = true; }
+                    else if (I == J + 2 && M.idx2[J] >= 0) { Yc = M.Yblk + (size_t)M.idx2[J] * n * n; tr = true; }
+                    // everything the block reads from memory first: the constant part of its elements, then g
+                    double yc4[2][2][4];
+                    const double* ysrc = Yc ? Yc : M.Yblk;             // (no constant part: any valid address, times zero)
+                    const double ycf = Yc ? 1.0 : 0.0;
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int arow = 16 * ta + 4 * r + lk, bcol = 16 * tb + li;
+                                const int ar = arow < n ? arow : n - 1, bc = bcol < n ? bcol : n - 1;
+                                yc4[ta][tb][r] = ysrc[tr ? bc * n + ar : ar * n + bc];
+                            }
+                    d4 acc[2][2];
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = (d4){0, 0, 0, 0};
+                    if (hasu) {
+                        const double* gv = G + ((size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J)) * m;
+                        for (int c0 = 0; c0 < m; c0 += 144) {
+                            double gq[36];
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) { const int cq = c0 + 4 * q + lk; gq[q] = gv[cq < m ? cq : m - 1]; }
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) {             // (straight-line: past m the A operands are zero)
+                                const int cq = c0 + 4 * q + lk;
+                                const int cc = cq < m ? cq : m - 1;
+                                const double gm = cq < m ? gq[q] : 0.0;
+                                const double x0 = sBt[cc * n + ra0], x1 = sBt[cc * n + ra1];
+                                const double z0 = x0 * gm, z1 = x1 * gm;
+                                acc[0][0] = MFMA64(z0, x0, acc[0][0]);
+                                acc[1][0] = MFMA64(z1, x0, acc[1][0]);
+                                acc[1][1] = MFMA64(z1, x1, acc[1][1]);
+                                acc[0][1] = MFMA64(z0, x1, acc[0][1]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int arow = 16 * ta + 4 * r + lk, bcol = 16 * tb + li;
+                                if (arow < n && bcol < n && (I != J || arow >= bcol)) {
+                                    const double v = acc[ta][tb][r] + ycf * yc4[ta][tb][r];
+                                    const int gr_ = I * n + arow, gc_ = J * n + bcol;      // gr_ >= gc_: the element of the lower triangle
+                                    put(gc_, gr_, v);
+                                    if ((gr_ >> 4) == (gc_ >> 4) && gr_ != gc_) put(gr_, gc_, v);
+                                }
+                            }
+                }
+            } else {
                 const int nblk = nb * (nb + 1) / 2, tpb = ntile * ntile;
                 for (int task = wv; task < nblk * tpb; task += NW) {
                     const int blk = task / tpb, tp = task - blk * tpb;
@@ -297,191 +496,59 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                     while ((I + 1) * (I + 2) / 2 <= blk) ++I;
                     const int J = blk - I * (I + 1) / 2;
                     const int ta = tp / ntile, tb = tp - ta * ntile;
+                    if (I == J && ta < tb) continue;                  // diagonal blocks: the lower pieces, mirrored below
                     const bool hasu = I < T;                         // (J <= I): both stages carry u
                     const double* Yc = nullptr; bool tr = false;
                     if (I == J) Yc = M.Yblk + (size_t)M.idxD[I] * n * n;
                     else if (I == J + 1 && M.idx1[J] >= 0) { Yc = M.Yblk + (size_t)M.idx1[J] * n * n; tr = true; }
                     else if (I == J + 2 && M.idx2[J] >= 0) { Yc = M.Yblk + (size_t)M.idx2[J] * n * n; tr = true; }
                     d4 acc = {0, 0, 0, 0};
-                    if (hasu) {
-                        const double* gv = G + ((size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J)) * m;
-                        const int ra = 16 * ta + li < n ? 16 * ta + li : n - 1, rb = 16 * tb + li < n ? 16 * tb + li : n - 1;
-                        int c0 = 0;
-                        for (; c0 + 16 <= m; c0 += 16) {
-                            double gq[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) gq[q] = gv[c0 + 4 * q + lk];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int c = c0 + 4 * q + lk;
-                                acc = MFMA64(sBt[c * n + ra] * gq[q], sBt[c * n + rb], acc);
-                            }
-                        }
-                        for (; c0 < m; c0 += 4) {
-                            const int c = c0 + lk;
-                            const bool ok = c < m;
-                            const int cc = ok ? c : m - 1;
-                            const double bv = sBt[cc * n + rb];
-                            const double av = ok ? sBt[cc * n + ra] * gv[cc] : 0.0;
-                            acc = MFMA64(av, bv, acc);
-                        }
-                    }
                     const int bcol = 16 * tb + li;
+                    // everything the task reads from memory first: the constant part of its four elements, then g
+                    double yc4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int arow = 16 * ta + 4 * r + lk;
-                        if (arow < n && bcol < n)
-                            Yd[(size_t)(I * n + arow) * nbn + J * n + bcol] =
-                                acc[r] + (Yc ? (tr ? Yc[bcol * n + arow] : Yc[arow * n + bcol]) : 0.0);
+                        const int ar = arow < n ? arow : n - 1, bc = bcol < n ? bcol : n - 1;
+                        const double* ysrc = Yc ? Yc : M.Yblk;                 // (no constant part: any valid address, times zero)
+                        yc4[r] = ysrc[tr ? bc * n + ar : ar * n + bc];
+                    }
+                    const double ycf = Yc ? 1.0 : 0.0;
+                    if (hasu) {
+                        const double* gv = G + ((size_t)J * T - (size_t)J * (J - 1) / 2 + (I - J)) * m;
+                        const int ra = 16 * ta + li < n ? 16 * ta + li : n - 1, rb = 16 * tb + li < n ? 16 * tb + li : n - 1;
+                        // 36 k-steps (144 actuators) at a time: their g values are requested before the first product
+                        for (int c0 = 0; c0 < m; c0 += 144) {
+                            double gq[36];
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) { const int cq = c0 + 4 * q + lk; gq[q] = gv[cq < m ? cq : m - 1]; }
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) {             // (straight-line: past m the A operand is zero)
+                                const int cq = c0 + 4 * q + lk;
+                                const int cc = cq < m ? cq : m - 1;
+                                const double msk = cq < m ? 1.0 : 0.0;
+                                acc = MFMA64(sBt[cc * n + ra] * (gq[q] * msk), sBt[cc * n + rb], acc);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int arow = 16 * ta + 4 * r + lk;
+                        if (arow < n && bcol < n && (I != J || arow >= bcol)) {
+                            const double v = acc[r] + ycf * yc4[r];
+                            const int gr_ = I * n + arow, gc_ = J * n + bcol;      // gr_ >= gc_: the element of the lower triangle
+                            put(gc_, gr_, v);
+                            if ((gr_ >> 4) == (gc_ >> 4) && gr_ != gc_) put(gr_, gc_, v);
+                        }
                     }
                 }
             }
             __syncthreads();
             FR_TICK(2);
 
-            // ================= P4: blocked left-looking Cholesky of Y in place, block column J at a time:
-            //   1. M[r][:] = Y[r][J-block] - L[r][0:K] L[J-block rows][0:K]'  for every row r >= J n (K = J n): MFMA,
-            //      operands straight from the workspace (L2 / L1); the rhs row nbn rides along (forward substitution)
-            //   2. S = M of the diagonal block -> LDS; potrf with the SAME row operations applied to an identity, which
-            //      leaves W = L_JJ^-1 (no serial triangular solves)
-            //   3. L[r][J-block] = M[r][:] W'  for the rows below (and the rhs row): MFMA, K = n
-            bool fail = false;
-            for (int J = 0; J < nb && !fail; ++J) {
-                const int K = J * n, r_lo = J * n, nrow = nbn + 1 - r_lo;
-                const int nrt = (nrow + 15) >> 4;
-                if (K > 0) {
-                    for (int tp = wv; tp < nrt * ntile; tp += NW) {
-                        const int rt = tp / ntile, tb = tp - rt * ntile;
-                        const int ra = r_lo + 16 * rt + li <= nbn ? r_lo + 16 * rt + li : nbn;
-                        const int rb = 16 * tb + li < n ? r_lo + 16 * tb + li : r_lo + n - 1;
-                        const double* pa = Yd + (size_t)ra * nbn;
-                        const double* pb = Yd + (size_t)rb * nbn;
-                        d4 acc = {0, 0, 0, 0};
-                        int c0 = 0;
-                        for (; c0 + 16 <= K; c0 += 16) {
-                            double av[4], bv[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { av[q] = pa[c0 + 4 * q + lk]; bv[q] = pb[c0 + 4 * q + lk]; }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) acc = MFMA64(av[q], bv[q], acc);
-                        }
-                        for (; c0 < K; c0 += 4) {
-                            const int c = c0 + lk;
-                            const bool ok = c < K;
-                            const double a1 = pa[ok ? c : K - 1], b1 = pb[ok ? c : K - 1];
-                            acc = MFMA64(ok ? a1 : 0.0, b1, acc);
-                        }
-                        const int bcol = 16 * tb + li;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = r_lo + 16 * rt + 4 * r + lk;
-                            if (row <= nbn && bcol < n) Yd[(size_t)row * nbn + r_lo + bcol] -= acc[r];
-                        }
-                    }
-                    __syncthreads();
-                }
-                // ---- 2. diagonal block
-                for (int idx = tid; idx < n * n; idx += NT) {
-                    const int a2 = idx / n, bb = idx - a2 * n;
-                    tA[a2 * ldt + bb] = Yd[(size_t)(r_lo + a2) * nbn + r_lo + bb];
-                    tB[a2 * ldt + bb] = a2 == bb ? 1.0 : 0.0;
-                }
-                __syncthreads();
-                for (int k2 = 0; k2 < n; ++k2) {
-                    const double piv = tA[k2 * ldt + k2];
-                    if (!(piv > 0.0) || isinf(piv)) { fail = true; break; }      // uniform
-                    const double ip = 1.0 / piv;
-                    if (tid == 0) srs[k2] = 1.0 / sqrt(piv);
-                    const int rem = n - k2 - 1;
-                    // rows r > k2:  S[r][c] -= l S[c][k2] (c = k2+1 .. r) ,  Wm[r][c] -= l Wm[k2][c] (c = 0 .. k2) ,  l = S[r][k2] / piv
-                    for (int idx = tid; idx < rem * n; idx += NT) {
-                        const int r = k2 + 1 + idx / n, c = idx % n;
-                        const double l = tA[r * ldt + k2] * ip;
-                        if (c <= k2) tB[r * ldt + c] -= l * tB[k2 * ldt + c];
-                        else if (c <= r) tA[r * ldt + c] -= l * tA[c * ldt + k2];
-                    }
-                    __syncthreads();
-                }
-                if (fail) break;
-                {
-                    double* Wj = Wg + (size_t)J * n * n;
-                    for (int idx = tid; idx < n * n; idx += NT) {
-                        const int r = idx / n, c = idx - r * n;
-                        const double v = c <= r ? tB[r * ldt + c] * srs[r] : 0.0;    // L^-1 = D^-1/2 (unit lower)^-1
-                        tB[r * ldt + c] = v;
-                        Wj[idx] = v;
-                    }
-                }
-                __syncthreads();
-                // ---- 3. rows below the diagonal block (and the rhs row): X = M W'.  A wave owns whole rows: it reads a
-                //         row tile completely before it overwrites it.
-                {
-                    const int r1 = r_lo + n, nrow2 = nbn + 1 - r1;
-                    const int nrt2 = (nrow2 + 15) >> 4;
-                    for (int rt = wv; rt < nrt2; rt += NW) {
-                        const int ra = r1 + 16 * rt + li <= nbn ? r1 + 16 * rt + li : nbn;
-                        const double* pa = Yd + (size_t)ra * nbn + r_lo;
-                        double av[FR_MAXKS];
-#pragma unroll
-                        for (int ks = 0; ks < FR_MAXKS; ++ks) {
-                            const int c = 4 * ks + lk;
-                            const double t1 = pa[c < n ? c : n - 1];
-                            av[ks] = c < n ? t1 : 0.0;
-                        }
-                        // (all of the row tile is in registers now: the column tiles may be overwritten one by one)
-#pragma nounroll
-                        for (int tb = 0; tb < ntile; ++tb) {
-                            d4 acc = {0, 0, 0, 0};
-                            const int rb = 16 * tb + li < n ? 16 * tb + li : n - 1;
-#pragma unroll
-                            for (int ks = 0; ks < FR_MAXKS; ++ks) {
-                                if (4 * ks < n) {
-                                    const int c = 4 * ks + lk < n ? 4 * ks + lk : n - 1;
-                                    acc = MFMA64(av[ks], tB[rb * ldt + c], acc);
-                                }
-                            }
-                            const int bcol = 16 * tb + li;
-                            if (bcol < n) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = r1 + 16 * rt + 4 * r + lk;
-                                    if (row <= nbn) Yd[(size_t)row * nbn + r_lo + bcol] = acc[r];
-                                }
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
+            // ================= P4: Cholesky of Y on 16 x 16 tiles (forward substitution in the rhs column), backward substitution
+            if (fr_tile_cholesky(Yd, NTl, nbn, Wg, dnu, sCh)) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FR_TICK(3);
-            // ---- backward substitution  L' d_nu = yy  (yy = the rhs row after the factorisation):
-            //      v = yy_J - sum_{r below} L[r][J-block] d_nu[r] ;  d_nu_J = W_J' v
-            for (int J = nb - 1; J >= 0; --J) {
-                const int r_lo = J * n, r1 = r_lo + n;
-                {
-                    const int bb = tid & 63, grp = tid >> 6;
-                    double part = 0.0;
-                    if (bb < n)
-                        for (int r = r1 + grp; r < nbn; r += NW) part += Yd[(size_t)r * nbn + r_lo + bb] * dnu[r];
-                    sred[grp * 64 + bb] = part;
-                }
-                __syncthreads();
-                if (tid < n) {
-                    double acc2 = 0.0;
-                    for (int q = 0; q < NW; ++q) acc2 += sred[q * 64 + tid];
-                    sv[tid] = Yd[(size_t)nbn * nbn + r_lo + tid] - acc2;
-                }
-                __syncthreads();
-                if (tid < n) {
-                    const double* Wj = Wg + (size_t)J * n * n;
-                    double v = 0.0;
-                    for (int bb = tid; bb < n; ++bb) v += Wj[bb * n + tid] * sv[bb];
-                    dnu[r_lo + tid] = v;
-                }
-                __syncthreads();
-            }
-
             FR_TICK(4);
             // ================= P5: d_z, line-search scalars, update
             for (int idx = tid; idx < T * m; idx += NT) {           // rhs of Phi_u d_u = B' d_nu_j - r_d,u
@@ -553,8 +620,9 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
 }
 
 // ---------------------------------------------------------------- host side
-size_t fmpc_ramp_lds_bytes(int n, int m) {      // sized for the 512-thread variant (8 waves)
-    const size_t d = (size_t)m * n + 2 * (size_t)n * (n + 1) + 2 * (size_t)n + 8 * 64 + 8;
+size_t fmpc_ramp_lds_bytes(int n, int m, int nbn) {      // sized for the 1024-thread variant (16 waves)
+    const size_t ntl = ((size_t)nbn + 1 + 15) / 16;
+    const size_t d = (size_t)m * n + 2 * (size_t)n * (n + 1) + 2 * (size_t)n + 16 * 64 + 16 + (16 * 17 + 16 * ntl + 16 * 16 + 16);
     return d * sizeof(double);
 }
 size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb) { return fr_ws_layout(n, m, T, nb).total; }
@@ -562,7 +630,9 @@ size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb) { return fr_ws_layout(n
 hipError_t fmpc_ramp_prepare(size_t lds_bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)fmpc_newton_ramp<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)fmpc_newton_ramp<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipFuncSetAttribute((const void*)fmpc_newton_ramp<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)fmpc_newton_ramp<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const double* dumax, int batch, int grid,
@@ -570,8 +640,11 @@ hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const do
                             const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
                             double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
                             size_t ws_stride, int threads, hipStream_t stream) {
-    const size_t lds = fmpc_ramp_lds_bytes(M.n, M.m);
-    if (threads == 512)
+    const size_t lds = fmpc_ramp_lds_bytes(M.n, M.m, M.nb * M.n);
+    if (threads == 1024)
+        hipLaunchKernelGGL(fmpc_newton_ramp<1024>, dim3(grid), dim3(1024), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+    else if (threads == 512)
         hipLaunchKernelGGL(fmpc_newton_ramp<512>, dim3(grid), dim3(512), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
                            zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
     else
