@@ -29,6 +29,7 @@
 
 #define FR_MAX_HALVINGS 64
 #define FR_MAXKS 16                     // k-steps of 4 covering n <= 64
+#define FR_OWN 3                        // tiles of a block row a wavefront keeps in registers (fr_tile_cholesky)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -111,15 +112,23 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
     __shared__ int sfail;
     if (tid == 0) sfail = 0;
     __syncthreads();
+    // A wavefront keeps up to FR_OWN tiles of a block row in registers between the two passes; with more tiles per wavefront
+    // (long horizons, few wavefronts) the unscaled tiles wait in the workspace instead.
+    const bool inreg = (NTl + NW - 1) / NW <= FR_OWN;
     for (int kb = 0; kb < NTl; ++kb) {
         const int cnt = nbn - 16 * kb < 16 ? nbn - 16 * kb : 16;          // live rows of this block row
+        ft_d4 own[FR_OWN];
+#ifdef FW_TIMING
+        const unsigned long long _ta = (unsigned long long)wall_clock64();
+#endif
         // ---- pass A: products with the block rows already done; the diagonal tile is factored, the others wait unscaled
-        for (int J = kb + wv; J < NTl; J += NW) {
+        int slot = 0;
+        for (int J = kb + wv; J < NTl; J += NW, ++slot) {
             double* tp = Yt + ((size_t)kb * NTl + J) * 256;
             ft_d4 acc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] = tp[TT::row(g, r) * 16 + c];
-#pragma unroll 2
+#pragma unroll 4
             for (int k = 0; k < kb; ++k) {
                 const double* X = Yt + ((size_t)k * NTl + kb) * 256;
                 const double* Z = Yt + ((size_t)k * NTl + J) * 256;
@@ -140,24 +149,37 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
                     ri[c * 16 + TT::row(g, r)] = Wo[r];
                     tp[TT::row(g, r) * 16 + c] = Ro[r];
                 }
+            } else if (inreg) {
+#pragma unroll
+                for (int q = 0; q < FR_OWN; ++q) if (q == slot) own[q] = acc;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tp[TT::row(g, r) * 16 + c] = acc[r];
             }
         }
         __syncthreads();
+#ifdef FW_TIMING
+        if (blockIdx.x == 0 && tid == 0) fr_timing[6] += (unsigned long long)wall_clock64() - _ta;
+#endif
         if (sfail) return 1;                                                // uniform
         // ---- pass B: R(kb, J) = W P(kb, J)
         {
             double wop[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) wop[r] = sW[TT::row(g, r) * 17 + c];
-            for (int J = kb + wv; J < NTl; J += NW) {
+            slot = 0;
+            for (int J = kb + wv; J < NTl; J += NW, ++slot) {
                 if (J == kb) continue;
                 double* tp = Yt + ((size_t)kb * NTl + J) * 256;
                 ft_d4 pv, o = {0, 0, 0, 0};
+                if (inreg) {
+                    pv = own[0];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pv[r] = tp[TT::row(g, r) * 16 + c];
+                    for (int q = 1; q < FR_OWN; ++q) if (q == slot) pv = own[q];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = tp[TT::row(g, r) * 16 + c];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
 #pragma unroll
@@ -169,14 +191,43 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
     // ---- backward substitution: x_kb = R(kb,kb)^-1 (y_kb - sum_{J>kb} R(kb,J) x_J), y = column nbn of the factor
     for (int i = tid; i < 16 * NTl; i += blockDim.x) xs[i] = 0.0;
     const int yc = nbn & 15, yt = nbn >> 4;
+#ifdef FW_TIMING
+    const unsigned long long _tb = (unsigned long long)wall_clock64();
+#endif
     for (int kb = NTl - 1; kb >= 0; --kb) {
+        // (everything this block row reads from memory is requested before the barrier that publishes x of the row below)
+        double tv[FR_OWN][4];
+        int nown = 0;
+        for (int J = kb + 1 + wv; J < NTl && nown < FR_OWN; J += NW, ++nown) {
+            const double* tp = Yt + ((size_t)kb * NTl + J) * 256;
+#pragma unroll
+            for (int q = 0; q < FR_OWN; ++q)
+                if (q == nown) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tv[q][r] = tp[64 * r + lane];
+                }
+        }
+        const double riv = tid < 256 ? RIt[(size_t)kb * 256 + tid] : 0.0;
+        const double yv0 = tid < 16 ? Yt[((size_t)kb * NTl + yt) * 256 + tid * 16 + yc] : 0.0;
         __syncthreads();
         double ps[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int J = kb + 1 + wv; J < NTl; J += NW) {
-            const double* tp = Yt + ((size_t)kb * NTl + J) * 256;
-            const double xv = xs[16 * J + c];
+        {
+            int q = 0;
+            for (int J = kb + 1 + wv; J < NTl; J += NW, ++q) {
+                const double xv = xs[16 * J + c];
+                if (q < FR_OWN) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ps[r] = fma(tp[64 * r + lane], xv, ps[r]);
+                    for (int u = 0; u < FR_OWN; ++u)
+                        if (u == q) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) ps[r] = fma(tv[u][r], xv, ps[r]);
+                        }
+                } else {
+                    const double* tp = Yt + ((size_t)kb * NTl + J) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ps[r] = fma(tp[64 * r + lane], xv, ps[r]);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -187,12 +238,12 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
         if (tid < 16) {
             double sacc = 0.0;
             for (int q = 0; q < NW; ++q) sacc += part[q * 16 + tid];
-            tsh[tid] = Yt[((size_t)kb * NTl + yt) * 256 + tid * 16 + yc] - sacc;
+            tsh[tid] = yv0 - sacc;
         }
         __syncthreads();
         if (tid < 256) {
             const int row = tid >> 4;
-            double v = RIt[(size_t)kb * 256 + row * 16 + c] * tsh[c];
+            double v = riv * tsh[c];
             v = ft_row16_sum<double>(v);
             if (c == 0) {
                 const int e = 16 * kb + row;
@@ -202,6 +253,9 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
         }
     }
     __syncthreads();
+#ifdef FW_TIMING
+    if (blockIdx.x == 0 && tid == 0) fr_timing[7] += (unsigned long long)wall_clock64() - _tb;
+#endif
     return 0;
 }
 

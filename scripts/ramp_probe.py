@@ -51,3 +51,4 @@ if hasattr(lib, "fmpc_debug_ramp_timing"):
     print("one problem, one Newton step, workgroup 0 (us):")
     for i, nm in enumerate(names):
         print("  %-36s %9.1f" % (nm, out[i] * 0.01))
+    print("  of P4: pass A + potrf %.1f, backward substitution %.1f" % (out[6] * 0.01, out[7] * 0.01))
