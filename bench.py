@@ -97,6 +97,19 @@ def cpu_cores():
 
 
 def main():
+    # Libraries (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.  Everything written to
+    # fd 1 from here on goes to stderr, the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
+    try:
+        _main(real_out)
+    finally:
+        real_out.flush()
+
+
+def _main(real_out):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -212,9 +225,10 @@ def main():
             self.st = torch.zeros(Bn, dtype=torch.int32, device=dev)
             self.it = torch.zeros(Bn, dtype=torch.int32, device=dev)
 
-        def step(self):
+        def step(self, u0_out=None):
             tx0, tx0p, tnu0, zi = self.a
-            self.h.solve_device(tx0, tx0p, None, zi, tnu0, self.nw, K_BAR, z_out=self.z, status=self.st, iters=self.it, u0_out=self.u0)
+            self.h.solve_device(tx0, tx0p, None, zi, tnu0, self.nw, K_BAR, z_out=self.z, status=self.st, iters=self.it,
+                                u0_out=self.u0 if u0_out is None else u0_out)
 
         def check(self):
             assert int((self.st < 0).sum().item()) == 0, "solver reported errors"
@@ -230,12 +244,13 @@ def main():
         gather_state["all"] = [torch.empty((world * B, m), dtype=torch.float64, device=dev) for _ in range(2)]
 
     def head_step():
-        head.step()
-        if dist_on:      # the one collective of the job: all-gather of the first moves (RCCL), two buffers in turn
-            s_ = gather_state["slot"]
+        if not dist_on:
+            head.step()
+        else:            # the one collective of the job: all-gather of the first moves (RCCL), two buffers in turn; the solve
+            s_ = gather_state["slot"]                      # writes its first moves straight into the buffer that is gathered
             if gather_state["pending"][s_] is not None:
                 gather_state["pending"][s_].wait()
-            gather_state["bufs"][s_].copy_(head.u0)
+            head.step(u0_out=gather_state["bufs"][s_])
             if rehearse:
                 parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(parts, gather_state["bufs"][s_].cpu())
@@ -533,7 +548,7 @@ def main():
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baselines(pkg, model, data, args.n_newton))
-        print(json.dumps(out), flush=True)
+        real_out.write(json.dumps(out) + "\n"); real_out.flush()
     h.close()
     if dist_on:
         dist.destroy_process_group()
