@@ -101,6 +101,7 @@ struct fmpc_handle_s {
     // dense form of the cold-start dual solve (fmpc_kernel_inv.hip): nu+ = nuc + J d, built per (handle, k) on first use
     int inv_enabled, inv_valid, inv_jks, inv_max_batch, inv_last; double inv_k;
     double* inv_jimg; double* inv_nuc; double* inv_eimg;
+    double* inv_jst; double* inv_nucst; int inv_fuse;            // per-stage rows of J_x and nuc: the dual solve fused into d_z (w = NULL, no xf, budget 1)
     double* inv_jimg2; int inv_jks2;     // J' = [J_x | -J_w M1 | -J_w M2]: closed-loop steps, w = -M1 B u1 - M2 B u2 (fmpc_loop_step_device)
     double* lp_v; size_t lp_cap; int lp_hint;                    // [B u1 ; B u2] per problem of the running loop step
     std::vector<double> hm_m1, hm_m2;
@@ -300,7 +301,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
+    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -551,6 +552,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                     const char* noinv = getenv("FMPC_NO_INV");
                     const char* mb = getenv("FMPC_INV_MAX_BATCH");
                     h->inv_enabled = !(noinv && noinv[0] == '1');
+                    { const char* nf = getenv("FMPC_FUSE_DZ"); h->inv_fuse = nf && nf[0] == '1'; }    // (measured slower: DESIGN.md §7; off unless asked for)
                     if (mb && mb[0]) h->inv_max_batch = atoi(mb);
                     h->inv_jks = FP_XKS + (T * n + 3) / 4;
                     h->inv_jks2 = 2 * FP_XKS;                       // [x0 ; x0_pre ; 0 0 ; B u1 ; B u2 ; 0 0]
@@ -558,6 +560,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                     if (h->inv_enabled && (hipMalloc((void**)&h->inv_jimg, nrt * (size_t)(16 * ((h->inv_jks + 15) / 16 + 3)) * 64 * sizeof(double)) != hipSuccess ||
                                            hipMalloc((void**)&h->inv_nuc, nrt * 16 * sizeof(double)) != hipSuccess ||
                                            hipMalloc((void**)&h->inv_eimg, 4 * FP_XKS * 64 * sizeof(double)) != hipSuccess ||
+                                           hipMalloc((void**)&h->inv_jst, (size_t)h->nb * 2 * FP_XKS * 64 * sizeof(double)) != hipSuccess ||
+                                           hipMalloc((void**)&h->inv_nucst, (size_t)h->nb * 32 * sizeof(double)) != hipSuccess ||
                                            hipMalloc((void**)&h->inv_jimg2, nrt * (size_t)(16 * ((2 * FP_XKS + 15) / 16 + 3)) * 64 * sizeof(double)) != hipSuccess)) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 }
             }
@@ -582,6 +586,8 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->inv_jimg) (void)hipFree(h->inv_jimg);
     if (h->inv_nuc) (void)hipFree(h->inv_nuc);
     if (h->inv_eimg) (void)hipFree(h->inv_eimg);
+    if (h->inv_jst) (void)hipFree(h->inv_jst);
+    if (h->inv_nucst) (void)hipFree(h->inv_nucst);
     if (h->inv_jimg2) (void)hipFree(h->inv_jimg2);
     if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
@@ -1138,6 +1144,7 @@ static void fmpc_panel_params(fmpc_handle h, double k, FpParams& Q) {
     Q.dzimg = h->pn_pool + h->pn_o_dz; Q.dzimg_len = h->pn_dz_len;
     Q.kbar = k;
     Q.jimg = h->inv_jimg; Q.nuc = h->inv_nuc; Q.jks = h->inv_jks; Q.jksp = 16 * ((h->inv_jks + 15) / 16 + 3); Q.eimg = h->inv_eimg;
+    Q.jst = h->inv_jst; Q.nucst = h->inv_nucst; Q.gate_only = 0;
     Q.gw = nullptr; Q.gwn = h->T * h->n;                          // (set per call)
 }
 
@@ -1201,6 +1208,23 @@ static int fmpc_build_inverse(fmpc_handle h, double k, hipStream_t stream) {
                     img[((size_t)rt * jksp + ks) * 64 + l] = v;
                 }
             }
+    // per stage: the rows of J_x as two 16-row A tiles (rows beyond n: zero) and nuc padded to 32 (d_z with the dual solve fused in)
+    {
+        std::vector<double> jst((size_t)nb * 2 * FP_XKS * 64, 0.0), ncs((size_t)nb * 32, 0.0);
+        for (int st = 0; st < nb; ++st) {
+            for (int r = 0; r < n; ++r) ncs[(size_t)st * 32 + r] = nuc[(size_t)st * n + r];
+            for (int I = 0; I < 2; ++I)
+                for (int ks = 0; ks < FP_XKS; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int rl = 16 * I + (l & 15), kk = 4 * ks + (l >> 4);
+                        if (rl >= n) continue;
+                        const int row = st * n + rl;
+                        jst[(((size_t)st * 2 + I) * FP_XKS + ks) * 64 + l] = img[((size_t)(row >> 4) * jksp + ks) * 64 + ((kk & 3) << 4) + (row & 15)];
+                    }
+        }
+        if (hipMemcpy(h->inv_jst, jst.data(), jst.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->inv_nucst, ncs.data(), ncs.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    }
     // J' = [J_x | d nu+ / d (B u1) | d nu+ / d (B u2)]
     const int jks2 = h->inv_jks2, jksp2 = 16 * ((jks2 + 15) / 16 + 3);
     std::vector<double> img2((size_t)nrt * jksp2 * 64, 0.0);
@@ -1324,6 +1348,9 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
             h->inv_last = dense_form && h->inv_valid;
+            // without w, without the terminal row and with a budget of 1 nobody but d_z reads nu+: d_z computes it itself
+            const bool fuse = h->inv_last && h->inv_fuse && w == nullptr && !h->has_xf && max_iter == 1;
+            Q.gate_only = fuse ? 1 : 0;
             if (h->inv_last) {
                 if (lowrank) { Q.gw = h->lp_v; Q.gwn = 2 * h->n; Q.jimg = h->inv_jimg2; Q.jks = h->inv_jks2; Q.jksp = 16 * ((h->inv_jks2 + 15) / 16 + 3); }
                 else { Q.gw = w; Q.gwn = h->T * h->n; }
@@ -1336,7 +1363,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             const int ppx = (npanels + 7) / 8;                       // panels of the fullest XCD share
             const int dgrid = 8 * ((ppx * h->T + FD_WAVES - 1) / FD_WAVES);
             (void)ntasks;
-            e = fmpc_launch_dz(Q, dgrid, split, (hipStream_t)stream);
+            e = fmpc_launch_dz(Q, dgrid, split, (hipStream_t)stream, fuse ? 1 : 0);
             if (e != hipSuccess) return FMPC_E_HIP;
             // decides the step length of every problem; solves exactly those whose decision is not clear-cut.  Budget 1:
             // one launch.  Budgets > 1: a decide-only launch that also evaluates the next exit test and COMPACTS the

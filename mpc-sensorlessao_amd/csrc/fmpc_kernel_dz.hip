@@ -43,8 +43,13 @@ extern "C" int fmpc_debug_dz_trace(unsigned long long* out, int n) {
 // NEXT: also leave, per task, the partial ||r_d||^2 of the NEW point (z+, nu+) with the barrier terms re-evaluated there,
 // i.e. what the exit test of the following Newton iteration (inf_newton_solver.m:19-22) needs; its x entries and r_p
 // vanish for a full step (the x part of Phi is constant), so only the u entries are summed.  Used for budgets > 1.
-template <bool NEXT>
-__global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
+// FUSED: nu+_j, nu+_{j+1}, nu+_{j+2} are not read from the panel workspace but computed here, from the dense form of the dual
+// solve (fmpc_kernel_inv.hip): nu+_s = nuc_s + J_s [x0 ; x0_pre] with the 27 x 56 rows of J of stage s as two 16-row A
+// tiles -- the result registers of the two products are exactly the B-operand layout the rest of the task works with.
+// Taken without w, without the terminal row and for a Newton budget of 1 (nobody else reads nu+ then): the 13 MB round trip
+// of nu+ through HBM and one launch disappear.
+template <bool NEXT, bool FUSED = false>
+__global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpParams Pv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const FpParams Q = Pv;
     const FdKP P = &Q;
@@ -93,7 +98,51 @@ __global__ void __launch_bounds__(FD_THREADS, 4) fmpc_cold_dz(FpParams Pv) {
     __builtin_amdgcn_s_setprio(3);
     double v0[FP_KS], v1[FP_KS], v2[FP_KS];        // nu+_j, nu+_{j+1}, nu+_{j+2} in B-operand layout (problem = lane % 16)
     double nx[2][4];                                // nu+_T at (problem 4 r + g, row 16 I + lane % 16): last stage with xf only
-    {
+    if (FUSED) {
+        const bool h1 = j + 1 < T, h2 = j + 2 < T && var2;
+        // d = [x0 ; x0_pre ; 0 0] of the panel's problems in B-operand layout: all requests first, the zeros afterwards
+        double dv[FP_XKS];
+        const long pp = (long)panel * FP_NP + c16;
+        const size_t pd = (size_t)(pp < batch ? pp : batch - 1);
+#pragma unroll
+        for (int ks = 0; ks < FP_XKS; ++ks) dv[ks] = *fi_addr(P->x0, P->x0p, nullptr, pd, 4 * ks + g, 0);
+        // the rows of J and nuc of the three stages: two register sets, the next stage requested before the products of the current
+        struct JS { double a[2][FP_XKS]; double nc[2][4]; };
+        auto jload = [&](int st, JS& S) {
+            const double* im = P->jst + (size_t)st * 2 * FP_XKS * 64 + lane;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int ks = 0; ks < FP_XKS; ++ks) S.a[I][ks] = im[(I * FP_XKS + ks) * 64];
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S.nc[I][r] = P->nucst[st * 32 + 16 * I + 4 * r + g];
+        };
+        auto jmul = [&](const JS& S, double v[FP_KS], bool on) {
+            d4 a0 = {S.nc[0][0], S.nc[0][1], S.nc[0][2], S.nc[0][3]}, a1 = {S.nc[1][0], S.nc[1][1], S.nc[1][2], S.nc[1][3]};
+#pragma unroll
+            for (int ks = 0; ks < FP_XKS; ++ks) { a0 = MFMA64(S.a[0][ks], dv[ks], a0); a1 = MFMA64(S.a[1][ks], dv[ks], a1); }
+            // result register r of tile I = row 16 I + 4 r + g = k-step 4 I + r of the B-operand layout (row 27 is a zero row of the image)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = on ? a0[r] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) v[4 + r] = on ? a1[r] : 0.0;
+        };
+        JS s0, s1;
+        jload(j, s0);
+        jload(h1 ? j + 1 : j, s1);
+#pragma unroll
+        for (int ks = 0; ks < FP_XKS; ++ks) dv[ks] = fi_zero(P->x0p != nullptr, false, 4 * ks + g) ? 0.0 : dv[ks];
+        jmul(s0, v0, true);
+        jload(h2 ? j + 2 : j, s0);
+        jmul(s1, v1, h1);
+        jmul(s0, v2, h2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < 2; ++I) nx[I][r] = 0.0;
+    } else {
         // nu+ arrives in panel layout, [stage row][16 problems]: the B-operand loads are 512 contiguous bytes
         const double* pnl = nuws + (size_t)panel * nus * FP_NP;
         const bool h1 = j + 1 < T, h2 = j + 2 < T && var2, xfl = j + 1 == T && has_xf;
@@ -260,12 +309,16 @@ hipError_t fmpc_dz_prepare(int mp) {
     hipError_t e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)fmpc_dz_lds_bytes(mp, 0));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)fmpc_dz_lds_bytes(mp, 0));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)fmpc_cold_dz<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)fmpc_dz_lds_bytes(mp, 1));
 }
 
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream) {
-    if (next) hipLaunchKernelGGL(fmpc_cold_dz<true>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 1), stream, P);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused) {
+    if (fused && !next) hipLaunchKernelGGL((fmpc_cold_dz<false, true>), dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
+    else if (next) hipLaunchKernelGGL(fmpc_cold_dz<true>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 1), stream, P);
     else hipLaunchKernelGGL(fmpc_cold_dz<false>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
     return hipGetLastError();
 }

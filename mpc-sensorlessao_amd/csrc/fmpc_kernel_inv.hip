@@ -30,20 +30,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define FI_CH 7                          // k-steps per register set (two sets in flight)
 
-// d[kk] of problem p, d = [x0 (27) ; x0_pre (27) ; 0 0 ; w (T n)]: ONE load from a selected address; a missing x0_pre / w
-// reads x0 and is zeroed, kk beyond the end reads a finite value (J has a zero column there).  Address and zero flag are
-// separate so that a caller can request all its values before it touches the first (a select right behind each load
-// makes the compiler wait for every load in turn).
-__device__ __forceinline__ const double* fi_addr(const double* x0, const double* x0p, const double* w, size_t p, int kk, int TN) {
-    const double* a = x0 + p * FP_N + (kk < FP_N ? kk : FP_N - 1);
-    if (x0p) { int kb = kk - FP_N; kb = kb < 0 ? 0 : (kb < FP_N ? kb : FP_N - 1); a = kk >= FP_N ? x0p + p * FP_N + kb : a; }
-    if (w) { int wi = kk - 4 * FP_XKS; wi = wi < 0 ? 0 : (wi < TN ? wi : TN - 1); a = kk >= 4 * FP_XKS ? w + p * (size_t)TN + wi : a; }
-    return a;
-}
-__device__ __forceinline__ bool fi_zero(bool has_x0p, bool has_w, int kk) {
-    return (kk >= 2 * FP_N && kk < 4 * FP_XKS) || (!has_x0p && kk >= FP_N && kk < 2 * FP_N) || (!has_w && kk >= 4 * FP_XKS);
-}
-
 __device__ __forceinline__ double fi_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -184,7 +170,7 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
         return;
     }
     const int bid = (int)blockIdx.x - ngate;
-    if (bid >= gemm_blocks) return;
+    if (bid >= gemm_blocks || P->gate_only) return;
     // XCD x = block & 7 works on the row tiles x, x + 8, ...: one row tile at a time, all panel groups
     const int x = bid & 7;
     const int q = (bid >> 3) * IPW + (KSPLIT == 1 ? wv : 0);
@@ -307,7 +293,7 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
         return;
     }
     const int bid = (int)blockIdx.x - ngate;
-    if (bid >= gemm_blocks) return;
+    if (bid >= gemm_blocks || P->gate_only) return;
     const int x = bid & 7, q = bid >> 3;
     const int rg = x + 8 * (q / npg), pg = q % npg;
     if (rg >= nrg) return;
@@ -442,7 +428,9 @@ int fmpc_inv_variant(int npanels, int has_w, int jks) {
 hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream) {
     const int nrow = P.nb * FP_N, nrt = (nrow + 15) / 16;
     const int variant = fmpc_inv_variant(P.npanels, P.gw != nullptr, P.jks);
-    auto grid_for = [&](int RT, int PB) { return 8 * (((nrt + RT - 1) / RT + 7) / 8) * ((P.npanels + PB - 1) / PB) + ((P.npanels + 7) & ~7); };
+    auto grid_for = [&](int RT, int PB) {
+        return (P.gate_only ? 0 : 8 * (((nrt + RT - 1) / RT + 7) / 8) * ((P.npanels + PB - 1) / PB)) + ((P.npanels + 7) & ~7);
+    };
     switch (variant) {
     case 0: {
         static int shape = -2;

@@ -96,8 +96,24 @@ struct FpParams {
     const double* jimg; const double* nuc; int jks, jksp;        // dense form (fmpc_cold_inv): image of J (jks k-steps, rows padded with zeros to jksp), nu+ at d = 0
     const double* gw; int gwn;                                   // the data behind [x0 ; x0_pre ; 0 0] in d and its row length: w (T n), or
                                                                  // [B u1 ; B u2] (2 n) with the image J' = [J_x | -J_w M1 | -J_w M2] (fmpc_loop_step_device)
+    const double* jst; const double* nucst;                      // per stage: image of the rows of J_x (2 row tiles x FP_XKS k-steps) and nuc, padded to 32 (fmpc_cold_dz<.., true>)
+    int gate_only;                                               // fmpc_cold_inv_rg: only the gate tasks (the dual solve itself is fused into d_z)
     const double* eimg;                                          // image of E = [A1 A2 ; A2 0] (4 row tiles x FP_XKS k-steps): b_0, b_1
 };
+
+// d[kk] of problem p, d = [x0 (27) ; x0_pre (27) ; 0 0 ; w (T n)]: ONE load from a selected address; a missing x0_pre / w
+// reads x0 and is zeroed, kk beyond the end reads a finite value (J has a zero column there).  Address and zero flag are
+// separate so that a caller can request all its values before it touches the first (a select right behind each load
+// makes the compiler wait for every load in turn).
+__device__ __forceinline__ const double* fi_addr(const double* x0, const double* x0p, const double* w, size_t p, int kk, int TN) {
+    const double* a = x0 + p * FP_N + (kk < FP_N ? kk : FP_N - 1);
+    if (x0p) { int kb = kk - FP_N; kb = kb < 0 ? 0 : (kb < FP_N ? kb : FP_N - 1); a = kk >= FP_N ? x0p + p * FP_N + kb : a; }
+    if (w) { int wi = kk - 4 * FP_XKS; wi = wi < 0 ? 0 : (wi < TN ? wi : TN - 1); a = kk >= 4 * FP_XKS ? w + p * (size_t)TN + wi : a; }
+    return a;
+}
+__device__ __forceinline__ bool fi_zero(bool has_x0p, bool has_w, int kk) {
+    return (kk >= 2 * FP_N && kk < 4 * FP_XKS) || (!has_x0p && kk >= FP_N && kk < 2 * FP_N) || (!has_w && kk >= 4 * FP_XKS);
+}
 
 size_t fmpc_panel_lds_bytes(int nb, int mp);
 size_t fmpc_panel_lds_used(int nb, int mp, int nsteps);
@@ -107,4 +123,4 @@ int fmpc_inv_variant(int npanels, int has_w, int jks);
 hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream);
 size_t fmpc_dz_lds_bytes(int mp, int next);
 hipError_t fmpc_dz_prepare(int mp);
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused = 0);

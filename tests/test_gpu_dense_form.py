@@ -104,3 +104,33 @@ def test_dense_form_with_a_newton_budget(pkg, gpu):
     for p in range(48):
         assert rel_err(z[p], zo[p]) <= TOL_Z and rel_err(info["nu"][p], nuo[p]) <= TOL_NU
     h.close()
+
+
+@pytest.mark.parametrize("T,batch,use_nu,var_order,m", [(30, 2000, True, 2, 144), (30, 37, False, 2, 144), (10, 40, True, 1, 144),
+                                                       (2, 17, True, 2, 144), (3, 20, True, 2, 97), (1, 5, True, 2, 144)])
+def test_dual_solve_fused_into_dz(pkg, gpu, T, batch, use_nu, var_order, m):
+    """Experimental variant (FMPC_FUSE_DZ=1 at create time; measured slower): without w, without the terminal row
+    and with a Newton budget of 1, d_z computes nu+ itself from [x0; x0_pre] (fmpc_cold_dz<.., true>: no nu+ round trip through
+    HBM).  Against the default dense form (1e-11) and the oracle; nu_out comes from d_z in both."""
+    import os
+    md, data = _case(pkg, T, batch, False, False, use_nu, seed=41, var_order=var_order, m=m)
+    hu = handle_from_model(pkg, md)
+    os.environ["FMPC_FUSE_DZ"] = "1"
+    try:
+        hf = handle_from_model(pkg, md)
+    finally:
+        del os.environ["FMPC_FUSE_DZ"]
+    zf, inf_ = hf.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
+    zu, inu = hu.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
+    assert hf.last_dual_form() == 1 and hu.last_dual_form() == 1
+    assert np.array_equal(inf_["iters"], inu["iters"]) and np.array_equal(inf_["status"], inu["status"])
+    assert np.array_equal(inf_["step"], inu["step"])
+    for p in range(batch):
+        assert rel_err(zf[p], zu[p]) <= 1e-11 and rel_err(inf_["nu"][p], inu["nu"][p]) <= 1e-11
+    nchk = min(batch, 32)
+    sub = {k: (v[:nchk] if v is not None else None) for k, v in data.items()}
+    zo, nuo, ito, sto, steps = oracle_batch(md, sub, 1, 1e-2)
+    assert np.array_equal(inf_["iters"][:nchk], ito) and np.array_equal(inf_["status"][:nchk], sto)
+    for p in range(nchk):
+        assert rel_err(zf[p], zo[p]) <= TOL_Z and rel_err(inf_["nu"][p], nuo[p]) <= TOL_NU
+    hf.close(); hu.close()
