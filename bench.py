@@ -238,27 +238,42 @@ def _main(real_out):
     depth = max(1, args.in_flight)
     h = make_handle()
     head = Replay(h, x0, x0p, nu0, args.n_newton)
-    gather_state = {"pending": [None, None], "bufs": None, "slot": 0}
+    # Multi-GPU: the first moves of every step are gathered (the one collective of the job, RCCL all-gather).  A collective
+    # costs ~30 us of host time to submit, more than half a step: the first moves of GROUP consecutive steps share one buffer
+    # and one all-gather ("fewer, larger collectives"), two buffers in turn so that a gather in flight never holds up a solve;
+    # the last, partial group is gathered when the timed region ends (head_after runs inside it).
+    GROUP = 8
+    gather_state = {"pending": [None, None], "bufs": None, "slot": 0, "fill": 0}
     if dist_on:
-        gather_state["bufs"] = [torch.empty((B, m), dtype=torch.float64, device=dev) for _ in range(2)]
-        gather_state["all"] = [torch.empty((world * B, m), dtype=torch.float64, device=dev) for _ in range(2)]
+        gather_state["bufs"] = [torch.empty((GROUP, B, m), dtype=torch.float64, device=dev) for _ in range(2)]
+        gather_state["all"] = [torch.empty((world, GROUP, B, m), dtype=torch.float64, device=dev) for _ in range(2)]
+
+    def gather_flush():
+        s_ = gather_state["slot"]
+        if gather_state["fill"] == 0:
+            return
+        if rehearse:
+            parts = [torch.empty((GROUP, B, m), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, gather_state["bufs"][s_].cpu())
+        else:
+            gather_state["pending"][s_] = dist.all_gather_into_tensor(gather_state["all"][s_], gather_state["bufs"][s_], async_op=True)
+        gather_state["slot"] = 1 - s_
+        gather_state["fill"] = 0
 
     def head_step():
         if not dist_on:
             head.step()
-        else:            # the one collective of the job: all-gather of the first moves (RCCL), two buffers in turn; the solve
-            s_ = gather_state["slot"]                      # writes its first moves straight into the buffer that is gathered
-            if gather_state["pending"][s_] is not None:
-                gather_state["pending"][s_].wait()
-            head.step(u0_out=gather_state["bufs"][s_])
-            if rehearse:
-                parts = [torch.empty((B, m), dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, gather_state["bufs"][s_].cpu())
-            else:
-                gather_state["pending"][s_] = dist.all_gather_into_tensor(gather_state["all"][s_], gather_state["bufs"][s_], async_op=True)
-            gather_state["slot"] = 1 - s_
+        else:
+            s_, f_ = gather_state["slot"], gather_state["fill"]
+            if f_ == 0 and gather_state["pending"][s_] is not None:        # the buffer's previous gather must have read it
+                gather_state["pending"][s_].wait(); gather_state["pending"][s_] = None
+            head.step(u0_out=gather_state["bufs"][s_][f_])                  # the solve writes its first moves straight into the buffer
+            gather_state["fill"] = f_ + 1
+            if f_ + 1 == GROUP:
+                gather_flush()
 
     def head_after():
+        gather_flush()
         for s_ in (0, 1):
             if gather_state["pending"][s_] is not None:
                 gather_state["pending"][s_].wait(); gather_state["pending"][s_] = None
@@ -539,7 +554,7 @@ def _main(real_out):
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)" if shared else "per problem",
                        "cold_start_dual_solve": ("dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
                                                  if shared and dense else "two sweeps through the shared block factor (panels of 16 problems)") if shared else None,
-                       "gather": "all-gather of the first moves u0 (RCCL) every step, two buffers in turn" if dist_on else "none (1 GPU)",
+                       "gather": "all-gather of the first moves u0 (RCCL), one collective per 8 steps (and at the end of the timed region), two buffers in turn" if dist_on else "none (1 GPU)",
                        "steps_requested": args.steps},
             "roofline": roof_pp if roof_pp is not None else roof_cold,
             "roofline_cold_start": roof_cold,
