@@ -271,10 +271,14 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
 // and the k groups on its four SIMDs; many panels -> more row tiles per workgroup share the staged panel.
 template <int PB, int RT, int KS, bool HAS_W>
 __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
-    constexpr int NP = PB * FP_NP, LD = NP + 1, PPW = NP / RT;    // problems per workgroup, LDS row, problems a wavefront loads
+    constexpr int NP = PB * FP_NP, PPW = NP / RT;                 // problems per workgroup, problems a wavefront loads
+    // LDS image of a chunk of d: per k-step a row of PB x 64 doubles in B-OPERAND ORDER (element (column 4 u + g, problem 16 j + c)
+    // at u RS + 64 j + 16 g + c): a wavefront's operand read is 64 consecutive doubles, free of bank conflicts (the matrix
+    // pipes wait for nothing but these reads); the row stride RS = 64 PB + 2 keeps the transposing writes at two lanes per bank
+    constexpr int RS = 64 * PB + 2;
     constexpr int KC = 16;                                         // k-steps per chunk = 64 columns of d, one per lane
     constexpr int NBUF = HAS_W ? 2 : 1;
-    constexpr int BUFD = 64 * LD;
+    constexpr int BUFD = 16 * RS;
     constexpr int LDSD = KS * NBUF * BUFD > 1048 ? KS * NBUF * BUFD : 1048;
     static_assert(KS == 1 || (KS - 1) * RT * PB * 256 <= KS * NBUF * BUFD, "partial tiles reuse the staging buffers");
     __shared__ double lds[LDSD];
@@ -331,13 +335,13 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     auto products = [&](const double* B, const double a[KC], int nks) {
         double bc[PB], bn[PB];
 #pragma unroll
-        for (int j = 0; j < PB; ++j) bc[j] = B[g * LD + j * FP_NP + c16];
+        for (int j = 0; j < PB; ++j) bc[j] = B[64 * j + lane];
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
             if (u < nks) {                                           // (compile-time after unrolling)
                 if (u + 1 < nks) {
 #pragma unroll
-                    for (int j = 0; j < PB; ++j) bn[j] = B[(4 * (u + 1) + g) * LD + j * FP_NP + c16];
+                    for (int j = 0; j < PB; ++j) bn[j] = B[(u + 1) * RS + 64 * j + lane];
                 }
 #pragma unroll
                 for (int j = 0; j < PB; ++j) acc[j] = MFMA64(a[u], bc[j], acc[j]);
@@ -348,7 +352,10 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     };
     auto stage = [&](double* B, const double v[PPW]) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) B[lane * LD + wv * PPW + i] = v[i];
+        for (int i = 0; i < PPW; ++i) {
+            const int pl = wv * PPW + i;                                // problem within the workgroup; lane = column of the chunk
+            B[(lane >> 2) * RS + 64 * (pl >> 4) + 16 * (lane & 3) + (pl & 15)] = v[i];
+        }
     };
     double bv[PPW], a0[KC];
 #pragma unroll
