@@ -114,7 +114,8 @@ struct fmpc_handle_s {
     int prec;                            // FMPC_PREC_F64 / FMPC_PREC_F32_MIXED of the per-problem-factor path
     int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
     struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // bm: padded fp64 images   // [0] fp64, [1] fp32
-    double* tl_ws; size_t tl_ws_doubles;
+    double* tl_ws; size_t tl_ws_doubles; int tl_prepared;         // (bit NW: that wavefront count of the fp64 instance is prepared)
+    int small_tiled;                      // per-problem-factor solves of few problems go to the tiled kernel (FMPC_NO_SMALL_TILED=1: off)
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
     int denseQ;                          // Q or Qf not diagonal: tiled kernel only
@@ -297,7 +298,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->generic_ok = generic_ok ? 1 : 0;
     h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
-    memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0;
+    memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
+    { const char* ns = getenv("FMPC_NO_SMALL_TILED"); h->small_tiled = (ns && ns[0] == '1') ? 0 : 1; }
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
@@ -1063,17 +1065,29 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
 }
 
 // launches the tiled kernel; caller holds h->mu
+// nw_override: wavefronts per problem other than the handle's default (2 or 4, fp64 without dense R): few problems per CU
+// are solved faster by more wavefronts each (the latency of a problem is what counts then)
 static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, const double* x0_pre, const double* w,
                             const double* z_init, const double* nu0, int n_newton, double k, double* z_out,
-                            double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+                            double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream,
+                            int nw_override = 0) {
     fmpc_handle_s::Tiled& X = h->tl[t];
     if (!X.ready) {
         const int rc = t ? fmpc_tiled_build<float>(h, 1) : fmpc_tiled_build<double>(h, 0);
         if (rc != FMPC_OK) return rc;
     }
-    int wgs = (int)(FMPC_LDS_LIMIT / X.lds);
+    int NWu = X.NW; size_t ldsu = X.lds;
+    if (nw_override && nw_override != X.NW && !t && !h->denseR) {
+        NWu = nw_override;
+        ldsu = fmpc_tiled_lds_bytes(X.NB, X.V.mb, NWu, t, h->nb, 0);
+        if (!(h->tl_prepared & (1 << NWu))) {
+            if (ldsu > FMPC_LDS_LIMIT || fmpc_tiled_prepare(h->n, X.NB, NWu, t, ldsu, 0) != hipSuccess) { NWu = X.NW; ldsu = X.lds; }
+            else h->tl_prepared |= 1 << NWu;
+        }
+    }
+    int wgs = (int)(FMPC_LDS_LIMIT / ldsu);
     if (wgs < 1) wgs = 1;
-    if (wgs * X.NW > 8) wgs = 8 / X.NW > 0 ? 8 / X.NW : 1;             // two waves per SIMD (the kernel's launch bound)
+    if (wgs * NWu > 8) wgs = 8 / NWu > 0 ? 8 / NWu : 1;                // two waves per SIMD (the kernel's launch bound)
     const int cap = h->num_cu * wgs;
     const int grid = batch < cap ? batch : cap;
     const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8, h->denseR);
@@ -1090,7 +1104,7 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     P.zout = z_out; P.nuout = nu_out; P.status = status; P.iters = iters; P.step = step; P.step_ld = fmpc_step_ld(n_newton);
     P.ws = h->tl_ws; P.ws_stride = L.total; P.u0out = u0_out;
     h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
-    return fmpc_launch_tiled(P, X.NB, X.NW, t, grid, X.lds, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+    return fmpc_launch_tiled(P, X.NB, NWu, t, grid, ldsu, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
 extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
@@ -1394,6 +1408,14 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 return FMPC_E_HIP;
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+        }
+        if (mode == 0 && h->small_tiled && batch <= 1024) {
+            // Every problem factors its own Schur complement and there are at most 4 problems per CU: the tiled kernel's
+            // 2 (4) wavefronts per problem finish a problem in 0.5 (0.4) ms where the one-wavefront kernel needs 1.0 ms;
+            // beyond 1024 problems the one-wavefront kernel's 8 problems per CU win (measured: scripts/latency_190.py)
+            const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                              u0_out, (hipStream_t)stream, batch <= 512 ? 4 : 2);
+            if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,

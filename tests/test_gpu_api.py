@@ -275,7 +275,7 @@ def test_shared_cold_start_factor_equals_per_problem_factor(pkg, gpu):
     hs.close(); hp.close()
 
 
-@pytest.mark.parametrize("case", ["panel", "panel_budget3", "handed_over", "warm_start", "no_shared", "generic_n8"])
+@pytest.mark.parametrize("case", ["panel", "panel_budget3", "handed_over", "warm_start", "warm_start_wave", "no_shared", "generic_n8"])
 def test_solve_with_first_move_output(pkg, gpu, case):
     """fmpc_solve_u0_device: u0_out == z[:, :m] on every device path (the fused write of the n = 27 kernels, the
     unpack launch elsewhere), and z itself is what fmpc_solve_device gives."""
@@ -291,15 +291,17 @@ def test_solve_with_first_move_output(pkg, gpu, case):
         data = pkg.synthetic.make_replay_batch(md, r=4, steps=40)
     if case == "no_shared":
         os.environ["FMPC_NO_SHARED"] = "1"
+    if case in ("no_shared", "warm_start_wave"):
+        os.environ["FMPC_NO_SMALL_TILED"] = "1"          # (few problems that factor their own Y go to the tiled kernel otherwise)
     try:
         h = handle_from_model(pkg, md)
     finally:
-        os.environ.pop("FMPC_NO_SHARED", None)
+        os.environ.pop("FMPC_NO_SHARED", None); os.environ.pop("FMPC_NO_SMALL_TILED", None)
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     x0, x0p, w, nu0 = t(data["x0"]), t(data["x0_pre"]), t(data.get("w")), t(data["nu0"])
     nw = 3 if case == "panel_budget3" else 1
     z_init = None
-    if case == "warm_start":
+    if case in ("warm_start", "warm_start_wave"):
         z_init = h.solve_device(x0, x0p, w, None, nu0, 1, 1e-2)[0].clone()
     z_ref, st_ref, it_ref = h.solve_device(x0, x0p, w, z_init, nu0, nw, 1e-2)
     z_ref, st_ref, it_ref = z_ref.clone(), st_ref.clone(), it_ref.clone()
@@ -308,7 +310,8 @@ def test_solve_with_first_move_output(pkg, gpu, case):
     torch.cuda.synchronize()
     path, handed = h.last_dispatch()
     want = {"panel": pkg.FMPC_PATH_PANEL, "panel_budget3": pkg.FMPC_PATH_PANEL, "handed_over": pkg.FMPC_PATH_PANEL,
-            "warm_start": pkg.FMPC_PATH_WAVE, "no_shared": pkg.FMPC_PATH_WAVE, "generic_n8": pkg.FMPC_PATH_GENERIC}[case]
+            "warm_start": pkg._lib.FMPC_PATH_TILED, "warm_start_wave": pkg.FMPC_PATH_WAVE, "no_shared": pkg.FMPC_PATH_WAVE,
+            "generic_n8": pkg.FMPC_PATH_GENERIC}[case]
     assert path == want and (handed > 0) == (case == "handed_over")
     assert torch.equal(z, z_ref) and torch.equal(st, st_ref) and torch.equal(it, it_ref)
     assert torch.equal(u0, z[:, :m])

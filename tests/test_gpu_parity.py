@@ -109,3 +109,44 @@ def test_unpack(pkg, gpu):
     assert np.array_equal(X, Z[:, :, 5:].reshape(5, -1))
     assert np.array_equal(u0, Z[:, 0, :5])
     h.close()
+
+
+@pytest.mark.parametrize("nw", [1, 4])
+def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw):
+    """From an explicit start every problem factors its own Schur complement: up to 1024 problems the tiled kernel (2 or 4
+    wavefronts per problem), beyond that the one-wavefront kernel (8 problems per CU); FMPC_NO_SMALL_TILED=1 keeps the
+    one-wavefront kernel.  All three against the oracle, and against each other to 1e-11."""
+    import os
+    model = pkg.synthetic.make_model(27, 144, 10)
+    model["u_min"] = -0.1 * np.ones(144); model["u_max"] = 0.1 * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(model, r=5, steps=24)
+    rng = np.random.default_rng(2)
+    z0 = np.tile(np.concatenate([np.zeros(144), np.zeros(27)]), 10)[None, :] + np.zeros((24, 1))
+    z0 = z0.reshape(24, 10, 171); z0[:, :, :144] = rng.uniform(-0.06, 0.06, (24, 10, 144)); z0 = z0.reshape(24, -1)
+    h = handle_from_model(pkg, model)
+    zt, it_ = h.solve(data["x0"], data["x0_pre"], None, z_init=z0, nu0=data["nu0"], n_newton=nw, k=1e-2, return_info=True)
+    assert h.last_dispatch()[0] == pkg._lib.FMPC_PATH_TILED
+    h.close()
+    os.environ["FMPC_NO_SMALL_TILED"] = "1"
+    try:
+        h = handle_from_model(pkg, model)
+    finally:
+        del os.environ["FMPC_NO_SMALL_TILED"]
+    zw, iw = h.solve(data["x0"], data["x0_pre"], None, z_init=z0, nu0=data["nu0"], n_newton=nw, k=1e-2, return_info=True)
+    assert h.last_dispatch()[0] == pkg.FMPC_PATH_WAVE
+    # 1100 problems (the 24 repeated): the one-wavefront kernel without any switch
+    rep = lambda a: np.ascontiguousarray(np.tile(a, (46, 1))[:1100])
+    zb, ib = h.solve(rep(data["x0"]), rep(data["x0_pre"]), None, z_init=rep(z0), nu0=rep(data["nu0"]), n_newton=nw, k=1e-2, return_info=True)
+    h.close()
+    h = handle_from_model(pkg, model)
+    zc, ic = h.solve(rep(data["x0"]), rep(data["x0_pre"]), None, z_init=rep(z0), nu0=rep(data["nu0"]), n_newton=nw, k=1e-2, return_info=True)
+    assert h.last_dispatch()[0] == pkg.FMPC_PATH_WAVE
+    h.close()
+    assert np.array_equal(zc, zb) and np.array_equal(zb[:24], zw)
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, 1e-2, z0)
+    for z_, i_ in ((zt, it_), (zw, iw)):
+        assert np.array_equal(i_["status"], sto) and np.array_equal(i_["iters"], ito)
+        for p in range(24):
+            assert rel_err(z_[p], zo[p]) <= TOL and rel_err(i_["nu"][p], nuo[p]) <= 1e-7
+            assert np.array_equal(i_["step"][p][:ito[p]], np.array(steps[p]))
+    assert max(rel_err(zt[p], zw[p]) for p in range(24)) <= 1e-11
