@@ -1070,7 +1070,8 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
 static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, const double* x0_pre, const double* w,
                             const double* z_init, const double* nu0, int n_newton, double k, double* z_out,
                             double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream,
-                            int nw_override = 0) {
+                            int nw_override = 0, const int* list = nullptr, const int* nlist = nullptr, const double* nuws = nullptr,
+                            int grid_hint = 0) {
     fmpc_handle_s::Tiled& X = h->tl[t];
     if (!X.ready) {
         const int rc = t ? fmpc_tiled_build<float>(h, 1) : fmpc_tiled_build<double>(h, 0);
@@ -1089,7 +1090,8 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     if (wgs < 1) wgs = 1;
     if (wgs * NWu > 8) wgs = 8 / NWu > 0 ? 8 / NWu : 1;                // two waves per SIMD (the kernel's launch bound)
     const int cap = h->num_cu * wgs;
-    const int grid = batch < cap ? batch : cap;
+    int grid = batch < cap ? batch : cap;
+    if (grid_hint > 0 && grid_hint < grid) grid = grid_hint;           // (a list: as many workgroups as it is expected to be long)
     const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8, h->denseR);
     const size_t need = L.total * (size_t)cap;
     if (need > h->tl_ws_doubles) {
@@ -1103,7 +1105,8 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     P.max_iter = n_newton > 0 ? n_newton : 1000; P.kbar = k;
     P.zout = z_out; P.nuout = nu_out; P.status = status; P.iters = iters; P.step = step; P.step_ld = fmpc_step_ld(n_newton);
     P.ws = h->tl_ws; P.ws_stride = L.total; P.u0out = u0_out;
-    h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
+    P.list = list; P.nlist = nlist; P.nuws = nuws;
+    if (!list) h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
     return fmpc_launch_tiled(P, X.NB, NWu, t, grid, ldsu, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
@@ -1397,6 +1400,16 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                         if (want < 8) want = 8;
                         if (want < g2) g2 = want;
                     }
+                }
+                if (ph == 2 && h->small_tiled) {
+                    // the continuation is a handful of problems per CU at most: the tiled kernel (4 wavefronts per problem)
+                    // finishes one in 0.45 ms where the one-wavefront kernel needs 1.0 ms (scripts/latency_190.py)
+                    const int last = ((volatile int*)h->pn_cnt_host)[1];
+                    const int hint = last >= 0 ? last + last / 2 + 16 : 0;
+                    const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters,
+                                                      step, u0_out, (hipStream_t)stream, 4, h->pn_list, h->pn_cnt + 1, h->pn_nuws, hint);
+                    if (rc_t == FMPC_OK) continue;
+                    if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
                 }
                 e = fmpc_launch_wave(h->dev, h->wave, batch, g2, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                      z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,

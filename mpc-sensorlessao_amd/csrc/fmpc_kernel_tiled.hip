@@ -325,20 +325,27 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
         else { sI[sl] = -1; sJ[sl] = -1; }
     }
 
-    for (int p = blockIdx.x; p < P.batch; p += gridDim.x) {
+    const int nitems = P.list ? *P.nlist : P.batch;
+    for (int item_p = blockIdx.x; item_p < nitems; item_p += gridDim.x) {
+        int p = item_p;
+        bool cont = false;                                           // continue behind the panel path's first step
+        if (P.list) { const int e = P.list[item_p]; p = e & (FT_LIST_HANDED - 1); cont = !(e & FT_LIST_HANDED); }
         double* zp = P.zout + (size_t)p * Nz;
         const double* x0v = P.x0 + (size_t)p * n;
         const double* x0pv = P.x0p ? P.x0p + (size_t)p * n : nullptr;
         __syncthreads();
         FT_T0();
         // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
+        if (!cont) {
 #pragma unroll 8
-        for (int idx = tid; idx < Nz; idx += NT) {
-            const int e = idx % s;
-            zp[idx] = P.zinit ? P.zinit[(size_t)p * Nz + idx] : (e < m ? M.umid[e] : M.xmid[e - m]);
+            for (int idx = tid; idx < Nz; idx += NT) {
+                const int e = idx % s;
+                zp[idx] = P.zinit ? P.zinit[(size_t)p * Nz + idx] : (e < m ? M.umid[e] : M.xmid[e - m]);
+            }
         }
         for (int idx = tid; idx < nbn; idx += NT) {
-            nu[idx] = P.nu0 ? P.nu0[(size_t)p * nbn + idx] : 0.0;
+            // (continuation: nu+ of the first step sits in the panel workspace, [panel][row][16 problems])
+            nu[idx] = cont ? P.nuws[((size_t)(p >> 4) * nbn + idx) * 16 + (p & 15)] : (P.nu0 ? P.nu0[(size_t)p * nbn + idx] : 0.0);
             const int i = idx / n, r = idx - i * n;
             double v = (i < T && P.w) ? P.w[(size_t)p * T * n + idx] : 0.0;
             if (i == 0) {
@@ -356,12 +363,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             b[idx] = v;
         }
         if (P.step)
-            for (int idx = tid; idx < P.step_ld; idx += NT) P.step[(size_t)p * P.step_ld + idx] = -1.0;
+            for (int idx = tid; idx < P.step_ld; idx += NT) P.step[(size_t)p * P.step_ld + idx] = (cont && idx == 0) ? 1.0 : -1.0;
         __syncthreads();
 
-        int st = FMPC_OK, nsteps = 0;
+        int st = FMPC_OK, nsteps = cont ? 1 : 0;
         FT_TICK(0);
-        for (int it = 0; it < P.max_iter; ++it) {
+        for (int it = cont ? 1 : 0; it < P.max_iter; ++it) {
             // ================= P1: residuals.  Every product is a GEMM with the horizon stages as one dimension
             // (out[stage][entry] = sum_k X[k][stage] Z[k][entry]) on the fp64 matrix cores; Z (B, A1, A2 and transposes)
             // is read from L2 with 128-byte rows, the epilogues read and write along the entries of a stage.

@@ -110,7 +110,12 @@ struct FtParams {
     double* zout; double* nuout; int* status; int* iters; double* step; int step_ld;
     double* ws; size_t ws_stride;
     double* u0out;          // nullable: first move of every problem (fmpc_solve_u0_device)
+    // Continuation of a Newton budget > 1 after the cold-start step of the panel path (fmpc_api.hip): the problems to work on come
+    // from the compacted list the decision launch wrote (entry = problem | FT_LIST_HANDED: redo from the cold start; else z+ is in
+    // zout and nu+ in the panel workspace, the first step is done).  list == NULL: all problems 0 .. batch-1 from the start.
+    const int* list; const int* nlist; const double* nuws;
 };
+#define FT_LIST_HANDED (1 << 30)       // (= FW_LIST_HANDED of fmpc_kernel_wave.hip)
 
 // supported (type, NB) pairs
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR = 0);
