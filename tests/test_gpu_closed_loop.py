@@ -139,3 +139,23 @@ def test_loop_step_equals_inputs_plus_solve(pkg, gpu, R, T):
     assert rel_err(la.z.cpu().numpy(), lb.z.cpu().numpy()) <= 1e-10
     assert rel_err(la.w.cpu().numpy(), lb.w.cpu().numpy()) <= 1e-10
     h1.close(); h2.close()
+
+
+def test_loop_step_with_a_newton_budget_and_no_nu0(pkg, gpu):
+    """fmpc_loop_step_device with n_newton = 3 (dense-form first step, continuation on the tiled kernel) and nu0 = NULL,
+    against the oracle loop."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10)
+    md["u_min"] = -0.08 * np.ones(144); md["u_max"] = 0.08 * np.ones(144)
+    R, steps = 4, 5
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    h = handle_from_model(pkg, md)
+    loop = pkg.ClosedLoop(h, R, n_newton=3, k=1e-2)
+    U0, X0 = loop.run(torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    assert h.last_dual_form() == 1 and int(loop.status.abs().sum()) == 0
+    U0, X0 = U0.cpu().numpy(), X0.cpu().numpy()
+    for r in range(R):
+        ref = closed_loop(md, a[:, r], 3, 1e-2)
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    h.close()

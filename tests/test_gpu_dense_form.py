@@ -134,3 +134,54 @@ def test_dual_solve_fused_into_dz(pkg, gpu, T, batch, use_nu, var_order, m):
     for p in range(nchk):
         assert rel_err(zf[p], zo[p]) <= TOL_Z and rel_err(inf_["nu"][p], nuo[p]) <= TOL_NU
     hf.close(); hu.close()
+
+
+@pytest.mark.parametrize("batch", [15, 17, 31, 33, 63, 65, 81, 257])
+def test_dense_form_at_panel_and_shape_boundaries(pkg, gpu, batch):
+    """Batch sizes either side of a panel (16 problems) and of the launch shapes of the product (4 / 16 / 64 panels), with w:
+    every problem against the sweep form of the same handle (1e-11) and a sample against the oracle."""
+    md, data = _case(pkg, 30, batch, False, True, True, seed=batch)
+    h = handle_from_model(pkg, md)
+    zd, idn = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
+    assert h.last_dual_form() == 1
+    h.set_dense_form(False)
+    zs, isw = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
+    assert np.array_equal(idn["iters"], isw["iters"]) and np.array_equal(idn["step"], isw["step"])
+    assert max(rel_err(zd[p], zs[p]) for p in range(batch)) <= 1e-11
+    pick = sorted(set([0, batch // 2, batch - 1]))
+    sub = {k: (v[pick] if v is not None else None) for k, v in data.items()}
+    zo, nuo, ito, sto, _ = oracle_batch(md, sub, 1, 1e-2)
+    for q, p in enumerate(pick):
+        assert rel_err(zd[p], zo[q]) <= TOL_Z and rel_err(idn["nu"][p], nuo[q]) <= TOL_NU
+    h.close()
+
+
+def test_budget_continuation_on_the_tiled_kernel_with_handed_over_problems(pkg, gpu):
+    """A tight box: the step-length decision hands many problems back, the others continue from the dense-form step; both
+    kinds go through the compacted list to the tiled kernel (FtParams::list).  Against the oracle, and against the
+    one-wavefront continuation (FMPC_NO_SMALL_TILED=1) to 1e-10."""
+    import os
+    md = pkg.synthetic.make_model(27, 144, 10)
+    md["u_min"] = -0.05 * np.ones(144); md["u_max"] = 0.05 * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(md, r=8, steps=53)
+    data["w"] = 0.01 * np.random.default_rng(8).standard_normal((53, 270))
+    h = handle_from_model(pkg, md)
+    z, info = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=6, k=1e-2, return_info=True)
+    path, handed = h.last_dispatch()
+    assert path == pkg.FMPC_PATH_PANEL and handed > 0 and h.last_dual_form() == 1
+    h.close()
+    os.environ["FMPC_NO_SMALL_TILED"] = "1"
+    try:
+        hw = handle_from_model(pkg, md)
+    finally:
+        del os.environ["FMPC_NO_SMALL_TILED"]
+    zw, iw = hw.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=6, k=1e-2, return_info=True)
+    hw.close()
+    zo, nuo, ito, sto, steps = oracle_batch(md, data, 6, 1e-2)
+    assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
+    assert np.array_equal(iw["iters"], ito) and np.array_equal(iw["status"], sto)
+    assert info["iters"].max() >= 3
+    for p in range(53):
+        assert rel_err(z[p], zo[p]) <= TOL_Z and rel_err(info["nu"][p], nuo[p]) <= TOL_NU
+        assert rel_err(z[p], zw[p]) <= 1e-10
+        assert np.array_equal(canon_steps(info["step"][p][:ito[p]]), canon_steps(steps[p]))
