@@ -298,9 +298,12 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     }
     const int bid = (int)blockIdx.x - ngate;
     if (bid >= gemm_blocks || P->gate_only) return;
+    // With w the workgroups of an XCD stay on a few row groups (their rows of J, 111 KB per tile, stay in that XCD's L2) and
+    // sweep the panels; without w a row tile needs 7 KB of J and the only concern is an even spread: 13 row groups over 8
+    // XCDs the first way left three XCDs half empty and the others with a second round of workgroups (14.7 -> 9 us).
     const int x = bid & 7, q = bid >> 3;
-    const int rg = x + 8 * (q / npg), pg = q % npg;
-    if (rg >= nrg) return;
+    const int rg = HAS_W ? x + 8 * (q / npg) : bid % nrg, pg = HAS_W ? q % npg : bid / nrg;
+    if (rg >= nrg || pg >= npg) return;
     const int rtq = RT * rg + wv;
     const bool live = rtq < nrt;
     const int rt = live ? rtq : nrt - 1;
