@@ -7,8 +7,9 @@
 //         = nuc + J d ,       d = [x0 ; x0_pre ; 0 0 ; w]          J = d nu+ / d d   (nb n  x  56 + T n)
 // fmpc_cold_panel evaluates this map through the block factor of Y: two sweeps over the horizon, a chain of ~31 dependent
 // steps on one CU per 16 problems, 41 us however few problems there are.  This kernel evaluates it as the product J d on
-// the fp64 matrix cores: about three times the flops and no dependency at all, so 16 problems take ~2 us, 512 problems
-// fill the chip, and without w (replay batches: w = NULL) only the 56 columns of [x0 ; x0_pre] are left.
+// the fp64 matrix cores: about three times the flops and no dependency at all -- a cold-start solve of up to 64 problems takes
+// 25-33 us instead of 56-75 us, 512 problems fill the chip -- and without w (replay batches: w = NULL) only the 56 columns of
+// [x0 ; x0_pre] are left (measured: DESIGN.md §7).
 // J and nuc come from the panel kernel itself (fmpc_build_inverse in fmpc_api.hip runs it once per (handle, k) on unit
 // vectors), so both paths share one factorisation.
 //
