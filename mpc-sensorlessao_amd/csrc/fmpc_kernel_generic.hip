@@ -684,8 +684,12 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
         const bool q1ok = 16 + li < n;
         const double* ua = su + (size_t)li * ldu;
         const double* ub = su + (size_t)(LI_PT + li) * ldu;
-        for (int c0 = 0; c0 < m; c0 += 4) {
-            const int c = c0 + lk;
+        // the four wavefronts split the actuators (k-steps of 4) and add their partial tiles in LDS in a fixed order: a
+        // quarter of the dependent products each instead of the same 4 x m / 4 on every wavefront
+        const int ksteps = (m + 3) / 4, per = (ksteps + 3) / 4;
+        const int k0 = wv * per, k1 = k0 + per < ksteps ? k0 + per : ksteps;
+        for (int ks = k0; ks < k1; ++ks) {
+            const int c = 4 * ks + lk;
             const bool cok = c < m;
             const int cc = cok ? c : m - 1;
             const double r0 = sBt[(size_t)cc * n + q0], r1 = sBt[(size_t)cc * n + q1];   // unconditional loads, then selects:
@@ -696,6 +700,25 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
             bu[1][0] = LI_MFMA(b0, v2, bu[1][0]); bu[1][1] = LI_MFMA(b1, v2, bu[1][1]);
         }
     }
+    __syncthreads();                                    // (u in LDS is dead: its space takes the partial tiles, [wave][tile][reg][lane])
+#pragma unroll
+    for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) su[((wv * 4 + wh * 2 + I) * 4 + r) * 64 + lane] = bu[wh][I][r];
+    __syncthreads();
+#pragma unroll
+    for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sacc += su[((v * 4 + wh * 2 + I) * 4 + r) * 64 + lane];
+                bu[wh][I][r] = sacc;
+            }
     LI_TICK(2);
     // ---- x0 = a + B u1 ,  x0_pre = x0_last    (one wave of the first row slice)
     if (blockIdx.y == 0 && wv == 0 && li < np) {
@@ -753,7 +776,9 @@ hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double*
     if (n > LI_NMAX) return hipErrorInvalidValue;
     if (n == 27) {
         const int Tn = T * n, rs = (Tn + 63) / 64, rows = (Tn + rs - 1) / rs;      // <= 64 rows = 4 tiles per workgroup
-        const size_t lds = ((size_t)m * n + 2 * LI_PT * (m + 1)) * sizeof(double);
+        size_t su_d = 2 * (size_t)LI_PT * (m + 1);                 // u1, u2 of the tile; afterwards the partial tiles of B u (4 x 4 x 256)
+        if (su_d < 4096) su_d = 4096;
+        const size_t lds = ((size_t)m * n + su_d) * sizeof(double);
         if (lds > 160 * 1024) return hipErrorInvalidValue;
         hipError_t ea = hipFuncSetAttribute((const void*)fmpc_loop_inputs_mfma27, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return ea;
