@@ -29,6 +29,17 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+#ifdef FW_TIMING
+// per-wavefront trace of the row-group kernel (constant 100 MHz clock): entry, operands in LDS, products done, stores issued
+__device__ unsigned long long fi_trace[4 * 8192];
+extern "C" int fmpc_debug_inv_trace(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fi_trace), sizeof(unsigned long long) * 4 * (n < 8192 ? n : 8192)) == hipSuccess ? 0 : -1;
+}
+#define FI_TICK(k) do { _tr[k] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define FI_TICK(k)
+#endif
 #define FI_CH 7                          // k-steps per register set (two sets in flight)
 
 __device__ __forceinline__ double fi_wave_sum(double v) {
@@ -287,6 +298,9 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     const FpParams* P = &Q;
     const int tid = threadIdx.x, lane = tid & 63, wvr = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
     const int kq = wvr / RT, wv = wvr % RT;                         // k group, row tile within the workgroup
+#ifdef FW_TIMING
+    unsigned long long _tr[4] = {(unsigned long long)wall_clock64(), 0, 0, 0};
+#endif
     const int T = P->T, nb = P->nb, batch = P->batch, npanels = P->npanels, TN = T * FP_N;
     const int nrow = nb * FP_N;
     const int nrt = (nrow + 15) / 16, nrg = (nrt + RT - 1) / RT, npg = (npanels + PB - 1) / PB, rg8 = (nrg + 7) / 8;
@@ -295,6 +309,9 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     const int ngate = (npanels + 7) & ~7;                           // gate tasks first (see fmpc_cold_inv)
     if ((int)blockIdx.x < ngate) {
         if ((int)blockIdx.x < npanels) fi_gate(P, (int)blockIdx.x, lds);
+#ifdef FW_TIMING
+        if (tid == 0 && blockIdx.x < 1000) { fi_trace[4 * (7000 + blockIdx.x)] = _tr[0]; fi_trace[4 * (7000 + blockIdx.x) + 3] = (unsigned long long)wall_clock64(); }
+#endif
         return;
     }
     const int bid = (int)blockIdx.x - ngate;
@@ -369,6 +386,7 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
     for (int i = 0; i < PPW; ++i) bv[i] = fi_zero(x0p != nullptr, HAS_W, 64 * cbase + lane) ? 0.0 : bv[i];
     stage(buf0, bv);
     __syncthreads();
+    FI_TICK(1);
     if constexpr (!HAS_W) {
         products(buf0, a0, FP_XKS);
     } else {
@@ -407,6 +425,7 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
                     for (int r = 0; r < 4; ++r) acc[j][r] += lds[(((v - 1) * RT + wv) * PB + j) * 256 + r * 64 + lane];
         }
     }
+    FI_TICK(2);
     if (live && kq == 0) {
         const size_t pstride = (size_t)nrow * FP_NP;
 #pragma unroll
@@ -419,6 +438,13 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
             }
         }
     }
+#ifdef FW_TIMING
+    FI_TICK(3);
+    if (lane == 0) {
+        const int wid = blockIdx.x * RT * KS + wvr;
+        if (wid < 8192) for (int q = 0; q < 4; ++q) fi_trace[4 * wid + q] = _tr[q];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
