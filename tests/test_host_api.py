@@ -138,3 +138,18 @@ def test_synthetic_is_seeded_and_stable(pkg):
     assert d["x0"].shape == (50, 27) and np.array_equal(d["x0"][:-1], d["x0_pre"][1:])
     assert abs(np.mean(np.linalg.norm(pkg.synthetic.make_realisation(a, 0, 500)[1:], axis=1)) - 3.0) < 1e-9
     assert [pkg.synthetic.radial_order(j) for j in (1, 2, 3, 4, 6, 7, 10, 11)] == [0, 1, 1, 2, 2, 3, 3, 4]
+
+
+def test_plain_c_client_builds_against_the_header_and_library(pkg, tmp_path):
+    """examples/c_client.c needs nothing but include/fastmpc.h and libfastmpc.so (no HIP, no torch): it compiles and links
+    with gcc on a box without a GPU (tests/test_gpu_c_client.py runs it)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "mpc-sensorlessao_amd", "lib")
+    exe = str(tmp_path / "c_client")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_client.c"),
+                    "-o", exe, "-L" + lib_dir, "-lfastmpc", "-Wl,-rpath," + lib_dir, "-lm"], check=True)
+    assert os.path.exists(exe)
