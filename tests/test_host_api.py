@@ -82,6 +82,11 @@ def test_create_argument_checks(pkg):
     assert lib.fmpc_solve_device(None, 1, *([None] * 5), 1, 0.01, *([None] * 5), None) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve_u0_device(None, 1, *([None] * 5), 1, 0.01, *([None] * 6), None) == pkg.FMPC_E_NULL
     assert lib.fmpc_set_ramp(None, one, one) == pkg.FMPC_E_NULL
+    # the entry points of round 2
+    assert lib.fmpc_loop_step_device(None, 1, *([None] * 8), 1, 0.01, *([None] * 6), None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_set_dense_form(None, 1, -1) == pkg.FMPC_E_NULL
+    assert lib.fmpc_last_dual_form(None) == pkg.FMPC_E_NULL
+    assert lib.fmpc_set_precision(None, 0) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve_ramp(None, 1, *([None] * 6), 1, 0.01, *([None] * 5)) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve_ramp_device(None, 1, *([None] * 6), 1, 0.01, *([None] * 5), None) == pkg.FMPC_E_NULL
     assert lib.fmpc_unpack_device(None, 1, None, None, None, None, None) == pkg.FMPC_E_NULL
