@@ -413,7 +413,11 @@ def _main(real_out):
         extra["budget5"] = {"what": "Newton budget 5 with the reference's exit test (test_fast_mpc.m:53,59) from the cold start, one step at a time",
                             "value": B * s5 / e5, "unit": "MPC steps/s", "kernel_ms": k5, "newton_iters_per_problem": i5 / B}
         if os.environ.get("FMPC_BENCH_MANY_LANES", "1") == "1":
-            l5 = pkg.SolveLanes(make_handle, B, depth=12, device=dev)
+            def make_lane_handle():                  # many lanes: the one-wavefront continuation shares the chip better
+                hl = make_handle()
+                hl.set_small_batch_kernel(False)
+                return hl
+            l5 = pkg.SolveLanes(make_lane_handle, B, depth=12, device=dev)
             e5l, s5l, _ = timed(lambda: l5.submit(x0, x0p, None, None, nu0, 5, K_BAR, after_current=False), max(48, ksteps), 12,
                                 after=l5.synchronize)
             extra["budget5_in_flight_12"] = {"value": B * s5l / e5l, "unit": "MPC steps/s", "ms_per_step": e5l / s5l * 1e3,

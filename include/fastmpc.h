@@ -280,6 +280,12 @@ int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
  *                        no panel path (n != 27).
  *   fmpc_last_dual_form: 1 if the last solve took the dense form, 0 otherwise. */
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
+
+/* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)
+ * run on the tiled kernel with 2-4 wavefronts per problem (tiled = 1, default: lowest latency of ONE call) or on the
+ * one-wavefront kernel (tiled = 0: its single wavefronts share the chip better when many handles have solves in flight at the
+ * same time; bench.py `budget5_in_flight_12`).  Environment FMPC_NO_SMALL_TILED=1 = tiled 0 at create time. */
+int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled);
 int fmpc_last_dual_form(fmpc_handle h);
 
 #ifdef __cplusplus

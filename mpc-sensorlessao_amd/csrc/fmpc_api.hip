@@ -1524,6 +1524,13 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
     return rc;
 }
 
+extern "C" int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled) {
+    if (!h) return FMPC_E_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->small_tiled = tiled ? 1 : 0;
+    return FMPC_OK;
+}
+
 extern "C" int fmpc_last_dual_form(fmpc_handle h) {
     if (!h) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(h->mu);

@@ -166,6 +166,13 @@ class FastMPCHandle:
         if rc != _lib.FMPC_OK:
             raise FastMPCError(rc, "fmpc_set_dense_form")
 
+    def set_small_batch_kernel(self, tiled):
+        """fmpc_set_small_batch_kernel: tiled kernel (True, default: lowest latency of one call) or the one-wavefront kernel
+        (False: better when many handles have solves in flight) for small per-problem-factor batches and budget continuations."""
+        rc = self._lib.fmpc_set_small_batch_kernel(self._h, int(bool(tiled)))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_set_small_batch_kernel")
+
     def last_dual_form(self):
         """1 if the last solve took the dense form of the dual solve (fmpc_last_dual_form)."""
         return int(self._lib.fmpc_last_dual_form(self._h))

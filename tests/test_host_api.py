@@ -87,6 +87,7 @@ def test_create_argument_checks(pkg):
     assert lib.fmpc_set_dense_form(None, 1, -1) == pkg.FMPC_E_NULL
     assert lib.fmpc_last_dual_form(None) == pkg.FMPC_E_NULL
     assert lib.fmpc_set_precision(None, 0) == pkg.FMPC_E_NULL
+    assert lib.fmpc_set_small_batch_kernel(None, 1) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve_ramp(None, 1, *([None] * 6), 1, 0.01, *([None] * 5)) == pkg.FMPC_E_NULL
     assert lib.fmpc_solve_ramp_device(None, 1, *([None] * 6), 1, 0.01, *([None] * 5), None) == pkg.FMPC_E_NULL
     assert lib.fmpc_unpack_device(None, 1, None, None, None, None, None) == pkg.FMPC_E_NULL
