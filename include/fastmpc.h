@@ -72,7 +72,7 @@ const char* fmpc_strerror(int code);
  *              solved by the tiled kernel, n <= 47 in fp64, <= 79 with the fp32 factor.  Dense R: the u block of Phi is
  *              then a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS by the
  *              tiled kernel in fp64 (n <= 47, m (m + 1) / 2 + m (n + 2) doubles of LDS: m = 144 fits); a generality
- *              path, ~20 x slower than a diagonal R.  Ramp rows (fmpc_set_ramp) need diagonal weights.
+ *              path, ~13 x slower than a diagonal R.  Ramp rows (fmpc_set_ramp) need diagonal weights.
  *              Not positive definite / not symmetric: FMPC_E_NOT_PD_PHI (the reference's chol(KKT_H) error,
  *              inf_newton_solver.m:24).
  *   q,r,qf     NULL = zeros (fast_mpc_objective.m:26-47).

@@ -1001,12 +1001,12 @@ static hipError_t ft_prepare(size_t lds) {
 
 // instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5); NW wavefronts per problem
 #define FT_DISPATCH(fn, ...)                                                                   \
-    /* dense R: fp64, four wavefronts (the per-stage m x m factorisation is workgroup-wide vector work) */                  \
+    /* dense R: fp64, eight wavefronts (the per-stage m x m factorisation is workgroup-wide vector work) */                  \
     if (denseR) {                                                                              \
-        if (is_float || NW != 4) return hipErrorInvalidValue;                                  \
-        if (NB == 1) return fn<double, 1, 4, -1, true>(__VA_ARGS__);                           \
-        if (NB == 2) return fn<double, 2, 4, -1, true>(__VA_ARGS__);                           \
-        if (NB == 3) return fn<double, 3, 4, -1, true>(__VA_ARGS__);                           \
+        if (is_float || NW != 8) return hipErrorInvalidValue;                                  \
+        if (NB == 1) return fn<double, 1, 8, -1, true>(__VA_ARGS__);                           \
+        if (NB == 2) return fn<double, 2, 8, -1, true>(__VA_ARGS__);                           \
+        if (NB == 3) return fn<double, 3, 8, -1, true>(__VA_ARGS__);                           \
         return hipErrorInvalidValue;                                                           \
     }                                                                                          \
     /* the AO sizes (n = 27 Zernike modes; n = 65: radial order 10) with their block structure at compile time, for the   \
@@ -1053,7 +1053,7 @@ bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* N
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
     if (NB > (is_float ? 5 : 3)) return false;
     if (denseR && is_float) return false;
-    const int NW = denseR ? 4 : ft_default_nw(NB, is_float);
+    const int NW = denseR ? 8 : ft_default_nw(NB, is_float);
     const int mb = (m + 15) / 16;
     if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb, denseR ? ft_pr_doubles(n, m) : 0).total > 160 * 1024) return false;
     if (NB_out) *NB_out = NB;
