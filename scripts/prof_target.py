@@ -6,7 +6,9 @@
   configs4        n = 65, T = 60, batch 1024, fp32 factor: fmpc_newton_tiled<float,5,8>
   batch512        configs[2]: 512 problems, cold start
   dense_w512      512 problems with a disturbance w: the dense form of the dual solve with all T n columns of w
-  closed512       closed loop, 512 realisations: fmpc_loop_step_device per step"""
+  closed512       closed loop, 512 realisations: fmpc_loop_step_device per step
+  budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
+                  + compaction, continuation of the ~9 % that go on by the tiled kernel"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,7 +43,7 @@ if target == "closed512":
     st, it = loop.status, loop.iters
 wt = torch.from_numpy(0.01 * np.random.default_rng(3).standard_normal((B, T * n))).to(dev) if target == "dense_w512" else None
 for _ in range(0 if target == "closed512" else reps):
-    h.solve_device(x0, x0p, wt, zi, nu0, 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
+    h.solve_device(x0, x0p, wt, zi, nu0, 5 if target == "budget5" else 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
 torch.cuda.synchronize()
 assert int((st < 0).sum()) == 0
 print(target, "path", h.last_dispatch(), "iters", int(it.sum()))
