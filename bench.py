@@ -242,7 +242,7 @@ def _main(real_out):
     # costs ~30 us of host time to submit, more than half a step: the first moves of GROUP consecutive steps share one buffer
     # and one all-gather ("fewer, larger collectives"), two buffers in turn so that a gather in flight never holds up a solve;
     # the last, partial group is gathered when the timed region ends (head_after runs inside it).
-    GROUP = 8
+    GROUP = int(os.environ.get("FMPC_BENCH_GATHER_GROUP", "8"))
     gather_state = {"pending": [None, None], "bufs": None, "slot": 0, "fill": 0}
     if dist_on:
         gather_state["bufs"] = [torch.empty((GROUP, B, m), dtype=torch.float64, device=dev) for _ in range(2)]
@@ -569,7 +569,7 @@ def _main(real_out):
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)" if shared else "per problem",
                        "cold_start_dual_solve": ("dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
                                                  if shared and dense else "two sweeps through the shared block factor (panels of 16 problems)") if shared else None,
-                       "gather": "all-gather of the first moves u0 (RCCL), one collective per 8 steps (and at the end of the timed region), two buffers in turn" if dist_on else "none (1 GPU)",
+                       "gather": ("all-gather of the first moves u0 (RCCL), one collective per %d steps (and at the end of the timed region), two buffers in turn" % GROUP) if dist_on else "none (1 GPU)",
                        "steps_requested": args.steps},
             "roofline": roof_pp if roof_pp is not None else roof_cold,
             "roofline_cold_start": roof_cold,
