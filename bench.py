@@ -501,6 +501,15 @@ def _main(real_out):
                                             "first_call_ms": t_first * 1e3, "next_calls_ms_median": float(np.median(ts)) * 1e3,
                                             "MPC_steps_per_s": 1.0 / float(np.median(ts))}
         lib.fmpc_solve_once_cache_clear()
+        # ------------------------------------------------------------------ end to end through the host-pointer entry
+        th = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            zh = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=args.n_newton, k=K_BAR)
+            th.append(time.perf_counter() - t0)
+        extra["host_pointer_entry"] = {"what": "fmpc_solve with HOST pointers on the headline batch: H2D of x0, x0_pre, nu0, the solve, D2H of z (%.0f MB), "
+                                               "pageable host memory, ctypes; never `value`" % (zh.nbytes / 1e6),
+                                       "ms_per_solve_median": float(np.median(th[1:])) * 1e3, "MPC_steps_per_s": B / float(np.median(th[1:]))}
 
     if dist_on and not args.no_extra:
         # ------------------------------------------------------------------ configs[3] literally: 4096 realisations sharded over the ranks
