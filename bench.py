@@ -508,7 +508,8 @@ def _main(real_out):
             zh = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=args.n_newton, k=K_BAR)
             th.append(time.perf_counter() - t0)
         extra["host_pointer_entry"] = {"what": "fmpc_solve with HOST pointers on the headline batch: H2D of x0, x0_pre, nu0, the solve, D2H of z (%.0f MB), "
-                                               "pageable host memory, ctypes; never `value`" % (zh.nbytes / 1e6),
+                                               "pageable host memory, a FRESH output array per call (its first touch is most of the time: the same copy into a buffer "
+                                               "that has been written before runs at 55 GB/s), ctypes; never `value`" % (zh.nbytes / 1e6),
                                        "ms_per_solve_median": float(np.median(th[1:])) * 1e3, "MPC_steps_per_s": B / float(np.median(th[1:]))}
 
     if dist_on and not args.no_extra:
