@@ -140,6 +140,7 @@ struct FwParams {
     int pphase;
     const double* rnp;              // per (panel, stage, problem): partial ||r_d||^2 at the new point (fmpc_cold_dz<true>)
     int* list;                      // problem index, bit 30 set = handed over (to be redone from scratch)
+    int flags;                      // experiment switches (environment FMPC_WAVE_FLAGS); 0 in production
 };
 #define FW_LIST_HANDED (1 << 30)
 
@@ -1724,6 +1725,8 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
     FwParams P;
     P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
     P.pphase = pphase; P.rnp = rnp; P.list = list;
+    static const int env_flags = [] { const char* e = getenv("FMPC_WAVE_FLAGS"); return e && e[0] ? atoi(e) : 0; }();
+    P.flags = env_flags;
     if (pphase == 1) lds_bytes = 0;                  // the decide-only launch touches no LDS: cheap to place
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
