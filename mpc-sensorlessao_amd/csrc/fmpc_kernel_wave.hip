@@ -79,18 +79,17 @@ struct FwCfg {
 };
 
 // per-wave workspace in HBM (doubles)
-struct FwWs { size_t b, nu, winv, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
+struct FwWs { size_t b, nu, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
 __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T, int nb, int LDG) {
     FwWs L; size_t o = 0;
     const size_t nbn = ((size_t)nb * N + 1) & ~(size_t)1;
     L.b = o; o += nbn;  L.nu = o; o += nbn;
-    L.winv = o; o += (size_t)T * mp;
     L.rdu = o; o += (size_t)T * m;   L.rdx = o; o += nbn;
     L.rp = o; o += nbn;  L.rhs = o; o += nbn;  L.y = o; o += nbn;  L.dnu = o; o += nbn;
     L.phx = o; o += nbn;
     L.rs = o; o += (size_t)nb * 32;
     o = (o + 1) & ~(size_t)1;
-    L.fac = o; o += (size_t)nb * 3 * N * LDG;
+    L.fac = o; o += (size_t)nb * 2 * N * LDG;                // L and U1 per stage (U2 = L^-1 Y2 is not streamed: see fw_phase_backward)
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -198,17 +197,20 @@ __device__ __forceinline__ void fw_mem_fence() {           // this wave's HBM wr
 template <int N>
 struct FwView {
     int m, mp, T, nb, s, has_xf, var2, fstride;
-    double *zp, *b, *nu, *winv, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
-    __device__ __forceinline__ FwView(FwKP P, int p) {
+    double *zp, *b, *nu, *rdu, *rdx, *rp, *rhs, *yv, *dnu, *phx, *rsg, *fac;
+    const double* zs;       // where the current iterate is read from: the caller's z_init until the first update has
+                            // written z_out (`first`), z_out afterwards -- the start point is never copied
+    __device__ __forceinline__ FwView(FwKP P, int p, int first = 0) {
         m = P->M.m; mp = P->V.mp; T = P->M.T; nb = P->M.nb; s = N + m; has_xf = P->M.has_xf; var2 = P->M.var2;
         const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG);
         const int wave_g = blockIdx.x * FW_WAVES + (threadIdx.x >> 6);
         double* wsp = P->ws + (size_t)wave_g * P->ws_stride;
         zp = P->zout + (size_t)p * T * s;
-        b = wsp + L.b; nu = wsp + L.nu; winv = wsp + L.winv; rdu = wsp + L.rdu;
+        zs = (first && P->zinit) ? P->zinit + (size_t)p * T * s : zp;
+        b = wsp + L.b; nu = wsp + L.nu; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
-        fstride = 3 * N * FwCfg<N>::LDG;
+        fstride = 2 * N * FwCfg<N>::LDG;
         if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; fstride = 6 * N * FwCfg<N>::LDG; }   // the factor IS the product
     }
 };
@@ -269,20 +271,25 @@ FW_FN void fw_phase_init(FwKP Pin, int p, int write_z) {
 // C' applied to a stacked dual vector v (nu or d_nu), all stages at once on the matrix cores.
 // Output tiles are (16 stages) x (16 consecutive entries of u_j or x_j): the epilogue then reads and
 // writes along contiguous elements of a stage, and the per-column constants are loaded once per tile.
-//   MODE 0 (P1): r_d = 2Hz + g + kP'd + C'nu, Rt^-1, Phi^-1 r_d on the x entries;
+// Rt_j = 2R + k diag(1/s+^2 + 1/s-^2) is recomputed from z wherever it is needed (here twice, once per stage in the
+// factorisation): it never makes a round trip through HBM.
+//   MODE 0 (P1): r_d = 2Hz + g + kP'd + C'nu; Phi^-1 r_d is what is kept (u entries: rdu, x entries: phx; r_d on x: rdx);
 //                out3 = { sum(r_d^2), -, "Phi not PD" flag }.
-//   MODE 1 (P5): d_z = Phi^-1(-r_d - C'd_nu) written over r_d; out3 = { <r_d,e>, ||e||^2, - }
-//                with e = k P'DP d_z (line search); k P'DP = Rt - 2R.
+//   MODE 1 (P5): d_z = Phi^-1(-r_d - C'd_nu) written over Phi^-1 r_d, AND the new iterate z + d_z written to z_out for
+//                the step length t = 1 (the usual outcome; fw_phase_zfix corrects it otherwise);
+//                out3 = { <r_d,e>, ||e||^2, - } with e = k P'DP d_z (line search); k P'DP = Rt - 2R.
 template <int N, int MODE>
-FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
+FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
-    const FwView<N> W(P, p);
+    first = __builtin_amdgcn_readfirstlane(first);
+    const FwView<N> W(P, p, first);
     const fw_clds_t sBt = (fw_clds_t)lds_g;
     const fw_lds_t out3 = (fw_lds_t)out3_g;
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-    const int m = W.m, mp = W.mp, T = W.T, s = W.s;
+    const int m = W.m, T = W.T, s = W.s;
     const double* vec = MODE == 0 ? W.nu : W.dnu;
+    const double* zs = W.zs;
     const double kbar = P->kbar;
     const double* umaxp = P->M.umax; const double* uminp = P->M.umin;
     const double* R2p = P->M.R2; const double* rlp = P->M.rl;
@@ -315,8 +322,19 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
                 a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
                 a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
             }
-        // ---- u entries: G[j][c] = sum_k v_j[k] B[k][c]
-        for (int J = 0; J * 16 < m; ++J) {
+        // ---- u entries: G[j][c] = sum_k v_j[k] B[k][c].  The inputs of column block J + 1 are requested before the
+        //      results of block J are stored (a load issued behind a store waits for it: vmcnt is in order).
+        const int NJ = (m + 15) >> 4;
+        double zu[8], in0[8], zun[8], in0n[8];
+        {
+            const int cc = c16 < m ? c16 : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                zu[e] = zs[sj[e] * s + cc];
+                in0[e] = MODE == 1 ? W.rdu[sj[e] * m + cc] : 0.0;
+            }
+        }
+        for (int J = 0; J < NJ; ++J) {
             const int c = 16 * J + c16;
             const bool cok = c < m;
             const int cc = cok ? c : 0;
@@ -328,16 +346,14 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
                 g0 = MFMA64(an[0][ks], bb, g0);
                 g1 = MFMA64(an[1][ks], bb, g1);
             }
-            double in0[8], in1[8];
-            double cmax = 0.0, cmin = 0.0, cr2 = R2p[cc], crl = 0.0;
-            if (MODE == 0) { cmax = umaxp[cc]; cmin = uminp[cc]; crl = rlp[cc]; }
+            const double cmax = umaxp[cc], cmin = uminp[cc], cr2 = R2p[cc], crl = MODE == 0 ? rlp[cc] : 0.0;
+            {
+                const int cn = 16 * (J + 1 < NJ ? J + 1 : J) + c16;
+                const int ccn = cn < m ? cn : 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (MODE == 0) {
-                    in0[e] = W.zp[sj[e] * s + cc];
-                } else {
-                    in0[e] = W.rdu[sj[e] * m + cc];
-                    in1[e] = W.winv[sj[e] * mp + cc];
+                for (int e = 0; e < 8; ++e) {
+                    zun[e] = zs[sj[e] * s + ccn];
+                    in0n[e] = MODE == 1 ? W.rdu[sj[e] * m + ccn] : 0.0;
                 }
             }
             double o0[8], o1[8];
@@ -345,37 +361,43 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
             for (int e = 0; e < 8; ++e) {
                 const double G = (e >> 2) == 0 ? g0[e & 3] : g1[e & 3];
                 const bool ok = cok && sok[e];
+                const double u = zu[e];
+                const double dp = fw_rcp(cmax - u), dm = fw_rcp(u - cmin);
+                const double hb = kbar * (dp * dp + dm * dm);        // k P'DP on this entry
+                const double rt = cr2 + hb;
+                const double wv = fw_rcp(rt);
                 if (MODE == 0) {
-                    const double u = in0[e];
-                    const double dp = fw_rcp(cmax - u), dm = fw_rcp(u - cmin);
-                    const double rt = cr2 + kbar * (dp * dp + dm * dm);
                     if (ok && (!(rt > 0.0) || isinf(rt))) bad = 1;
                     const double rd = cr2 * u + crl + kbar * (dp - dm) - G;
-                    o0[e] = fw_rcp(rt); o1[e] = rd;
+                    o0[e] = wv * rd;
                     if (ok) acc0 += rd * rd;
                 } else {
-                    const double rd = in0[e];
-                    const double du = (G - rd) * in1[e];
-                    const double ee = (fw_rcp(in1[e]) - cr2) * du;       // k P'DP dz, k P'DP = Rt - 2R
-                    o0[e] = du;
+                    const double rd = in0[e] * rt;
+                    const double du = (G - rd) * wv;
+                    const double ee = hb * du;
+                    o0[e] = du; o1[e] = u + du;
                     if (ok) { acc0 += rd * ee; acc1 += ee * ee; }
                 }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (cok && sok[e]) {
-                    if (MODE == 0) { W.winv[sj[e] * mp + c] = o0[e]; W.rdu[sj[e] * m + c] = o1[e]; }
-                    else W.rdu[sj[e] * m + c] = o0[e];
+                    W.rdu[sj[e] * m + c] = o0[e];
+                    if (MODE == 1) W.zp[sj[e] * s + c] = o1[e];
                 }
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { zu[e] = zun[e]; in0[e] = in0n[e]; }
         }
         // ---- x entries (x_jx, jx = j+1 for stage column j): H[j][r] = sum_k v_{j+1}[k] A1[k][r] + v_{j+2}[k] A2[k][r]
+        d4 h[2][2];
+        double cq2[2], cqf2[2], cql[2], cqfl[2], vprev[2][8], vxf[2][8], xin[2][8], zx[2][8];
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
             const int rr = 16 * J + c16;
             const bool rok = rr < N;
             const int rc = rok ? rr : 0;
-            d4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
+            h[J][0] = (d4){0, 0, 0, 0}; h[J][1] = (d4){0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
                 const int k = 4 * ks + g;
@@ -383,44 +405,49 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
                 const int off = ok ? k * N + rr : 0;
                 const double t1 = A1p[off], t2 = A2p[off];
                 const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
-                h0 = MFMA64(a1[0][ks], b1, h0);
-                h1 = MFMA64(a1[1][ks], b1, h1);
-                h0 = MFMA64(a2[0][ks], b2, h0);
-                h1 = MFMA64(a2[1][ks], b2, h1);
+                h[J][0] = MFMA64(a1[0][ks], b1, h[J][0]);
+                h[J][1] = MFMA64(a1[1][ks], b1, h[J][1]);
+                h[J][0] = MFMA64(a2[0][ks], b2, h[J][0]);
+                h[J][1] = MFMA64(a2[1][ks], b2, h[J][1]);
             }
-            const double cq2 = Q2p[rc], cqf2 = Qf2p[rc];
-            const double cql = MODE == 0 ? qlp[rc] : 0.0, cqfl = MODE == 0 ? qflp[rc] : 0.0;
-            double vprev[8], vxf[8], in0[8];
+            cq2[J] = Q2p[rc]; cqf2[J] = Qf2p[rc];
+            cql[J] = MODE == 0 ? qlp[rc] : 0.0; cqfl[J] = MODE == 0 ? qflp[rc] : 0.0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool last = sj[e] + 1 == T;
-                vprev[e] = vec[sj[e] * N + rc];
-                vxf[e] = vec[(last && has_xf ? T : sj[e]) * N + rc];
-                in0[e] = MODE == 0 ? W.zp[sj[e] * s + m + rc] : W.rdx[sj[e] * N + rc];
+                vprev[J][e] = vec[sj[e] * N + rc];
+                vxf[J][e] = vec[(last && has_xf ? T : sj[e]) * N + rc];
+                zx[J][e] = zs[sj[e] * s + m + rc];
+                xin[J][e] = MODE == 0 ? 0.0 : W.rdx[sj[e] * N + rc];
             }
-            double o0[8], o1[8];
+        }
+        // all loads are issued: only now the stores
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            const int rr = 16 * J + c16;
+            const bool rok = rr < N;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const double H = (e >> 2) == 0 ? h0[e & 3] : h1[e & 3];
+                const double H = (e >> 2) == 0 ? h[J][0][e & 3] : h[J][1][e & 3];
                 const bool last = sj[e] + 1 == T;
-                const double q2 = last ? cqf2 : cq2;
+                const double q2 = last ? cqf2[J] : cq2[J];
                 const double iq = fw_rcp(q2);
                 if (MODE == 0) {
-                    double v = q2 * in0[e] + (last ? cqfl : cql) + vprev[e] - H;
-                    if (last && has_xf) v += vxf[e];
-                    o0[e] = v; o1[e] = v * iq;                  // r_d and Phi^-1 r_d on x_j
-                    if (rok && sok[e]) acc0 += v * v;
+                    double v = q2 * zx[J][e] + (last ? cqfl[J] : cql[J]) + vprev[J][e] - H;
+                    if (last && has_xf) v += vxf[J][e];
+                    if (rok && sok[e]) {
+                        W.rdx[sj[e] * N + rr] = v;                    // r_d on x_j
+                        W.phx[sj[e] * N + rr] = v * iq;               // Phi^-1 r_d on x_j
+                        acc0 += v * v;
+                    }
                 } else {
-                    double v = -in0[e] - vprev[e] + H;
-                    if (last && has_xf) v -= vxf[e];
-                    o0[e] = v * iq;                              // d_x
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (rok && sok[e]) {
-                    W.rdx[sj[e] * N + rr] = o0[e];
-                    if (MODE == 0) W.phx[sj[e] * N + rr] = o1[e];
+                    double v = -xin[J][e] - vprev[J][e] + H;
+                    if (last && has_xf) v -= vxf[J][e];
+                    const double dx = v * iq;
+                    if (rok && sok[e]) {
+                        W.rdx[sj[e] * N + rr] = dx;                   // d_x
+                        W.zp[sj[e] * s + m + rr] = zx[J][e] + dx;
+                    }
                 }
             }
         }
@@ -433,63 +460,79 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// C applied to a stacked primal vector, all stages at once on the matrix cores; output tiles are
+// C applied to two stacked primal vectors in one pass, all stages at once on the matrix cores; output tiles are
 // (16 block rows i) x (16 state entries), so the epilogue runs along contiguous entries.
-//   MODE 0 (P1): r_p = C z - b; out1 = sum(r_p^2).
-//   MODE 1 (P2): rhs = r_p - C Phi^-1 r_d   (inf_newton_solver.m:28-29)
-template <int N, int MODE>
-FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
+//   P1: r_p = C z - b, out1 = sum(r_p^2)      P2: rhs = r_p - C Phi^-1 r_d   (inf_newton_solver.m:28-29)
+// Both products share the operand tiles of B (LDS), A1, A2; the exit test that sits between them in the reference
+// (inf_newton_solver.m:19-22) is taken by the caller from out1 -- rhs is then simply not used.
+template <int N>
+FW_FN void fw_phase_C2(FwKP Pin, int p, double* lds_g, double* out1_g, int first) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
-    const FwView<N> W(P, p);
+    first = __builtin_amdgcn_readfirstlane(first);
+    const FwView<N> W(P, p, first);
     const fw_clds_t sBt = (fw_clds_t)lds_g;
     const fw_lds_t out1 = (fw_lds_t)out1_g;
     const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int m = W.m, mp = W.mp, T = W.T, s = W.s, nb = W.nb;
     const double* A1tp = P->M.A1t; const double* A2tp = P->M.A2t;
+    const double* zs = W.zs;
     const bool var2 = W.var2 != 0;
     double acc = 0.0;
     for (int j0 = 0; j0 < nb; j0 += 32) {
-        d4 a[2][2];                              // a[I][J]: block rows 16I.., entries 16J..
+        d4 a[2][2], c[2][2];                     // a: C z, c: C Phi^-1 r_d;  [I][J]: block rows 16I.., entries 16J..
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
-            for (int J = 0; J < 2; ++J) a[I][J] = (d4){0, 0, 0, 0};
-        // ---- B u_i (K = m): A operand = u_i[c] (or Phi^-1 r_d on u) with the stage on the row index
+            for (int J = 0; J < 2; ++J) { a[I][J] = (d4){0, 0, 0, 0}; c[I][J] = a[I][J]; }
+        // ---- B u_i (K = m): A operand = u_i[c] / (Phi^-1 r_d)[u_i][c] with the stage on the row index
         const int i0 = j0 + c16, i1 = j0 + 16 + c16;
         const bool ok0 = i0 < T, ok1 = i1 < T;
-        const double* u0p = MODE == 0 ? W.zp + (size_t)(ok0 ? i0 : 0) * s : W.rdu + (size_t)(ok0 ? i0 : 0) * m;
-        const double* u1p = MODE == 0 ? W.zp + (size_t)(ok1 ? i1 : 0) * s : W.rdu + (size_t)(ok1 ? i1 : 0) * m;
-        const double* w0p = W.winv + (size_t)(ok0 ? i0 : 0) * mp;
-        const double* w1p = W.winv + (size_t)(ok1 ? i1 : 0) * mp;
+        const double* u0p = zs + (size_t)(ok0 ? i0 : 0) * s;
+        const double* u1p = zs + (size_t)(ok1 ? i1 : 0) * s;
+        const double* w0p = W.rdu + (size_t)(ok0 ? i0 : 0) * m;
+        const double* w1p = W.rdu + (size_t)(ok1 ? i1 : 0) * m;
+        double v0[FW_KCH], v1[FW_KCH], y0[FW_KCH], y1[FW_KCH];
+#pragma unroll
+        for (int q = 0; q < FW_KCH; ++q) {
+            const int k = 4 * q + g;
+            const int kk = k < m ? k : 0;
+            v0[q] = u0p[kk]; v1[q] = u1p[kk]; y0[q] = w0p[kk]; y1[q] = w1p[kk];
+        }
         for (int kc = 0; kc < mp; kc += 4 * FW_KCH) {
-            double x0[FW_KCH], x1[FW_KCH], v0[FW_KCH], v1[FW_KCH];
+            double x0[FW_KCH], x1[FW_KCH], v0n[FW_KCH], v1n[FW_KCH], y0n[FW_KCH], y1n[FW_KCH];
+            const int kn = kc + 4 * FW_KCH < mp ? kc + 4 * FW_KCH : kc;
 #pragma unroll
             for (int q = 0; q < FW_KCH; ++q) {
                 const int k = kc + 4 * q + g;
                 x0[q] = sBt[k * FW_LDB + c16];                    // B[r = c16][c = k]
                 x1[q] = sBt[k * FW_LDB + 16 + c16];
-                const int kk = k < m ? k : 0;
-                double t0 = u0p[kk], t1 = u1p[kk];
-                if (MODE == 1) { t0 *= w0p[kk]; t1 *= w1p[kk]; }
-                v0[q] = (ok0 && k < m) ? t0 : 0.0;
-                v1[q] = (ok1 && k < m) ? t1 : 0.0;
+                const int k2 = kn + 4 * q + g;
+                const int kk = k2 < m ? k2 : 0;
+                v0n[q] = u0p[kk]; v1n[q] = u1p[kk]; y0n[q] = w0p[kk]; y1n[q] = w1p[kk];
             }
 #pragma unroll
             for (int q = 0; q < FW_KCH; ++q) {
-                a[0][0] = MFMA64(v0[q], x0[q], a[0][0]);
-                a[0][1] = MFMA64(v0[q], x1[q], a[0][1]);
-                a[1][0] = MFMA64(v1[q], x0[q], a[1][0]);
-                a[1][1] = MFMA64(v1[q], x1[q], a[1][1]);
+                const int k = kc + 4 * q + g;
+                const double f0 = (ok0 && k < m) ? 1.0 : 0.0, f1 = (ok1 && k < m) ? 1.0 : 0.0;
+                const double p0 = v0[q] * f0, p1 = v1[q] * f1, q0 = y0[q] * f0, q1 = y1[q] * f1;
+                a[0][0] = MFMA64(p0, x0[q], a[0][0]);
+                a[0][1] = MFMA64(p0, x1[q], a[0][1]);
+                a[1][0] = MFMA64(p1, x0[q], a[1][0]);
+                a[1][1] = MFMA64(p1, x1[q], a[1][1]);
+                c[0][0] = MFMA64(q0, x0[q], c[0][0]);
+                c[0][1] = MFMA64(q0, x1[q], c[0][1]);
+                c[1][0] = MFMA64(q1, x0[q], c[1][0]);
+                c[1][1] = MFMA64(q1, x1[q], c[1][1]);
             }
+#pragma unroll
+            for (int q = 0; q < FW_KCH; ++q) { v0[q] = v0n[q]; v1[q] = v1n[q]; y0[q] = y0n[q]; y1[q] = y1n[q]; }
         }
-        // ---- A1 x_i + A2 x_{i-1}  (K = n)
-        const double* xs = MODE == 0 ? W.zp + m : W.phx;          // x_j at xs[(j-1)*xstride + k]
-        const int xstride = MODE == 0 ? s : N;
+        // ---- A1 x_i + A2 x_{i-1}  (K = n): x_j at zs[(j-1)*s + m + k], (Phi^-1 r_d)[x_j] at phx[(j-1)*N + k]
 #pragma unroll
         for (int ks = 0; ks < 7; ++ks) {
             const int k = 4 * ks + g;
-            double xa[2], xb[2], za[2], zb[2];
+            double xa[2], xb[2], za[2], zb[2], pa[2], pb[2];
 #pragma unroll
             for (int J = 0; J < 2; ++J) {
                 const int rr = 16 * J + c16;
@@ -504,10 +547,12 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
                 const int i = j0 + 16 * I + c16;
                 const bool oka = k < N && i >= 1 && i < T;
                 const bool okb = k < N && i >= 2 && i < T && var2;
-                const double ta = xs[oka ? (size_t)(i - 1) * xstride + k : 0];
-                const double tb = xs[okb ? (size_t)(i - 2) * xstride + k : 0];
-                za[I] = oka ? ta : 0.0;
-                zb[I] = okb ? tb : 0.0;
+                const double ta = zs[oka ? (size_t)(i - 1) * s + m + k : m];
+                const double tb = zs[okb ? (size_t)(i - 2) * s + m + k : m];
+                const double ua = W.phx[oka ? (size_t)(i - 1) * N + k : 0];
+                const double ub = W.phx[okb ? (size_t)(i - 2) * N + k : 0];
+                za[I] = oka ? ta : 0.0; zb[I] = okb ? tb : 0.0;
+                pa[I] = oka ? ua : 0.0; pb[I] = okb ? ub : 0.0;
             }
 #pragma unroll
             for (int I = 0; I < 2; ++I)
@@ -515,10 +560,12 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
                 for (int J = 0; J < 2; ++J) {
                     a[I][J] = MFMA64(za[I], xa[J], a[I][J]);
                     a[I][J] = MFMA64(zb[I], xb[J], a[I][J]);
+                    c[I][J] = MFMA64(pa[I], xa[J], c[I][J]);
+                    c[I][J] = MFMA64(pb[I], xb[J], c[I][J]);
                 }
         }
         {   // epilogue: element e = (I, J, r): block row i = j0+16I+4r+g, entry 16J+c16
-            bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16];
+            bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16], in2[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
@@ -526,32 +573,25 @@ FW_FN void fw_phase_C(FwKP Pin, int p, double* lds_g, double* out1_g) {
                 ok[e] = row < N && i < nb;
                 ir[e] = ok[e] ? row : 0; ii[e] = ok[e] ? i : 0;
                 const int jx = ii[e] < T ? ii[e] : T - 1;           // x_{i+1}; the xf row uses x_T
-                if (MODE == 0) {
-                    in0[e] = W.zp[jx * s + m + ir[e]];
-                    in1[e] = W.b[ii[e] * N + ir[e]];
-                } else {
-                    in0[e] = W.phx[jx * N + ir[e]];
-                    in1[e] = W.rp[ii[e] * N + ir[e]];
-                }
+                in0[e] = zs[jx * s + m + ir[e]];
+                in1[e] = W.b[ii[e] * N + ir[e]];
+                in2[e] = W.phx[jx * N + ir[e]];
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int I = e >> 3, J = (e >> 2) & 1, r = e & 3;
                 const double cz = ii[e] < T ? a[I][J][r] : 0.0;
-                if (MODE == 0) {
-                    const double v = in0[e] - in1[e] - cz;
-                    if (ok[e]) { W.rp[ii[e] * N + ir[e]] = v; acc += v * v; }
-                } else {
-                    const double v = in1[e] - (in0[e] - cz);
-                    if (ok[e]) W.rhs[ii[e] * N + ir[e]] = v;
+                const double cw = ii[e] < T ? c[I][J][r] : 0.0;
+                const double rp = in0[e] - in1[e] - cz;
+                if (ok[e]) {
+                    W.rp[ii[e] * N + ir[e]] = rp; acc += rp * rp;
+                    W.rhs[ii[e] * N + ir[e]] = rp - (in2[e] - cw);
                 }
             }
         }
     }
-    if (MODE == 0) {
-        acc = fw_wave_sum(acc);
-        if (lane == 0) out1[0] = acc;
-    }
+    acc = fw_wave_sum(acc);
+    if (lane == 0) out1[0] = acc;
     fw_mem_fence();
 }
 
@@ -986,14 +1026,16 @@ FW_FN void fw_cold_nu_update(FwKP Pin, int p, double* lds_g, double t) {
 // ------------------------------------------------------------------------------------------------
 // P3: block-penta-diagonal Cholesky of Y fused with the forward sweep (inf_newton_solver.m:27,30-31)
 template <int N>
-FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
+FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
     using C = FwCfg<N>;
     constexpr int LD = C::LD, LDG = C::LDG, RC = C::RC;
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
-    const FwView<N> W(P, p);
+    first = __builtin_amdgcn_readfirstlane(first);
+    const FwView<N> W(P, p, first);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
-    const int mp = W.mp, T = W.T, nb = W.nb;
+    const int m = W.m, mp = W.mp, T = W.T, nb = W.nb;
+    const double kbar = P->kbar;
     const bool var2 = W.var2 != 0;
     const fw_lds_t lds = (fw_lds_t)lds_g;
     const fw_clds_t sBt = lds;
@@ -1008,6 +1050,13 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int J = 0; J < 2; ++J) { Ua[I][J] = (d4){0, 0, 0, 0}; Ub[I][J] = Ua[I][J]; Uc[I][J] = Ua[I][J]; }
     int notpd = 0;
+    // Rt_i^-1 = 1 / (2R + k (1/s+^2 + 1/s-^2)) of stage i from u_i: three entries per lane (lane, lane + 64, lane + 128),
+    // handed to the k-steps of the product below through this wave's LDS tile tA (free at that point).  u_{i+1} is
+    // requested a stage ahead.
+    constexpr int NWQ = 3;
+    double un[NWQ];
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) { const int c = lane + 64 * q; un[q] = W.zs[c < m ? c : 0]; }
     for (int i = 0; i < nb; ++i) {
         const double* img = imgs + (size_t)P->V.iD[i] * C::IMG_STRIDE + lane;
         const double* img1 = imgs + (size_t)P->V.i1[i] * C::IMG_STRIDE + C::IMG_D + lane;
@@ -1032,19 +1081,33 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
         //      (No software pipelining against the VALU loop below: on gfx950 the fp64 MFMA and
         //      VALU instructions of a SIMD do not execute concurrently -- measured, see DESIGN.md.)
         if (i < T) {
-            const double* wi = W.winv + (size_t)i * mp + g;
-            const fw_clds_t bp = sBt + g * FW_LDB + c16;
-            // winv comes from HBM/L2 (a global load per k-step group): the next chunk's values are requested before
-            // this chunk's products (one chunk = 18 MFMAs = 1.2 k cycles, about one L2 round trip)
-            double wk[FW_KCH], wn[FW_KCH];
+            {
+                const double* umaxp = P->M.umax; const double* uminp = P->M.umin; const double* R2p = P->M.R2;
+                double cmx[NWQ], cmn[NWQ], cr2[NWQ], uc[NWQ];
 #pragma unroll
-            for (int q = 0; q < FW_KCH; ++q) wk[q] = wi[4 * q];
+                for (int q = 0; q < NWQ; ++q) {
+                    const int c = lane + 64 * q, cc = c < m ? c : 0;
+                    cmx[q] = umaxp[cc]; cmn[q] = uminp[cc]; cr2[q] = R2p[cc]; uc[q] = un[q];
+                }
+                const double* znext = W.zs + (size_t)(i + 1 < T ? i + 1 : i) * (N + m);
+#pragma unroll
+                for (int q = 0; q < NWQ; ++q) { const int c = lane + 64 * q; un[q] = znext[c < m ? c : 0]; }
+#pragma unroll
+                for (int q = 0; q < NWQ; ++q) {
+                    const int c = lane + 64 * q;
+                    const double dp = fw_rcp(cmx[q] - uc[q]), dm = fw_rcp(uc[q] - cmn[q]);
+                    const double wv = fw_rcp(cr2[q] + kbar * (dp * dp + dm * dm));
+                    if (c < mp) tA[c] = c < m ? wv : 0.0;              // zero weight on the k-step padding
+                }
+            }
+            fw_wave_fence();
+            const fw_clds_t wi = tA + g;
+            const fw_clds_t bp = sBt + g * FW_LDB + c16;
             for (int kc = 0; kc < mp; kc += 4 * FW_KCH) {
-                double b0[FW_KCH], b1[FW_KCH];
-                const int kn = kc + 4 * FW_KCH < mp ? kc + 4 * FW_KCH : kc;
+                double b0[FW_KCH], b1[FW_KCH], wk[FW_KCH];
 #pragma unroll
                 for (int q = 0; q < FW_KCH; ++q) {
-                    wn[q] = wi[kn + 4 * q];
+                    wk[q] = wi[kc + 4 * q];
                     b0[q] = bp[(kc + 4 * q) * FW_LDB];
                     b1[q] = bp[(kc + 4 * q) * FW_LDB + 16];
                 }
@@ -1055,8 +1118,6 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
                     S01 = MFMA64(a0, b1[q], S01);
                     S11 = MFMA64(a1, b1[q], S11);
                 }
-#pragma unroll
-                for (int q = 0; q < FW_KCH; ++q) wk[q] = wn[q];
             }
         }
         // ---- S -= Ua'Ua + Uc'Uc ;  M1 = Y_{i,i+1} - Ua'Ub
@@ -1158,12 +1219,14 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
             const fw_lds_t tdst = (hi ? tA : tB) + (cl < 28 ? cl : 28);
 #pragma unroll
             for (int j = 0; j < N; ++j) tdst[j * LD] = x[j];
-            if (cl < N) {
+            const bool ex = P->mode == FW_MODE_EXPORT;
+            if (cl < N && (!hi || ex)) {
+                // U1 row-major for the backward sweep.  U2 = L^-1 Y_{i,i+2} is not streamed (the backward sweep applies
+                // L^-1 to the constant block times d_nu_{i+2} instead); only the exported shared factor carries it
                 double* gdst = f + (hi ? 2 : 1) * N * LDG + cl;
 #pragma unroll
-                for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];       // U1 / U2 row-major for the backward sweep
+                for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];
             }
-            const bool ex = P->mode == FW_MODE_EXPORT;
             if (lane < N) {
                 // column j of L contiguous in r.  Shared (exported) tiles carry exact zeros on and above
                 // the diagonal so that the shared sweeps need no per-step masking; otherwise that part is unused.
@@ -1224,8 +1287,12 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g) {
 
 // ------------------------------------------------------------------------------------------------
 // P4: backward sweep, d_nu_i = L^-T (y_i - U1 d_nu_{i+1} - U2 d_nu_{i+2})   (inf_newton_solver.m:32)
+// Only L_i and U1_i come back from HBM.  U2_i = L_i^-1 Y_{i,i+2} with a CONSTANT block Y_{i,i+2}, so
+//     U2_i d_nu_{i+2} = L_i^-1 (Y_{i,i+2} d_nu_{i+2}):
+// a product with a constant block (its rows stay in registers) and one more forward substitution with L_i, whose
+// rows the lanes hold anyway -- a third less factor traffic in both directions for ~130 vector instructions per stage.
 // The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
-// and turned to the row-/column-per-lane layouts through this wave's LDS tiles.
+// and turned to the row-/column-per-lane layouts through this wave's LDS tile.
 template <int N>
 FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     using C = FwCfg<N>;
@@ -1241,14 +1308,16 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
     const double* facp = W.fac;
     const double* rsp = W.rsg;
+    const double* imgs = P->V.img + C::IMG_D + C::IMG_1;       // [block][row j][col c] copies of the constant blocks
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
     // software pipeline: each register set is reloaded for stage i-1 as soon as stage i has consumed it
-    double g1[N], g2[N], gl[N], yv_n, rs_n;
+    double g1[N], gl[N], y2[N], yv_n, rs_n;
+    int cur2 = -1;                    // block whose rows are in y2
     {
         const int i = W.nb - 1;
         const double* f = facp + (size_t)i * W.fstride + lc;
 #pragma unroll
-        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; g2[j] = f[(2 * N + j) * LDG]; gl[j] = f[j * LDG]; }
+        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; gl[j] = f[j * LDG]; }
         yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
     }
     for (int i = W.nb - 1; i >= 0; --i) {
@@ -1256,33 +1325,51 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         const double* fp = facp + (size_t)ip * W.fstride + lc;
         double v = yv_n;
         const double rsv = rs_n;
-        // U1 -> tA, U2 -> tB (row-major tiles), then row lr of each on lane lr
+        const int b2 = P->V.i2[i];
+        if (b2 != cur2) {                                      // (wave-uniform; changes once or twice per sweep)
+            const double* yr = imgs + (size_t)b2 * C::IMG_STRIDE + lr * 32;
 #pragma unroll
-        for (int j = 0; j < N; ++j) { tA[j * LD + lc] = g1[j]; tB[j * LD + lc] = g2[j]; }
+            for (int c = 0; c < N; ++c) y2[c] = yr[c];
+            cur2 = b2;
+        }
+        // U1 -> tA (row-major tile), then row lr on lane lr
+#pragma unroll
+        for (int j = 0; j < N; ++j) tA[j * LD + lc] = g1[j];
         fw_wave_fence();
 #pragma unroll
-        for (int j = 0; j < N; ++j) { g1[j] = fp[(N + j) * LDG]; g2[j] = fp[(2 * N + j) * LDG]; }
+        for (int j = 0; j < N; ++j) g1[j] = fp[(N + j) * LDG];
         yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
+        double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
         {
             const fw_clds_t r1 = tA + lr * LD;
-            const fw_clds_t r2 = tB + lr * LD;
 #pragma unroll
             for (int c = 0; c < N; ++c) {
                 const double a = fw_readlane(x1, c), bb = fw_readlane(x2, c);
                 v = fma(-r1[c], a, v);
-                v = fma(-r2[c], bb, v);
+                cc = fma(y2[c], bb, cc);
             }
         }
-        fw_wave_fence();
-        // L -> tA as [column j][row r]; lane j then reads its column (row j of the LDS tile)
+        // forward substitution  w = L^-1 cc  (lane r holds row r of L in gl: gl[k] = L[r][k]);  v -= w
+        {
+            double wres = 0.0;
 #pragma unroll
-        for (int j = 0; j < N; ++j) tA[j * LD + lc] = gl[j];
+            for (int k = 0; k < N; ++k) {
+                const double wk = fw_readlane(cc * rsv, k);
+                if (lane == k) wres = wk;
+                cc = fma(-gl[k], wk, cc);          // meaningful on lanes > k only
+            }
+            v -= wres;
+        }
+        fw_wave_fence();
+        // L -> tB as [column j][row r]; lane j then reads its column (row j of the LDS tile)
+#pragma unroll
+        for (int j = 0; j < N; ++j) tB[j * LD + lc] = gl[j];
         fw_wave_fence();
 #pragma unroll
         for (int j = 0; j < N; ++j) gl[j] = fp[j * LDG];
         double res = 0.0;
         {
-            const fw_clds_t cl = tA + lr * LD;
+            const fw_clds_t cl = tB + lr * LD;
 #pragma unroll
             for (int r = N - 1; r >= 0; --r) {
                 const double xr = fw_readlane(v * rsv, r);
@@ -1290,7 +1377,6 @@ FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
                 v = fma(-cl[r], xr, v);        // meaningful on lanes < r only
             }
         }
-        fw_wave_fence();
         if (lane < N) W.dnu[i * N + lane] = res;
         x2 = x1;
         x1 = res;
@@ -1394,19 +1480,64 @@ FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// z += t d_z, nu += t d_nu   (backtracking_inf_newton.m:10-11)
+// nu += t d_nu   (backtracking_inf_newton.m:11); every load before the first store
 template <int N>
-FW_FN void fw_phase_update(FwKP Pin, int p, double t) {
+FW_FN void fw_phase_nu_update(FwKP Pin, int p, double t) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     const FwView<N> W(P, p);
     const int lane = threadIdx.x & 63;
-    const int Nz = W.T * W.s, nbn = W.nb * N, m = W.m, s = W.s;
-    for (int idx = lane; idx < Nz; idx += 64) {
-        const int j = idx / s, e = idx - j * s;
-        W.zp[idx] += t * (e < m ? W.rdu[j * m + e] : W.rdx[j * N + e - m]);
+    const int nbn = W.nb * N;
+    for (int base = 0; base < nbn; base += 64 * 14) {
+        double a[14], d[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) { const int idx = base + lane + 64 * q; const int ic = idx < nbn ? idx : 0; a[q] = W.nu[ic]; d[q] = W.dnu[ic]; }
+#pragma unroll
+        for (int q = 0; q < 14; ++q) { const int idx = base + lane + 64 * q; if (idx < nbn) W.nu[idx] = a[q] + t * d[q]; }
     }
-    for (int idx = lane; idx < nbn; idx += 64) W.nu[idx] += t * W.dnu[idx];
+    fw_mem_fence();
+}
+
+// The rare case of a step length t != 1 (backtracking_inf_newton.m:10): fw_phase_CT<1> has written z + d_z and left
+// d_z in the workspace; z + t d_z = (z + d_z) + (t - 1) d_z.  Loads in groups of 8 ahead of the stores.
+template <int N>
+FW_FN void fw_phase_zfix(FwKP Pin, int p, double t) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63;
+    const int Nz = W.T * W.s, m = W.m, s = W.s;
+    const double tm1 = t - 1.0;
+    for (int base = 0; base < Nz; base += 64 * 8) {
+        double zv[8], dv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = base + lane + 64 * q, ic = idx < Nz ? idx : 0;
+            const int j = ic / s, e = ic - j * s;
+            zv[q] = W.zp[ic];
+            dv[q] = e < m ? W.rdu[j * m + e] : W.rdx[j * N + e - m];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int idx = base + lane + 64 * q; if (idx < Nz) W.zp[idx] = zv[q] + tm1 * dv[q]; }
+    }
+    fw_mem_fence();
+}
+
+// z_out = z_init for a problem that left before its first step (exit test met at the start point, or an error)
+template <int N>
+FW_FN void fw_phase_zcopy(FwKP Pin, int p) {
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p, 1);
+    const int lane = threadIdx.x & 63;
+    const int Nz = W.T * W.s;
+    for (int base = 0; base < Nz; base += 64 * 16) {
+        double zv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int idx = base + lane + 64 * q; zv[q] = W.zs[idx < Nz ? idx : 0]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int idx = base + lane + 64 * q; if (idx < Nz) W.zp[idx] = zv[q]; }
+    }
     fw_mem_fence();
 }
 
@@ -1494,10 +1625,6 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     // scalars handed back by the phases: a 4-double LDS slot per wave behind the tiles
     double* red = lds + (size_t)mp * FW_LDB + (size_t)FW_WAVES * C::PER_WAVE + wv * 4;
 
-    {   // zero the k-step padding of winv once (columns m..mp-1 never change)
-        const FwView<N> W(P, 0);
-        for (int idx = lane; idx < W.T * mp; idx += 64) W.winv[idx] = 0.0;
-    }
     const int max_iter = P->max_iter;
 #ifdef FW_TIMING
     unsigned long long _k0 = __builtin_readcyclecounter(), _k1, _ka[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1597,16 +1724,17 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             }
             it0 = 1;
         } else if (active) {
-            fw_phase_init<N>(P, p, 1);
+            fw_phase_init<N>(P, p, P->zinit ? 0 : 1);       // an explicit start point is read where it lies (FwView::zs)
             FW_KTICK(0);
         }
         for (int it = it0; it < max_iter && !done; ++it) {
-            fw_phase_CT<N, 0>(P, p, lds, red);              // r_d
+            const int first = (P->zinit != nullptr && nsteps == 0) ? 1 : 0;     // z_out not written yet: read z_init
+            fw_phase_CT<N, 0>(P, p, lds, red, first);       // r_d
             fw_wave_fence();
             const double rd2 = red[0];
             const bool bad = red[2] != 0.0;
             fw_wave_fence();
-            fw_phase_C<N, 0>(P, p, lds, red);               // r_p
+            fw_phase_C2<N>(P, p, lds, red, first);          // r_p and the right-hand side
             fw_wave_fence();
             const double rp2 = red[0];
             fw_wave_fence();
@@ -1614,15 +1742,14 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             const double rho2 = rd2 + rp2;
             if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
-            fw_phase_C<N, 1>(P, p, lds, red);               // rhs
             FW_KTICK(2);
-            const int npd = fw_phase_factor<N>(P, p, lds);
+            const int npd = fw_phase_factor<N>(P, p, lds, first);
             if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
             if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FW_KTICK(3);
             fw_phase_backward<N>(P, p, lds);
             FW_KTICK(4);
-            fw_phase_CT<N, 1>(P, p, lds, red);              // d_z and the line-search dots
+            fw_phase_CT<N, 1>(P, p, lds, red, first);       // d_z, the line-search dots, z + d_z
             fw_wave_fence();
             const double beta_e = red[0], eps2 = red[1];
             fw_wave_fence();
@@ -1638,13 +1765,15 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                     if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
                 }
             }
-            fw_phase_update<N>(P, p, t);
+            if (t != 1.0) fw_phase_zfix<N>(P, p, t);
+            fw_phase_nu_update<N>(P, p, t);
             if (P->step && lane == 0 && it < P->step_ld) P->step[(size_t)p * P->step_ld + it] = t;
             ++nsteps;
             FW_KTICK(5);
         }
         if (!active) continue;
         if (cold_mode && nsteps == 0) fw_phase_init<N>(P, p, 2);       // left before stepping: z is the start point
+        if (!cold_mode && nsteps == 0 && P->zinit) fw_phase_zcopy<N>(P, p);
         FW_KTICK(6);
         if (P->nuout) {
             const FwView<N> W(P, p);
