@@ -1192,24 +1192,67 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
         fw_wave_fence();
         FW_TICK(1);
         // ---- fused potrf (lane = row) + forward substitution (lane = column)
+        // Column k of L (one entry per lane) reaches all lanes THROUGH LDS: one ds_write of the column and
+        // uniform-address reads (two entries per ds_read2) instead of two v_readlane + hazard wait states per entry --
+        // the vector unit then issues little more than the 2 x 351 fma of the updates, and LDS instructions have their
+        // own issue port.  Column k + 1 is final after the first update of step k: it is scaled and written out
+        // before the rest of step k, whose fma cover the LDS round trip (and so does the SIMD's other wave).
+        const fw_lds_t colb = tA;                    // 2 x 64 doubles (tA and tB are free until the results are written);
+                                                     // every lane writes (no predicate: a conditional store is a branch)
+        constexpr int CH = 8;                        // entries of a column in flight per request (registers)
         double myrs = 1.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double d = fw_readlane(row[k], k);
+        double lk, xk;
+        {
+            const double d = fw_readlane(row[0], 0);
             if (!(d > 0.0) || isinf(d)) notpd = 1;
             const double rs = fw_rsqrt(d);
-            const double lk = row[k] * rs;           // L[r][k] on lane r (r > k)
-            row[k] = lk;
-            const double xk = x[k] * rs;
-            x[k] = xk;
-            if (lane == k) myrs = rs;
-#pragma unroll
-            for (int c = k + 1; c < N; ++c) {
-                const double lck = fw_readlane(lk, c);   // L[c][k], uniform
-                row[c] = fma(-lk, lck, row[c]);
-                x[c] = fma(-lck, xk, x[c]);
-            }
+            lk = row[0] * rs; xk = x[0] * rs;        // L[r][0] on lane r (r > 0)
+            row[0] = lk; x[0] = xk;
+            if (lane == 0) myrs = rs;
+            colb[lane] = lk;
         }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            fw_wave_fence();
+            const fw_clds_t cb = colb + (k & 1) * 64;                  // L[c][k]: one address for all lanes
+            double lc[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) lc[q] = cb[k + 1 + q < N ? k + 1 + q : N - 1];
+            double lkn = 0.0, xkn = 0.0;
+            if (k + 1 < N) {
+                // the entry the dependency chain runs through (pivot of step k + 1) comes by v_readlane: the chain
+                // then holds no LDS round trip, which only feeds the updates that are off the critical path
+                const double l1 = fw_readlane(lk, k + 1);
+                row[k + 1] = fma(-lk, l1, row[k + 1]);
+                x[k + 1] = fma(-l1, xk, x[k + 1]);
+                const double d = fw_readlane(row[k + 1], k + 1);
+                if (!(d > 0.0) || isinf(d)) notpd = 1;
+                const double rs = fw_rsqrt(d);
+                lkn = row[k + 1] * rs; xkn = x[k + 1] * rs;
+                row[k + 1] = lkn; x[k + 1] = xkn;
+                if (lane == k + 1) myrs = rs;
+                colb[((k + 1) & 1) * 64 + lane] = lkn;
+            }
+            // (requesting the head of column k + 1 here, ahead of the rest of step k, was measured: 1 % slower)
+#pragma unroll
+            for (int c0 = k + 1; c0 < N; c0 += CH) {
+                double ln[CH];
+                if (c0 + CH < N) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) ln[q] = cb[c0 + CH + q < N ? c0 + CH + q : N - 1];
+                }
+#pragma unroll
+                for (int q = (c0 == k + 1 ? 1 : 0); q < CH; ++q) {
+                    const int c = c0 + q;
+                    if (c < N) { row[c] = fma(-lk, lc[q], row[c]); x[c] = fma(-lc[q], xk, x[c]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) lc[q] = ln[q];
+            }
+            lk = lkn; xk = xkn;
+        }
+        fw_wave_fence();
         FW_TICK(2);
         // ---- results: U1|y -> tB, U2|y -> tA (layout change) and the factor to HBM
         {
