@@ -136,6 +136,10 @@ int fmpc_solve_device(fmpc_handle h, int batch,
  * fmpc_solve_device that also leaves the first move u0 = z(1:m) of every problem (u_prev = U(1:nu), README.md:589)
  * in u0_out (m x batch): the solve and the one output a closed loop needs in ONE call.  On the n = 27 paths the last
  * kernel of the solve writes it (no extra launch); otherwise it is fmpc_solve_device + fmpc_unpack_device.
+ * Output options: z_out may be NULL -- the caller of the reference only applies U(1:nu) (README.md:558-570,589).  The
+ * first moves, status, iters and step are then exactly those of the call with z_out given; on the cold-start panel path
+ * with n_newton = 1 and nu_out = NULL nothing of z is written at all (41 KB per problem at (27,144,30) become 1.1 KB),
+ * on every other path the iterate lives in a scratch array of the handle.
  */
 int fmpc_solve_u0_device(fmpc_handle h, int batch,
                          const double* x0, const double* x0_pre, const double* w,
@@ -199,6 +203,7 @@ int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const d
  * (same arguments, same results; x0, x0_pre, w are written as before).  Knowing that w = -M1 (B u1) - M2 (B u2) has
  * only 2 n degrees of freedom, the dense form of the cold-start dual solve (see fmpc_set_dense_form) takes
  * [B u1 ; B u2] in place of the T n entries of w: 28 instead of 217 k-steps per tile at (27, 144, 30), at any batch.
+ * z_out may be NULL (first moves only, see fmpc_solve_u0_device).
  */
 int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
                           const double* u1, const double* u2, double* x0, double* x0_pre, double* w,

@@ -21,7 +21,7 @@ class ClosedLoop:
     """ramp=True (after `handle.set_ramp`): every solve carries the VAR_1 variant's ramp-rate rows against the
     previous first move, u_prev = U(1:nu) (README.md:589; VAR_1/fast_mpc_ineq_const.m:58-76), zeros at the first step."""
 
-    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None, ramp=False, fused=True):
+    def __init__(self, handle, batch, n_newton=1, k=1e-2, device=None, ramp=False, fused=True, keep_z=True):
         import torch
         self.h, self.batch, self.n_newton, self.k = handle, int(batch), int(n_newton), float(k)
         dev = torch.device("cuda", handle.device) if device is None else device
@@ -31,7 +31,8 @@ class ClosedLoop:
         self.x0_pre = torch.zeros((batch, n), **f64)
         self.w = torch.zeros((batch, T * n), **f64)
         self.u = [torch.zeros((batch, m), **f64) for _ in range(3)]     # ring: u[k], u[k-1], u[k-2]
-        self.z = torch.empty((batch, handle.nz), **f64)
+        # keep_z=False: only the first moves leave the solve (z_out = NULL at the C ABI; README.md:589 applies U(1:nu) only)
+        self.z = torch.empty((batch, handle.nz), **f64) if (keep_z or ramp) else None
         self.status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.steps_done = 0
@@ -47,7 +48,8 @@ class ClosedLoop:
             self.h.loop_inputs_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
                                       self.x0, self.x0_pre, self.w)
             self.h.solve_device(self.x0, self.x0_pre, self.w, None, nu0, self.n_newton, self.k, z_out=self.z,
-                                status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new)
+                                status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new,
+                                want_z=self.z is not None)
         else:
             self.h.loop_step_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
                                     self.x0, self.x0_pre, self.w, nu0, self.n_newton, self.k, z_out=self.z,

@@ -54,7 +54,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
                             const double* nuws = nullptr, double* u0out = nullptr,
-                            int pphase = 0, const double* rnp = nullptr, int* list = nullptr);
+                            int pphase = 0, const double* rnp = nullptr, int* list = nullptr, int u0_done = 0);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -133,6 +133,8 @@ struct fmpc_handle_s {
     std::mutex host_mu;          // serialises the host-pointer entry points (shared staging)
     double* ws;
     size_t ws_doubles;
+    // z_out == NULL (first moves only): the working iterate of the problems a kernel has to iterate on lives here
+    double* zs; size_t zs_doubles;
     // staging for the host-pointer entry points
     void* stage;
     size_t stage_bytes;
@@ -291,7 +293,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     if (!h) return FMPC_E_ALLOC;
     h->n = n; h->m = m; h->T = T; h->var_order = var_order; h->has_xf = xf ? 1 : 0;
     h->nb = T + h->has_xf; h->device = device;
-    h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0;
+    h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0; h->zs = nullptr; h->zs_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
@@ -611,6 +613,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->ramp_du) (void)hipFree(h->ramp_du);
     if (h->ramp_ws) (void)hipFree(h->ramp_ws);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->zs) (void)hipFree(h->zs);
     if (h->stage) (void)hipFree(h->stage);
     delete h;
     return FMPC_OK;
@@ -1285,11 +1288,24 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                                   int n_newton, double k,
                                   double* z_out, double* nu_out, int* status, int* iters, double* step,
                                   double* u0_out, void* stream) {
-    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+    if (!h || !x0 || (!z_out && !u0_out)) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     const int max_iter = n_newton > 0 ? n_newton : 1000;
     hipError_t e;
+    // Output options (README.md:558-570,589: the loop uses U(1:nu) only): z_out == NULL with u0_out given returns the first
+    // moves alone.  The kernels that iterate on z then work in a scratch array of the handle; the cold-start panel path
+    // with a budget of 1 does not write z at all (fmpc_cold_dz<.., .., true>).
+    const bool z_null = z_out == nullptr;
+    if (z_null) {
+        const size_t need = (size_t)batch * h->T * (h->n + h->m);
+        if (need > h->zs_doubles) {
+            if (h->zs) { (void)hipDeviceSynchronize(); (void)hipFree(h->zs); h->zs = nullptr; h->zs_doubles = 0; }
+            if (hipMalloc((void**)&h->zs, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+            h->zs_doubles = need;
+        }
+        z_out = h->zs;
+    }
     if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
@@ -1368,6 +1384,8 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             // without w, without the terminal row and with a budget of 1 nobody but d_z reads nu+: d_z computes it itself
             const bool fuse = h->inv_last && h->inv_fuse && w == nullptr && !h->has_xf && max_iter == 1;
             Q.gate_only = fuse ? 1 : 0;
+            const bool u0only = z_null && max_iter == 1 && nu_out == nullptr;       // nothing of z leaves the chip
+            Q.u0out = u0_out;
             if (h->inv_last) {
                 if (lowrank) { Q.gw = h->lp_v; Q.gwn = 2 * h->n; Q.jimg = h->inv_jimg2; Q.jks = h->inv_jks2; Q.jksp = 16 * ((h->inv_jks2 + 15) / 16 + 3); }
                 else { Q.gw = w; Q.gwn = h->T * h->n; }
@@ -1380,7 +1398,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             const int ppx = (npanels + 7) / 8;                       // panels of the fullest XCD share
             const int dgrid = 8 * ((ppx * h->T + FD_WAVES - 1) / FD_WAVES);
             (void)ntasks;
-            e = fmpc_launch_dz(Q, dgrid, split, (hipStream_t)stream, fuse ? 1 : 0);
+            e = fmpc_launch_dz(Q, dgrid, split, (hipStream_t)stream, fuse ? 1 : 0, u0only ? 1 : 0);
             if (e != hipSuccess) return FMPC_E_HIP;
             // decides the step length of every problem; solves exactly those whose decision is not clear-cut.  Budget 1:
             // one launch.  Budgets > 1: a decide-only launch that also evaluates the next exit test and COMPACTS the
@@ -1414,7 +1432,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 e = fmpc_launch_wave(h->dev, h->wave, batch, g2, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                      z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                                      h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
-                                     h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws, u0_out, ph, h->pn_rnp, h->pn_list);
+                                     h->pn_gate, h->pn_epsp, h->pn_cnt, h->pn_nuws, u0_out, ph, h->pn_rnp, h->pn_list, u0only ? 1 : 0);
                 if (e != hipSuccess) return FMPC_E_HIP;
             }
             if (split && hipMemcpyAsync(h->pn_cnt_host, h->pn_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
@@ -1456,7 +1474,7 @@ static int fmpc_solve_device_impl(fmpc_handle h, int batch,
                                   int n_newton, double k,
                                   double* z_out, double* nu_out, int* status, int* iters, double* step,
                                   double* u0_out, void* stream) {
-    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+    if (!h || !x0 || (!z_out && !u0_out)) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
@@ -1497,7 +1515,7 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
                                      const double* nu0, int n_newton, double k,
                                      double* z_out, double* nu_out, int* status, int* iters, double* step,
                                      double* u0_out, void* stream) {
-    if (!h || !a_k || !x0 || !x0_pre || !w || !z_out || !u0_out) return FMPC_E_NULL;
+    if (!h || !a_k || !x0 || !x0_pre || !w || !u0_out) return FMPC_E_NULL;       // z_out may be NULL: first moves only
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;

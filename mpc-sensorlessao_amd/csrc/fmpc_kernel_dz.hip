@@ -48,7 +48,10 @@ extern "C" int fmpc_debug_dz_trace(unsigned long long* out, int n) {
 // tiles -- the result registers of the two products are exactly the B-operand layout the rest of the task works with.
 // Taken without w, without the terminal row and for a Newton budget of 1 (nobody else reads nu+ then): the 13 MB round trip
 // of nu+ through HBM and one launch disappear.
-template <bool NEXT, bool FUSED = false>
+// U0: the caller asked for the first moves only (z_out == NULL, README.md:589 uses nothing but U(1:nu)): nothing of z is
+// written -- the task of stage 0 writes u_0 of its 16 problems to u0out, every task still leaves its partial ||e||^2 (the
+// step-length decision needs all stages), and the x entries (a third of the products, two thirds of the loads) are skipped.
+template <bool NEXT, bool FUSED = false, bool U0 = false>
 __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpParams Pv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const FpParams Q = Pv;
@@ -131,13 +134,15 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
         };
         JS s0, s1;
         jload(j, s0);
-        jload(h1 ? j + 1 : j, s1);
+        if (!U0) jload(h1 ? j + 1 : j, s1);
 #pragma unroll
         for (int ks = 0; ks < FP_XKS; ++ks) dv[ks] = fi_zero(P->x0p != nullptr, false, 4 * ks + g) ? 0.0 : dv[ks];
         jmul(s0, v0, true);
-        jload(h2 ? j + 2 : j, s0);
-        jmul(s1, v1, h1);
-        jmul(s0, v2, h2);
+        if (!U0) {
+            jload(h2 ? j + 2 : j, s0);
+            jmul(s1, v1, h1);
+            jmul(s0, v2, h2);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -151,15 +156,18 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
             const bool kok = 4 * ks + g < FP_N;
             const int ko = (kok ? 4 * ks + g : 0) * FP_NP + c16;
             const double t0 = pnl[j * FP_N * FP_NP + ko];
-            const double t1 = pnl[(h1 ? j + 1 : j) * FP_N * FP_NP + ko];
-            const double t2 = pnl[(h2 ? j + 2 : j) * FP_N * FP_NP + ko];
-            v0[ks] = kok ? t0 : 0.0; v1[ks] = (kok && h1) ? t1 : 0.0; v2[ks] = (kok && h2) ? t2 : 0.0;
+            v0[ks] = kok ? t0 : 0.0;
+            if (!U0) {
+                const double t1 = pnl[(h1 ? j + 1 : j) * FP_N * FP_NP + ko];
+                const double t2 = pnl[(h2 ? j + 2 : j) * FP_N * FP_NP + ko];
+                v1[ks] = (kok && h1) ? t1 : 0.0; v2[ks] = (kok && h2) ? t2 : 0.0;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int I = 0; I < 2; ++I) nx[I][r] = 0.0;
-        if (xfl) {                                  // (wave-uniform; a strided load: 16 cache lines per instruction)
+        if (xfl && !U0) {                           // (wave-uniform; a strided load: 16 cache lines per instruction)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -172,13 +180,14 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
     // nu+_j is also needed TRANSPOSED, at (problem 4 r + g, row 16 I + lane % 16).  Loading it that way costs 16 cache
     // lines per instruction; the values are already here in B-operand layout, so they go through this wave's LDS
     // scratch instead: element (row, problem) at row * 16 + (problem ^ (row & 15)) -- conflict-free both ways.
+    double nj[2][4];
+    if (!U0) {
     const fd_lds_t scr = (fd_lds_t)lds + (NEXT ? L.total_next : L.total) + wv * FD_SCR;
 #pragma unroll
     for (int ks = 0; ks < FP_KS; ++ks) {
         const int row = 4 * ks + g;
         if (row < FP_N) scr[row * FP_NP + (c16 ^ (row & 15))] = v0[ks];
     }
-    double nj[2][4];
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -186,6 +195,7 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
             const int row = 16 * I + c16 < FP_N ? 16 * I + c16 : 0;
             nj[I][r] = scr[row * FP_NP + ((4 * r + g) ^ (row & 15))];
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);                     // operands are here (the LDS round trip above needed v0): compute and store
     __builtin_amdgcn_sched_barrier(0);
@@ -194,8 +204,9 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int p = panel * FP_NP + 4 * r + g;         // problem 4 r + g of the panel
-        zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + (size_t)j * s + c16;
-        nq[r] = P->nuout ? (p < batch ? P->nuout + (size_t)p * nus : P->dump + (size_t)T * s) + c16 : nullptr;
+        if (U0) zq[r] = (p < batch && j == 0 ? P->u0out + (size_t)p * m : P->dump) + c16;      // only stage 0 has something to write
+        else zq[r] = (p < batch ? P->zout + (size_t)p * T * s : P->dump) + (size_t)j * s + c16;
+        nq[r] = (P->nuout && !U0) ? (p < batch ? P->nuout + (size_t)p * nus : P->dump + (size_t)T * s) + c16 : nullptr;
     }
     double eps2[4] = {0.0, 0.0, 0.0, 0.0}, rn2[4] = {0.0, 0.0, 0.0, 0.0};
     const fd_clds_t UX = (fd_clds_t)lds + L.UX + c16;
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
     const bool last = j + 1 == T;
     const fd_clds_t xcv = XQ + (last ? 32 : 0), iqv = XQ + 64 + (last ? 32 : 0);
 #pragma unroll
-    for (int I = 0; I < 2; ++I) {
+    for (int I = 0; I < (U0 ? 0 : 2); ++I) {
         d4 hh = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < FP_KS; ++ks) hh = MFMA64(v1[ks], A1T[(I * FP_KS + ks) * 64], hh);
@@ -247,7 +258,7 @@ __global__ void __launch_bounds__(FD_THREADS, FUSED ? 2 : 4) fmpc_cold_dz(FpPara
             const double e = hc * du;
             if (cok) {
                 eps2[r] = fma(e, e, eps2[r]);
-                zq[r][16 * J] = ub + du;
+                if (!U0 || j == 0) zq[r][16 * J] = ub + du;
             }
             if (NEXT) {
                 // r_d[u] at the new point: 2R u+ + r + k (1/(umax - u+) - 1/(u+ - umin)) - B' nu+ ,  u+ = ubar + du
@@ -312,12 +323,21 @@ hipError_t fmpc_dz_prepare(int mp) {
     e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)fmpc_dz_lds_bytes(mp, 0));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)fmpc_dz_lds_bytes(mp, 0));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)fmpc_cold_dz<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)fmpc_dz_lds_bytes(mp, 0));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)fmpc_cold_dz<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)fmpc_dz_lds_bytes(mp, 1));
 }
 
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused) {
-    if (fused && !next) hipLaunchKernelGGL((fmpc_cold_dz<false, true>), dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused, int u0only) {
+    if (u0only && !next) {
+        if (fused) hipLaunchKernelGGL((fmpc_cold_dz<false, true, true>), dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
+        else hipLaunchKernelGGL((fmpc_cold_dz<false, false, true>), dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
+    } else if (fused && !next) hipLaunchKernelGGL((fmpc_cold_dz<false, true>), dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
     else if (next) hipLaunchKernelGGL(fmpc_cold_dz<true>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 1), stream, P);
     else hipLaunchKernelGGL(fmpc_cold_dz<false>, dim3(grid), dim3(FD_THREADS), fmpc_dz_lds_bytes(P.mp, 0), stream, P);
     return hipGetLastError();

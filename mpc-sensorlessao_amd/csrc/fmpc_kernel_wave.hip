@@ -140,6 +140,8 @@ struct FwParams {
     const double* rnp;              // per (panel, stage, problem): partial ||r_d||^2 at the new point (fmpc_cold_dz<true>)
     int* list;                      // problem index, bit 30 set = handed over (to be redone from scratch)
     int flags;                      // experiment switches (environment FMPC_WAVE_FLAGS); 0 in production
+    int u0_done;                    // panel path, first moves only: fmpc_cold_dz has written u0out itself (zout is a scratch
+                                    // array that only the problems redone here touch)
 };
 #define FW_LIST_HANDED (1 << 30)
 
@@ -1604,7 +1606,7 @@ __device__ __forceinline__ bool fw_panel_decide(FwKP P, int p, bool write) {
         if (P->iters) P->iters[p] = 1;
         if (P->step) for (int q = 0; q < P->step_ld; ++q) P->step[(size_t)p * P->step_ld + q] = q == 0 ? 1.0 : -1.0;
     }
-    if (clear && write && P->u0out) {               // z is what the d_z kernel wrote (an earlier launch)
+    if (clear && write && P->u0out && !P->u0_done) {     // z is what the d_z kernel wrote (an earlier launch)
         const int m = P->M.m;
         const double* zp = P->zout + (size_t)p * T * (P->M.n + m);
         for (int idx = lane; idx < m; idx += 64) P->u0out[(size_t)p * m + idx] = zp[idx];
@@ -1892,11 +1894,11 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out,
-                            int pphase, const double* rnp, int* list) {
+                            int pphase, const double* rnp, int* list, int u0_done) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
     P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
-    P.pphase = pphase; P.rnp = rnp; P.list = list;
+    P.pphase = pphase; P.rnp = rnp; P.list = list; P.u0_done = u0_done;
     static const int env_flags = [] { const char* e = getenv("FMPC_WAVE_FLAGS"); return e && e[0] ? atoi(e) : 0; }();
     P.flags = env_flags;
     if (pphase == 1) lds_bytes = 0;                  // the decide-only launch touches no LDS: cheap to place

@@ -99,6 +99,7 @@ struct FpParams {
     const double* jst; const double* nucst;                      // per stage: image of the rows of J_x (2 row tiles x FP_XKS k-steps) and nuc, padded to 32 (fmpc_cold_dz<.., true>)
     int gate_only;                                               // fmpc_cold_inv_rg: only the gate tasks (the dual solve itself is fused into d_z)
     const double* eimg;                                          // image of E = [A1 A2 ; A2 0] (4 row tiles x FP_XKS k-steps): b_0, b_1
+    double* u0out;                                               // fmpc_cold_dz<.., .., true>: first moves (m x batch); z is not written
 };
 
 // d[kk] of problem p, d = [x0 (27) ; x0_pre (27) ; 0 0 ; w (T n)]: ONE load from a selected address; a missing x0_pre / w
@@ -123,4 +124,4 @@ int fmpc_inv_variant(int npanels, int has_w, int jks);
 hipError_t fmpc_launch_inv(const FpParams& P, hipStream_t stream);
 size_t fmpc_dz_lds_bytes(int mp, int next);
 hipError_t fmpc_dz_prepare(int mp);
-hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused = 0);
+hipError_t fmpc_launch_dz(const FpParams& P, int grid, int next, hipStream_t stream, int fused = 0, int u0only = 0);

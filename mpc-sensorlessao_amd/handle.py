@@ -179,11 +179,13 @@ class FastMPCHandle:
 
     # ------------------------------------------------------------------ device tensors
     def solve_device(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
-                     z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None, u0_out=None):
+                     z_out=None, nu_out=None, status=None, iters=None, step=None, u_prev=None, u0_out=None, want_z=True):
         """Asynchronous solve on torch CUDA(HIP) tensors, on torch's current stream.
         Returns (z_out, status, iters).  Nothing is copied through the host.
         u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`).
-        u0_out (batch, m): also receives the first moves z[:, :m] (fmpc_solve_u0_device: no separate unpack)."""
+        u0_out (batch, m): also receives the first moves z[:, :m] (fmpc_solve_u0_device: no separate unpack).
+        want_z=False (with u0_out): first moves only -- z_out = NULL at the C ABI, the returned z is None (README.md:589
+        uses nothing but U(1:nu))."""
         import torch
 
         def chk(t, cols, name, dtype=torch.float64):
@@ -200,8 +202,12 @@ class FastMPCHandle:
         chk(x0, self.n, "x0"); chk(x0_pre, self.n, "x0_pre"); chk(w, self.T * self.n, "w")
         chk(z_init, self.nz, "z_init"); chk(nu0, self.nu_len, "nu0"); chk(u_prev, self.m, "u_prev")
         n_newton = 0 if n_newton is None else int(n_newton)
-        if z_out is None:
+        if not want_z and (u0_out is None or u_prev is not None):
+            raise FastMPCError(_lib.FMPC_E_NULL, "want_z=False needs u0_out (and no ramp rows)")
+        if z_out is None and want_z:
             z_out = torch.empty((batch, self.nz), dtype=torch.float64, device=dev)
+        if not want_z:
+            z_out = None
         if status is None:
             status = torch.empty(batch, dtype=torch.int32, device=dev)
         if iters is None:
@@ -250,7 +256,7 @@ class FastMPCHandle:
     def loop_step_device(self, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0=None, n_newton=1, k=1e-2,
                          z_out=None, status=None, iters=None, u0_out=None):
         """fmpc_loop_step_device: loop inputs + solve with first-move output in one call (same results as
-        `loop_inputs_device` followed by `solve_device(..., u0_out=...)`)."""
+        `loop_inputs_device` followed by `solve_device(..., u0_out=...)`).  z_out=None: first moves only."""
         import torch
         batch = a_k.shape[0]
         for t, cols, name in ((a_k, self.n, "a_k"), (x0_last, self.n, "x0_last"), (u1, self.m, "u1"), (u2, self.m, "u2"),

@@ -316,3 +316,59 @@ def test_solve_with_first_move_output(pkg, gpu, case):
     assert torch.equal(z, z_ref) and torch.equal(st, st_ref) and torch.equal(it, it_ref)
     assert torch.equal(u0, z[:, :m])
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["panel", "panel_sweeps_w", "panel_budget3", "handed_over", "warm_start", "warm_start_wave", "no_shared",
+                                  "generic_n8", "tiled_f32_n65", "panel_ragged"])
+def test_first_moves_only_output(pkg, gpu, case):
+    """Output options of the caller (README.md:558-570,589 applies U(1:nu) only): z_out = NULL with u0_out given.  The first
+    moves must be BITWISE what the full solve leaves in z[:, :m], with identical status / iters, on every device path --
+    the cold-start panel path then writes nothing of z (fmpc_cold_dz<.., .., true>), the others iterate in a scratch array."""
+    import torch
+    dev = torch.device("cuda:0")
+    B = 37 if case == "panel_ragged" else 40
+    n, m, T = (8, 5, 6) if case == "generic_n8" else (65, 144, 6) if case == "tiled_f32_n65" else (27, 144, 10)
+    if case == "generic_n8":
+        md, data = pkg.synthetic.make_test_problem(n, m, T, seed=3, batch=B)
+    else:
+        md = pkg.synthetic.make_model(n, m, T)
+        if case == "handed_over":
+            md["u_min"] = -0.05 * np.ones(m); md["u_max"] = 0.05 * np.ones(m)
+        data = pkg.synthetic.make_replay_batch(md, r=4, steps=B)
+        if case == "panel_sweeps_w":
+            data["w"] = 0.01 * np.random.default_rng(5).standard_normal((B, T * n))
+    if case == "no_shared":
+        os.environ["FMPC_NO_SHARED"] = "1"
+    if case in ("no_shared", "warm_start_wave"):
+        os.environ["FMPC_NO_SMALL_TILED"] = "1"
+    if case == "panel_sweeps_w":
+        os.environ["FMPC_NO_INV"] = "1"
+    try:
+        h = handle_from_model(pkg, md)
+    finally:
+        for v in ("FMPC_NO_SHARED", "FMPC_NO_SMALL_TILED", "FMPC_NO_INV"):
+            os.environ.pop(v, None)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x0, x0p, w, nu0 = t(data["x0"]), t(data["x0_pre"]), t(data.get("w")), t(data["nu0"])
+    nw = 3 if case == "panel_budget3" else 2 if case == "tiled_f32_n65" else 1
+    z_init = None
+    if case in ("warm_start", "warm_start_wave"):
+        z_init = h.solve_device(x0, x0p, w, None, nu0, 1, 1e-2)[0].clone()
+    z_ref, st_ref, it_ref = h.solve_device(x0, x0p, w, z_init, nu0, nw, 1e-2)
+    z_ref, st_ref, it_ref = z_ref.clone(), st_ref.clone(), it_ref.clone()
+    path_ref = h.last_dispatch()
+    u0 = torch.full((B, m), float("nan"), dtype=torch.float64, device=dev)
+    z, st, it = h.solve_device(x0, x0p, w, z_init, nu0, nw, 1e-2, u0_out=u0, want_z=False)
+    torch.cuda.synchronize()
+    assert z is None
+    assert h.last_dispatch() == path_ref
+    assert (path_ref[1] > 0) == (case == "handed_over")
+    assert torch.equal(st, st_ref) and torch.equal(it, it_ref)
+    assert torch.equal(u0, z_ref[:, :m])
+    # raw C ABI: z_out == NULL without u0_out is refused
+    import ctypes as C
+    rc = pkg.load().fmpc_solve_device(h._h, B, C.c_void_p(x0.data_ptr()), C.c_void_p(x0p.data_ptr()), None, None, None, 1, 1e-2,
+                                      None, None, None, None, None, None)
+    assert rc == pkg._lib.FMPC_E_NULL
+    h.close()

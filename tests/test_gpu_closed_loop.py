@@ -159,3 +159,25 @@ def test_loop_step_with_a_newton_budget_and_no_nu0(pkg, gpu):
         ref = closed_loop(md, a[:, r], 3, 1e-2)
         assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
     h.close()
+
+
+@pytest.mark.parametrize("R,T", [(1, 30), (40, 30), (37, 10)])
+def test_closed_loop_first_moves_only(pkg, gpu, R, T):
+    """ClosedLoop(keep_z=False): z_out = NULL at the C ABI (fmpc_loop_step_device), only u[k] = U(1:nu) leaves the solve
+    (README.md:589).  Trajectories bit for bit those of the loop that keeps z."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, T)
+    steps = 6
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    nu0 = torch.from_numpy(np.random.default_rng(1).random((steps, R, T * 27))).to(at.device)
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa = la.run(at, nu0)
+    Ub, Xb = lb.run(at, nu0)
+    torch.cuda.synchronize()
+    assert lb.z is None and h2.last_dispatch()[0] == pkg.FMPC_PATH_PANEL
+    assert int(la.status.abs().sum()) == 0 and int(lb.status.abs().sum()) == 0
+    assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb) and torch.equal(la.iters, lb.iters)
+    h1.close(); h2.close()
