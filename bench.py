@@ -45,6 +45,8 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X datasheet fp64 vector = matrix peak (scrip
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix = vector peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s
 MIN_LEG_MS = 50.0            # every timed GPU leg lasts at least this long
+HEAD_SETS = 4                # buffer sets the headline rotates through: 4 x 82 MB of z > the 256 MB Infinity Cache
+HEAD_REGIONS = int(os.environ.get("FMPC_BENCH_REGIONS", "15"))   # timed regions of EXACTLY --steps steps each; the median is reported
 
 
 def flops_per_problem_factor(n, m, T):
@@ -146,6 +148,8 @@ def _main(real_out):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("FMPC_BENCH_FORCE_DIST", "0") != "1":
+            assert dist.get_world_size() == args.gpus, "--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size())
 
     pkg = importlib.import_module("mpc-sensorlessao_amd")
     n, m, T, B = N_MODES, N_ACT, HORIZON, args.batch
@@ -181,9 +185,12 @@ def _main(real_out):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(step_fn, steps, warmup, min_ms=MIN_LEG_MS, after=None, exact=False):
+    def timed(step_fn, steps, warmup, min_ms=MIN_LEG_MS, after=None, exact=False, regions=1, all_regions=None):
         """W warm-up steps, then `steps` timed steps between barriers -- exactly `steps` for the headline (exact=True),
-        otherwise as many more as it takes for the timed region to last min_ms.
+        otherwise as many more as it takes for the timed region to last min_ms.  regions > 1 (headline): that many timed
+        regions of exactly `steps` steps back to back, each bracketed by barrier + synchronize; the MEDIAN region is
+        returned (a single 20-step region lasts 1 ms and spread by 15 % from run to run in round 2), all of them in
+        `all_regions`.
         Returns (elapsed_s, steps_done, kernel_ms): kernel_ms = median device time of ONE step run alone, from HIP
         events on the stream the step is enqueued on, measured outside the timed region."""
         for _ in range(warmup):
@@ -201,26 +208,31 @@ def _main(real_out):
         kern_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
         if world == 1 and not exact:
             steps = max(steps, int(np.ceil(min_ms / max(kern_ms, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step_fn()
-        if after:
-            after()
-        sync()
-        elapsed = time.perf_counter() - t0
+        times = []
+        for _ in range(max(1, regions)):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            if after:
+                after()
+            sync()
+            times.append(time.perf_counter() - t0)
         if dist_on:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            tmax = torch.tensor(times, dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                 # per region: the slowest rank
+            times = [float(v_) for v_ in tmax.tolist()]
+        if all_regions is not None:
+            all_regions.extend(times)
+        elapsed = float(np.median(times))
         return elapsed, steps, kern_ms
 
     class Replay:
         """One handle + output buffers for a replay batch; step() = solve + first moves (README.md:589) on torch's stream."""
-        def __init__(self, h, tx0, tx0p, tnu0, n_newton, z_init=None):
+        def __init__(self, h, tx0, tx0p, tnu0, n_newton, z_init=None, want_z=True):
             self.h, self.a = h, (tx0, tx0p, tnu0, z_init)
             Bn = tx0.shape[0]
             self.nw = n_newton
-            self.z = torch.empty((Bn, h.nz), dtype=torch.float64, device=dev)
+            self.z = torch.empty((Bn, h.nz), dtype=torch.float64, device=dev) if want_z else None
             self.u0 = torch.empty((Bn, h.m), dtype=torch.float64, device=dev)
             self.st = torch.zeros(Bn, dtype=torch.int32, device=dev)
             self.it = torch.zeros(Bn, dtype=torch.int32, device=dev)
@@ -228,7 +240,7 @@ def _main(real_out):
         def step(self, u0_out=None):
             tx0, tx0p, tnu0, zi = self.a
             self.h.solve_device(tx0, tx0p, None, zi, tnu0, self.nw, K_BAR, z_out=self.z, status=self.st, iters=self.it,
-                                u0_out=self.u0 if u0_out is None else u0_out)
+                                u0_out=self.u0 if u0_out is None else u0_out, want_z=self.z is not None)
 
         def check(self):
             assert int((self.st < 0).sum().item()) == 0, "solver reported errors"
@@ -237,7 +249,26 @@ def _main(real_out):
     # ------------------------------------------------------------------ headline: configs[1], one step at a time
     depth = max(1, args.in_flight)
     h = make_handle()
-    head = Replay(h, x0, x0p, nu0, args.n_newton)
+
+    class Ring:
+        """HEAD_SETS replay batches (different stretches of the realisation, own inputs AND outputs) solved in turn by one
+        handle: consecutive steps neither re-read the same inputs nor overwrite the same 82 MB of z, so the output stream of a
+        step really goes to HBM (4 x 82 MB exceed the 256 MB Infinity Cache; round 2 wrote one buffer over and over)."""
+        def __init__(self, h_, n_newton, want_z=True):
+            self.sets = []
+            for i_ in range(HEAD_SETS):
+                d_ = data if i_ == 0 else pkg.synthetic.make_replay_batch(model, r=rank + 1000 * i_, steps=B)
+                self.sets.append(Replay(h_, to_dev(d_["x0"]), to_dev(d_["x0_pre"]), to_dev(d_["nu0"]), n_newton, want_z=want_z))
+            self.i = 0
+
+        def step(self, u0_out=None):
+            self.sets[self.i].step(u0_out)
+            self.i = (self.i + 1) % len(self.sets)
+
+        def check(self):
+            return sum(s_.check() for s_ in self.sets) / len(self.sets)
+
+    head = Ring(h, args.n_newton)
     # Multi-GPU: the first moves of every step are gathered (the one collective of the job, RCCL all-gather).  A collective
     # costs ~30 us of host time to submit, more than half a step: the first moves of GROUP consecutive steps share one buffer
     # and one all-gather ("fewer, larger collectives"), two buffers in turn so that a gather in flight never holds up a solve;
@@ -278,8 +309,10 @@ def _main(real_out):
             if gather_state["pending"][s_] is not None:
                 gather_state["pending"][s_].wait(); gather_state["pending"][s_] = None
 
+    head_regions = []
     if depth == 1:
-        elapsed, steps_done, kern_ms = timed(head_step, args.steps, args.warmup, after=head_after, exact=True)
+        elapsed, steps_done, kern_ms = timed(head_step, args.steps, args.warmup, after=head_after, exact=True,
+                                             regions=HEAD_REGIONS, all_regions=head_regions)
     else:
         lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev)
         lane_step = lambda: lanes.submit(x0, x0p, None, None, nu0, args.n_newton, K_BAR, after_current=False)
@@ -350,6 +383,14 @@ def _main(real_out):
         eL, sL, _ = timed(head_step, args.steps, 2)
         extra["headline_min_50ms"] = {"what": "the headline leg again over a timed region of at least %.0f ms" % MIN_LEG_MS,
                                       "value": B * sL / eL, "unit": "MPC steps/s", "steps": sL, "ms_per_step": eL / sL * 1e3}
+        # ------------------------------------------------------------------ output options: first moves only (README.md:589)
+        hu = Ring(h, args.n_newton, want_z=False)
+        eU, sU, kU = timed(hu.step, args.steps, args.warmup)
+        hu.check()
+        extra["headline_u0_only"] = {"what": "same workload, z_out = NULL: only the first moves u0 = U(1:nu) leave the solve (what the reference's loop "
+                                             "applies, README.md:589); fmpc_cold_dz writes 1.1 KB instead of 41 KB per problem",
+                                     "value": B * sU / eU, "unit": "MPC steps/s", "ms_per_step": eU / sU * 1e3, "kernel_ms": kU}
+        del hu
         # ------------------------------------------------------------------ two steps in flight (independent batches)
         lanes = pkg.SolveLanes(make_handle, B, depth=2, device=dev)
         e2, s2, _ = timed(lambda: lanes.submit(x0, x0p, None, None, nu0, args.n_newton, K_BAR, after_current=False),
@@ -429,17 +470,18 @@ def _main(real_out):
             a_np = np.stack([pkg.synthetic.make_realisation(model, r=r_, steps=nsteps_)[1:nsteps_ + 1] for r_ in range(min(R_, 8))], axis=1)
             a_np = np.ascontiguousarray(np.tile(a_np, (1, (R_ + a_np.shape[1] - 1) // a_np.shape[1], 1))[:, :R_])
             a_t = torch.from_numpy(a_np).to(dev)
-            for rep in range(2):
-                loop = pkg.ClosedLoop(h, R_, n_newton=args.n_newton, k=K_BAR)
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for s_ in range(nsteps_):
-                    loop.step(a_t[s_])
-                torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t0
-            assert int(loop.status.abs().sum()) == 0
-            cl["realisations_%d" % R_] = {"value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3,
-                                          "sequential_steps": nsteps_}
+            for keep_z in (True, False):
+                for rep in range(2):
+                    loop = pkg.ClosedLoop(h, R_, n_newton=args.n_newton, k=K_BAR, keep_z=keep_z)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for s_ in range(nsteps_):
+                        loop.step(a_t[s_])
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t0
+                assert int(loop.status.abs().sum()) == 0
+                cl["realisations_%d%s" % (R_, "" if keep_z else "_u0_only")] = {
+                    "value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3, "sequential_steps": nsteps_}
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
                                          "depends on the previous first move, so only realisations batch; one fmpc_loop_step_device call per step", **cl)
         # ------------------------------------------------------------------ configs[0] on the device: VAR(1), T = 10, ramp rows
@@ -515,19 +557,21 @@ def _main(real_out):
     if dist_on and not args.no_extra:
         # ------------------------------------------------------------------ configs[3] literally: 4096 realisations sharded over the ranks
         BG = 4096
-        dg = pkg.synthetic.make_replay_batch(model, r=100, steps=BG)          # the same replicated global batch on every rank
-        gx0, gx0p, gnu = to_dev(dg["x0"]), to_dev(dg["x0_pre"]), to_dev(dg["nu0"])
-        if rehearse:
-            sh = pkg.ShardedFastMPC.from_handle(h)
-        else:
-            sh = pkg.ShardedFastMPC.from_handle(h)
-        fn3 = lambda: sh.solve_gather(gx0, gx0p, None, gnu, args.n_newton, K_BAR, what="u0")
+        sh = pkg.ShardedFastMPC.from_handle(h)
+        lo, hi = sh.block(BG)                                                  # this rank's contiguous block of realisations
+        # every rank generates ONLY its own block (realisation g = one problem, seeds 1000 + g / 5000 + g as in SURVEY 8d);
+        # nothing of the global batch is replicated
+        blk = [pkg.synthetic.make_replay_batch(model, r=100 + g_, steps=1) for g_ in range(lo, hi)]
+        cat = lambda k_: to_dev(np.concatenate([b_[k_] for b_ in blk], axis=0)) if blk else torch.empty((0, n if k_ != "nu0" else T * n), dtype=torch.float64, device=dev)
+        lx0, lx0p, lnu = cat("x0"), cat("x0_pre"), cat("nu0")
+        fn3 = lambda: sh.solve_gather_local(BG, lx0, lx0p, None, lnu, args.n_newton, K_BAR, what="u0")
         e3, s3, k3 = timed(fn3, max(20, args.steps // 4), 5)
         if rank == 0:
-            extra["configs3_sharded"] = {"what": "configs[3]: 4096 realisations sharded over the ranks (contiguous blocks, no data-path collective) "
-                                                 "+ ONE all-gather of the first moves per step (ShardedFastMPC.solve_gather)",
+            extra["configs3_sharded"] = {"what": "configs[3]: 4096 realisations sharded over the ranks (contiguous blocks generated rank-locally, no "
+                                                 "data-path collective) + ONE all-gather of the first moves per step (ShardedFastMPC.solve_gather_local)",
                                          "value": BG * s3 / e3, "unit": "MPC steps/s", "ms_per_step": e3 / s3 * 1e3, "ranks": world,
-                                         "problems_per_rank": -(-BG // world)}
+                                         "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "device_ordinal": local_rank,
+                                         "problems_per_rank": -(-BG // world), "this_rank_block": [lo, hi]}
 
     if rank == 0:
         units = iters_head
@@ -580,7 +624,12 @@ def _main(real_out):
                        "cold_start_dual_solve": ("dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
                                                  if shared and dense else "two sweeps through the shared block factor (panels of 16 problems)") if shared else None,
                        "gather": ("all-gather of the first moves u0 (RCCL), one collective per %d steps (and at the end of the timed region), two buffers in turn" % GROUP) if dist_on else "none (1 GPU)",
-                       "steps_requested": args.steps},
+                       "steps_requested": args.steps,
+                       "timing": "median of %d timed regions of exactly %d steps each (barrier + synchronize on both sides of every region); "
+                                 "regions (ms): min %.3f, median %.3f, max %.3f" % (len(head_regions) or 1, steps_done,
+                                                                                   1e3 * min(head_regions or [elapsed]), 1e3 * elapsed, 1e3 * max(head_regions or [elapsed])),
+                       "buffers": "%d input/output sets solved in turn (%.0f MB of z in rotation: larger than the 256 MB Infinity Cache)" % (HEAD_SETS, HEAD_SETS * B * T * (n + m) * 8 / 1e6),
+                       "ranks": world, "rccl_ranks": dist.get_world_size() if dist_on else 1, "device_ordinal": local_rank},
             "roofline": roof_pp if roof_pp is not None else roof_cold,
             "roofline_cold_start": roof_cold,
         }
@@ -630,17 +679,30 @@ def cpu_baselines(pkg, model, data, n_newton):
                                        "sample": "1 problem, BLAS limited to 1 thread (the reference's tic/toc is a single MATLAB thread), %.1f s" % t1}
     try:
         from oracle import banded_cpu
-        sub = {k_: (None if v_ is None else v_[:256]) for k_, v_ in data.items()}
-        t0 = time.perf_counter(); banded_cpu.solve_batch(model, {k_: (None if v_ is None else v_[:16]) for k_, v_ in data.items()}, n_newton, K_BAR, threads=1)
-        t1 = (time.perf_counter() - t0) / 16
+        take = lambda cnt: {k_: (None if v_ is None else np.ascontiguousarray(np.tile(v_, ((cnt + len(v_) - 1) // len(v_), 1))[:cnt]))
+                            for k_, v_ in data.items()}
+        # one thread: 32 problems, repeated until 1 s has passed
+        d1 = take(32)
+        o1 = banded_cpu.solve_batch(model, d1, n_newton, K_BAR, threads=1)
+        t0 = time.perf_counter(); r1 = 0
+        while time.perf_counter() - t0 < 1.0:
+            banded_cpu.solve_batch(model, d1, n_newton, K_BAR, threads=1, out=o1); r1 += 1
+        t1 = (time.perf_counter() - t0) / (32 * r1)
+        # all cores: 32 problems PER THREAD in one call (OpenMP over the batch, per-thread workspace, outputs first touched by
+        # the warm-up call and then reused), repeated until 2 s have passed; round 2 measured one problem per thread per call,
+        # i.e. mostly the start of 256 threads and the first touch of the outputs
         nthr = cores
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter(); banded_cpu.solve_batch(model, sub, n_newton, K_BAR, threads=nthr); ts.append((time.perf_counter() - t0) / 256)
-        out["cpu_baseline_structured"] = {"value": 1.0 / float(np.median(ts)), "unit": "MPC steps/s", "cores": nthr, "kind": "port",
-                                          "one_thread_value": 1.0 / t1,
+        dn = take(32 * nthr)
+        on = banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr)
+        t0 = time.perf_counter(); rn = 0
+        while time.perf_counter() - t0 < 2.0:
+            banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr, out=on); rn += 1
+        tn = (time.perf_counter() - t0) / (32 * nthr * rn)
+        out["cpu_baseline_structured"] = {"value": 1.0 / tn, "unit": "MPC steps/s", "cores": nthr, "kind": "port",
+                                          "one_thread_value": 1.0 / t1, "speedup_over_one_thread": t1 / tn,
                                           "sample": "oracle/banded_cpu.c (block-penta-diagonal Newton step, the GPU's algorithm; OpenMP over the "
-                                                    "batch): 256 problems x 3 on %d threads, 16 problems on 1 thread" % nthr}
+                                                    "batch): %d problems per call (32 per thread) x %d calls on %d threads in %.1f s; 32 problems x %d calls "
+                                                    "on 1 thread" % (32 * nthr, rn, nthr, tn * 32 * nthr * rn, r1)}
     except Exception as e:     # the baseline library is optional
         out["cpu_baseline_structured"] = {"error": repr(e)}
     return out

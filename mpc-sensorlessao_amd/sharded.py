@@ -19,8 +19,9 @@ class ShardedFastMPC:
     device.  On a GPU rank this is `FastMPCHandle.solve_device`; CPU gloo tests inject a checker.
     """
 
-    def __init__(self, solve_fn, nz, m, T, n, group=None):
+    def __init__(self, solve_fn, nz, m, T, n, group=None, solve_u0_fn=None):
         self.solve_fn = solve_fn
+        self.solve_u0_fn = solve_u0_fn     # optional: (x0, x0_pre, w, nu0, n_newton, k) -> first moves (local_batch, m) only
         self.nz, self.m, self.T, self.n = nz, m, T, n
         self.group = group
 
@@ -30,13 +31,23 @@ class ShardedFastMPC:
         the rank's GPU, asynchronous on torch's current stream)."""
         def solve_fn(x0, x0_pre, w, nu0, n_newton, k):
             return handle.solve_device(x0, x0_pre, w, None, nu0, n_newton, k)[0]
-        return cls(solve_fn, handle.nz, handle.m, handle.T, handle.n, group)
+
+        def solve_u0_fn(x0, x0_pre, w, nu0, n_newton, k):          # z_out = NULL at the C ABI: nothing but u0 leaves the solve
+            u0 = x0.new_empty((x0.shape[0], handle.m))
+            handle.solve_device(x0, x0_pre, w, None, nu0, n_newton, k, u0_out=u0, want_z=False)
+            return u0
+        return cls(solve_fn, handle.nz, handle.m, handle.T, handle.n, group, solve_u0_fn)
 
     def _dist(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             return dist, dist.get_world_size(self.group), dist.get_rank(self.group)
         return None, 1, 0
+
+    def block(self, batch):
+        """(lo, hi) of this rank's contiguous block of a global batch."""
+        _, ws, rank = self._dist()
+        return shard_range(batch, ws, rank)
 
     def solve_local(self, x0, x0_pre, w, nu0, n_newton, k):
         """Solve this rank's shard of a replicated global batch.  Returns (z_local, lo, hi)."""
@@ -52,7 +63,9 @@ class ShardedFastMPC:
         what: "z" (N_z), "u0" (first move, README.md:589), "U" (T*m)."""
         import torch
         dist, ws, rank = self._dist()
-        if what == "u0":
+        if what == "rows":
+            pass                                     # `local` already holds what is to be gathered (e.g. first moves)
+        elif what == "u0":
             local = local[:, :self.m].contiguous()
         elif what == "U":
             local = local.reshape(local.shape[0], self.T, self.n + self.m)[:, :, :self.m] \
@@ -76,3 +89,14 @@ class ShardedFastMPC:
     def solve_gather(self, x0, x0_pre, w, nu0, n_newton, k, what="u0"):
         z, lo, hi = self.solve_local(x0, x0_pre, w, nu0, n_newton, k)
         return self.gather(z, x0.shape[0], what)
+
+    def solve_gather_local(self, batch, x0, x0_pre, w, nu0, n_newton, k, what="u0"):
+        """Like solve_gather, but the inputs are THIS RANK'S BLOCK only (rows lo..hi of a global batch of `batch` problems,
+        see `block`): nothing is replicated.  An empty block (more ranks than problems) takes part in the gather with no rows."""
+        lo, hi = self.block(batch)
+        assert x0.shape[0] == hi - lo, "solve_gather_local: pass exactly this rank's block"
+        if what == "u0" and self.solve_u0_fn is not None:
+            local = self.solve_u0_fn(x0, x0_pre, w, nu0, n_newton, k) if hi > lo else x0.new_zeros((0, self.m))
+            return self.gather(local, batch, "rows")
+        z = self.solve_fn(x0, x0_pre, w, nu0, n_newton, k) if hi > lo else x0.new_zeros((0, self.nz))
+        return self.gather(z, batch, what)

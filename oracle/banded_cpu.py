@@ -37,8 +37,10 @@ def _c(a):
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 
 
-def solve_batch(model, data, n_newton, k, z_init=None, threads=0):
-    """model / data as in mpc-sensorlessao_amd.synthetic.  Returns z, nu, iters, status, step (batch x step_ld)."""
+def solve_batch(model, data, n_newton, k, z_init=None, threads=0, out=None):
+    """model / data as in mpc-sensorlessao_amd.synthetic.  Returns z, nu, iters, status, step (batch x step_ld).
+    out: the tuple a previous call of the same shape returned -- its arrays are written again (a timing loop then does
+    not pay the first touch of 41 KB of z per problem on every repetition)."""
     lib = load()
     n, m, T = model["n"], model["m"], model["T"]
     var2 = model.get("var_order", 2) == 2
@@ -52,8 +54,12 @@ def solve_batch(model, data, n_newton, k, z_init=None, threads=0):
     x0 = _c(data["x0"]); batch = x0.shape[0]
     x0p = _c(data.get("x0_pre")); w = _c(data.get("w")); nu0 = _c(data.get("nu0")); zi = _c(z_init)
     sld = n_newton if n_newton and n_newton > 0 else 1000
-    z = np.empty((batch, T * (n + m))); nu = np.empty((batch, nb * n))
-    iters = np.zeros(batch, dtype=np.int32); status = np.zeros(batch, dtype=np.int32); step = np.empty((batch, sld))
+    if out is not None:
+        z, nu, iters, status, step = out
+        assert z.shape == (batch, T * (n + m)) and nu.shape == (batch, nb * n) and step.shape == (batch, sld)
+    else:
+        z = np.empty((batch, T * (n + m))); nu = np.empty((batch, nb * n))
+        iters = np.zeros(batch, dtype=np.int32); status = np.zeros(batch, dtype=np.int32); step = np.empty((batch, sld))
     keep = [_c(model.get("q")), _c(model.get("r")), _c(model.get("qf")), _c(model["u_min"]), _c(model["u_max"]),
             _c(model["x_min"]), _c(model["x_max"]), _c(xf)]
     rc = lib.banded_cpu_solve_batch(C.c_int(n), C.c_int(m), C.c_int(T), _p(A1), _p(A2), _p(B), _p(Q2), _p(R2), _p(Qf2),

@@ -65,3 +65,47 @@ def test_sharded_hip_solve_equals_single_process(tmp_path, pkg, gpu, batch, nw):
         assert np.array_equal(r["u0"], zref[:, :144])
     zo, *_ = oracle_batch(model, {k: (None if v is None else v[:3]) for k, v in data.items()}, nw, 1e-2)
     assert max(rel_err(zref[p], zo[p]) for p in range(3)) <= 1e-9
+
+
+def _worker_local(rank, world, port, batch, out_dir):
+    """Rank-LOCAL inputs (bench.py's configs[3] leg): every rank holds only its block; first moves only (z_out = NULL)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("mpc-sensorlessao_amd")
+    from tests.util import handle_from_model
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    model = pkg.synthetic.make_model(27, 144, 30)
+    data = pkg.synthetic.make_replay_batch(model, r=11, steps=batch)
+    h = handle_from_model(pkg, model)
+    sh = pkg.ShardedFastMPC.from_handle(h)
+    lo, hi = sh.block(batch)
+    t = {k: (None if v is None else torch.from_numpy(np.ascontiguousarray(v[lo:hi])).to(dev)) for k, v in data.items()}
+    u0 = sh.solve_gather_local(batch, t["x0"], t["x0_pre"], None, t["nu0"], 1, 1e-2, what="u0")
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), u0=u0.cpu().numpy(), lo=lo, hi=hi)
+    h.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch", [(2, 1), (3, 50)])
+def test_sharded_local_blocks_with_empty_shard(tmp_path, pkg, gpu, world, batch):
+    """More ranks than problems (batch 1 on 2 ranks: rank 1 is empty) and a ragged split (50 over 3: 17, 17, 16): the HIP path of
+    every non-empty rank + the gather == the single-process first moves, bit for bit."""
+    from tests.util import handle_from_model
+    port = _free_port()
+    mp.spawn(_worker_local, args=(world, port, batch, str(tmp_path)), nprocs=world, join=True)
+    model = pkg.synthetic.make_model(27, 144, 30)
+    data = pkg.synthetic.make_replay_batch(model, r=11, steps=batch)
+    h = handle_from_model(pkg, model)
+    zref = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2)
+    h.close()
+    per = -(-batch // world)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert (int(d["lo"]), int(d["hi"])) == (min(r * per, batch), min(r * per + per, batch))
+        assert np.array_equal(d["u0"], zref[:, :144])
