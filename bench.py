@@ -92,10 +92,26 @@ def executed_mfma_flops_tiled(n, m, T):
 
 
 def cpu_cores():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 CPUs
+    in the mask but grants a share of them: round 2's 256 BLAS / OpenMP threads ran on that share)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n_ = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n_ = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n_ = min(n_, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q_ = int(txt[0]); per_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q_ > 0:
+                    n_ = min(n_, max(1, int(q_ / per_ + 0.5)))
+            break
+        except Exception:
+            continue
+    return n_
 
 
 def main():
@@ -663,15 +679,23 @@ def cpu_baselines(pkg, model, data, n_newton):
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-    if threadpool_limits:
-        with threadpool_limits(limits=cores):
-            ts = [dense_once(k_)[0] for k_ in range(3)]
-    else:
-        ts = [dense_once(k_)[0] for k_ in range(3)]
-    out["cpu_baseline"] = {"value": 1.0 / float(np.median(ts)), "unit": "MPC steps/s", "cores": cores, "kind": "port",
-                           "sample": "3 problems of the same workload, one at a time (dense H, P, C, dense P'DP, dense chol, dense Schur as the "
-                                     "reference; %d Newton step), BLAS on %d threads, median %.2f s (min %.2f, max %.2f)"
-                                     % (n_newton, cores, float(np.median(ts)), min(ts), max(ts))}
+    # thread counts: everything the affinity mask / cgroup quota shows, and 16 (the CPU share of a one-GPU box may be smaller
+    # than what the mask shows: more threads than granted cores only add contention); the better one is the baseline
+    cand_thr = sorted({cores, min(cores, 16)})
+    res = {}
+    for thr in cand_thr:
+        if threadpool_limits:
+            with threadpool_limits(limits=thr):
+                res[thr] = [dense_once(k_)[0] for k_ in range(3 if thr == cand_thr[-1] or len(cand_thr) == 1 else 2)]
+        else:
+            res[thr] = [dense_once(k_)[0] for k_ in range(3)]
+    best_thr = min(res, key=lambda t_: float(np.median(res[t_])))
+    ts = res[best_thr]
+    out["cpu_baseline"] = {"value": 1.0 / float(np.median(ts)), "unit": "MPC steps/s", "cores": best_thr, "kind": "port",
+                           "sample": "%d problems of the same workload, one at a time (dense H, P, C, dense P'DP, dense chol, dense Schur as the "
+                                     "reference; %d Newton step), BLAS on %d threads, median %.2f s (min %.2f, max %.2f); thread counts tried: %s"
+                                     % (len(ts), n_newton, best_thr, float(np.median(ts)), min(ts), max(ts),
+                                        ", ".join("%d -> %.2f s" % (t_, float(np.median(v_))) for t_, v_ in sorted(res.items())))}
     if threadpool_limits:
         with threadpool_limits(limits=1):
             t1, _ = dense_once(3)
@@ -688,21 +712,28 @@ def cpu_baselines(pkg, model, data, n_newton):
         while time.perf_counter() - t0 < 1.0:
             banded_cpu.solve_batch(model, d1, n_newton, K_BAR, threads=1, out=o1); r1 += 1
         t1 = (time.perf_counter() - t0) / (32 * r1)
-        # all cores: 32 problems PER THREAD in one call (OpenMP over the batch, per-thread workspace, outputs first touched by
-        # the warm-up call and then reused), repeated until 2 s have passed; round 2 measured one problem per thread per call,
-        # i.e. mostly the start of 256 threads and the first touch of the outputs
-        nthr = cores
-        dn = take(32 * nthr)
-        on = banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr)
-        t0 = time.perf_counter(); rn = 0
-        while time.perf_counter() - t0 < 2.0:
-            banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr, out=on); rn += 1
-        tn = (time.perf_counter() - t0) / (32 * nthr * rn)
+        # many threads: 32 problems PER THREAD in one call (OpenMP over the batch, per-thread workspace, outputs first touched by
+        # the warm-up call and then reused), repeated until 1 s has passed, for several thread counts up to what the affinity
+        # mask shows; the best is reported with ITS thread count.  (Round 2 measured one problem per thread per call on 256
+        # threads, i.e. mostly thread start-up and first touch; and a one-GPU box grants fewer cores than its mask shows.)
+        best = None; tried = []
+        for nthr in sorted({t_ for t_ in (8, 16, 32, 64, cores) if t_ <= cores}):
+            dn = take(32 * nthr)
+            on = banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr)
+            t0 = time.perf_counter(); rn = 0
+            while time.perf_counter() - t0 < 1.0:
+                banded_cpu.solve_batch(model, dn, n_newton, K_BAR, threads=nthr, out=on); rn += 1
+            tn = (time.perf_counter() - t0) / (32 * nthr * rn)
+            tried.append((nthr, 1.0 / tn))
+            if best is None or tn < best[1]:
+                best = (nthr, tn, rn)
+        nthr, tn, rn = best
         out["cpu_baseline_structured"] = {"value": 1.0 / tn, "unit": "MPC steps/s", "cores": nthr, "kind": "port",
                                           "one_thread_value": 1.0 / t1, "speedup_over_one_thread": t1 / tn,
                                           "sample": "oracle/banded_cpu.c (block-penta-diagonal Newton step, the GPU's algorithm; OpenMP over the "
-                                                    "batch): %d problems per call (32 per thread) x %d calls on %d threads in %.1f s; 32 problems x %d calls "
-                                                    "on 1 thread" % (32 * nthr, rn, nthr, tn * 32 * nthr * rn, r1)}
+                                                    "batch): %d problems per call (32 per thread) x %d calls on %d threads; 32 problems x %d calls on 1 "
+                                                    "thread; steps/s by thread count: %s (the speed-up stops where the box's CPU share ends)"
+                                                    % (32 * nthr, rn, nthr, r1, ", ".join("%d: %.0f" % t_ for t_ in tried))}
     except Exception as e:     # the baseline library is optional
         out["cpu_baseline_structured"] = {"error": repr(e)}
     return out

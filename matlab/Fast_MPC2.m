@@ -39,6 +39,55 @@ classdef Fast_MPC2
             for i = 1:numel(ks), z = obj.solve_once(z, 0, ks(i)); end
             x_opt = z;
         end
+        % ---- dense builders of the reference class (VAR_2/Fast_MPC2.m:56-67).  The device path never forms H, P, C;
+        % these are host-side MATLAB, written from the index maps of the solver (z = [u0;x1;u1;x2;...;u_{T-1};x_T]) and
+        % kept so that callers of objective_function / inequality_const / equality_const / fomulate_mpc keep working.
+        % Python twin (tested against the dense restatement): mpc-sensorlessao_amd/fast_mpc2.py.
+        function [H,g] = objective_function(obj)                 % cost z'Hz + g'z (no 1/2): fast_mpc_objective.m:50-65
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            H = zeros(T*s); g = zeros(T*s,1);
+            qv = obj.q; if isempty(qv), qv = zeros(n,1); end
+            rv = obj.r; if isempty(rv), rv = zeros(m,1); end
+            qfv = obj.qf; if isempty(qfv), qfv = zeros(n,1); end
+            for j = 0:T-1
+                iu = j*s + (1:m); ix = j*s + m + (1:n);
+                H(iu,iu) = obj.R; g(iu) = rv;
+                if j == T-1, H(ix,ix) = obj.Qf; g(ix) = qfv; else, H(ix,ix) = obj.Q; g(ix) = qv; end
+            end
+        end
+        function [P,h] = inequality_const(obj)                   % P z <= h: fast_mpc_ineq_const.m:46-56
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            P = zeros(2*T*m, T*s); h = zeros(2*T*m,1);
+            for j = 0:T-1
+                iu = j*s + (1:m); r1 = 2*j*m + (1:m); r2 = (2*j+1)*m + (1:m);
+                P(r1,iu) = eye(m); P(r2,iu) = -eye(m);
+                h(r1) = obj.u_max; h(r2) = -obj.u_min;
+            end
+        end
+        function [C,b] = equality_const(obj)                     % C z = b: fast_mpc_eq_const.m:38-49, terminal rows :67-71
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            wv = obj.w; if isempty(wv), wv = zeros(T*n,1); end
+            nb = T + ~isempty(obj.x_final);
+            C = zeros(nb*n, T*s); b = zeros(nb*n,1);
+            for i = 0:T-1
+                rows = i*n + (1:n);
+                C(rows, i*s + (1:m)) = -obj.B;
+                C(rows, i*s + m + (1:n)) = eye(n);
+                if i >= 1, C(rows, (i-1)*s + m + (1:n)) = -obj.A1; end
+                if i >= 2, C(rows, (i-2)*s + m + (1:n)) = -obj.A2; end
+                b(rows) = wv(i*n + (1:n));
+            end
+            b(1:n) = b(1:n) + obj.A1*obj.x0 + obj.A2*obj.x0_pre;          % the prediction A1 x[k-1] + A2 x[k-2]
+            if T > 1, b(n+(1:n)) = b(n+(1:n)) + obj.A2*obj.x0; end
+            if ~isempty(obj.x_final)
+                C(T*n + (1:n), (T-1)*s + m + (1:n)) = eye(n); b(T*n + (1:n)) = obj.x_final;
+            end
+        end
+        function [J,A_eq,b_eq] = fomulate_mpc(obj,k)             % VAR_2/Fast_MPC2.m:68-75 (name as in the reference)
+            [P,h] = obj.inequality_const(); [H,g] = obj.objective_function();
+            J = @(z)(z'*H*z + g'*z + k*(-sum(log(h - P*z))));
+            [A_eq,b_eq] = obj.equality_const();
+        end
         function z_init = initialize(obj)                        % fast_mpc_init.m:12-27
             n = size(obj.Q,1); m = size(obj.R,1);
             if ~isempty(obj.x_init), z_init = obj.x_init; return; end

@@ -38,6 +38,64 @@ classdef Fast_MPC2
             for i = 1:numel(ks), z = obj.solve_once(z, 0, ks(i)); end
             x_opt = z;
         end
+        % ---- dense builders of the reference class (VAR_1/Fast_MPC2.m:52-63).  The device path never forms H, P, C;
+        % these are host-side MATLAB, written from the index maps of the solver (z = [u0;x1;u1;x2;...;u_{T-1};x_T]) and
+        % kept so that callers of objective_function / inequality_const / equality_const / fomulate_mpc keep working.
+        % Python twin (tested against the dense restatement): mpc-sensorlessao_amd/fast_mpc2.py.
+        function [H,g] = objective_function(obj)                 % cost z'Hz + g'z (no 1/2): fast_mpc_objective.m:50-65
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            H = zeros(T*s); g = zeros(T*s,1);
+            qv = obj.q; if isempty(qv), qv = zeros(n,1); end
+            rv = obj.r; if isempty(rv), rv = zeros(m,1); end
+            qfv = obj.qf; if isempty(qfv), qfv = zeros(n,1); end
+            for j = 0:T-1
+                iu = j*s + (1:m); ix = j*s + m + (1:n);
+                H(iu,iu) = obj.R; g(iu) = rv;
+                if j == T-1, H(ix,ix) = obj.Qf; g(ix) = qfv; else, H(ix,ix) = obj.Q; g(ix) = qv; end
+            end
+        end
+        function [P,h] = inequality_const(obj)                   % box rows, then ramp rows: VAR_1/fast_mpc_ineq_const.m:42-79
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            P = zeros(2*T*m, T*s); h = zeros(2*T*m,1);
+            for j = 0:T-1
+                iu = j*s + (1:m); r1 = 2*j*m + (1:m); r2 = (2*j+1)*m + (1:m);
+                P(r1,iu) = eye(m); P(r2,iu) = -eye(m);
+                h(r1) = obj.u_max; h(r2) = -obj.u_min;
+            end
+            if isempty(obj.du_min) || isempty(obj.du_max) || isempty(obj.u_prev), return; end   % box rows only
+            Pr = zeros(2*T*m, T*s); hr = zeros(2*T*m,1);         % du_min <= u_j - u_{j-1} <= du_max, u_{-1} = u_prev
+            for j = 0:T-1
+                iu = j*s + (1:m); r1 = 2*j*m + (1:m); r2 = (2*j+1)*m + (1:m);
+                Pr(r1,iu) = eye(m); Pr(r2,iu) = -eye(m);
+                up = zeros(m,1);
+                if j >= 1, ip = (j-1)*s + (1:m); Pr(r1,ip) = -eye(m); Pr(r2,ip) = eye(m); else, up = obj.u_prev; end
+                hr(r1) = up + obj.du_max; hr(r2) = -up - obj.du_min;
+            end
+            P = [P; Pr]; h = [h; hr];
+        end
+        function [C,b] = equality_const(obj)                     % C z = b: VAR_1/fast_mpc_eq_const.m:32-55
+            n = size(obj.Q,1); m = size(obj.R,1); s = n + m; T = obj.T;
+            wv = obj.w; if isempty(wv), wv = zeros(T*n,1); end
+            nb = T + ~isempty(obj.x_final);
+            C = zeros(nb*n, T*s); b = zeros(nb*n,1);
+            for i = 0:T-1
+                rows = i*n + (1:n);
+                C(rows, i*s + (1:m)) = -obj.B;
+                C(rows, i*s + m + (1:n)) = eye(n);
+                if i >= 1, C(rows, (i-1)*s + m + (1:n)) = -obj.A; end     % intended VAR(1) dynamics (the reference writes this
+                                                                            % block at column n instead of m+1 for i = 1: VAR_1/fast_mpc_eq_const.m:36)
+                b(rows) = wv(i*n + (1:n));
+            end
+            b(1:n) = b(1:n) + obj.A*obj.x0;                               % the prediction A x[k-1]
+            if ~isempty(obj.x_final)
+                C(T*n + (1:n), (T-1)*s + m + (1:n)) = eye(n); b(T*n + (1:n)) = obj.x_final;
+            end
+        end
+        function [J,A_eq,b_eq] = fomulate_mpc(obj,k)             % VAR_1/Fast_MPC2.m:64-71 (name as in the reference)
+            [P,h] = obj.inequality_const(); [H,g] = obj.objective_function();
+            J = @(z)(z'*H*z + g'*z + k*(-sum(log(h - P*z))));
+            [A_eq,b_eq] = obj.equality_const();
+        end
         function z_init = initialize(obj)                        % fast_mpc_init.m:12-27
             n = size(obj.Q,1); m = size(obj.R,1);
             if ~isempty(obj.x_init), z_init = obj.x_init; return; end

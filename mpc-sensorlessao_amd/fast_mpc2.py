@@ -237,6 +237,65 @@ class Fast_MPC2:
         self.last_info = infos
         return x_opt
 
+    # ---------------------------------------------------------------- dense builders of the class (host side)
+    # The device never forms H, P, C; these exist because they are public methods of the reference class
+    # (VAR_2/Fast_MPC2.m:56-67) that a caller may use for its own purposes (e.g. `fomulate_mpc`).  Written from the
+    # index maps of SURVEY App. A.1-A.3, checked against oracle/dense_ref.py in tests/test_host_api.py.
+    def objective_function(self):
+        """[H, g]: cost z'Hz + g'z (no 1/2), H = blkdiag(R, [Q 0; 0 R] x (T-1), Qf)   (fast_mpc_objective.m:50-65)."""
+        n, m, T = self._check()
+        s = n + m
+        H = np.zeros((T * s, T * s)); g = np.zeros(T * s)
+        zr = lambda v, k: np.zeros(k) if v is None else v
+        for j in range(T):
+            H[j * s:j * s + m, j * s:j * s + m] = self.R
+            H[j * s + m:(j + 1) * s, j * s + m:(j + 1) * s] = self.Qf if j == T - 1 else self.Q
+            g[j * s:j * s + m] = zr(self.r, m)
+            g[j * s + m:(j + 1) * s] = zr(self.qf, n) if j == T - 1 else zr(self.q, n)
+        return H, g
+
+    def inequality_const(self):
+        """[P, h]: P z <= h, per stage u_j <= u_max, -u_j <= -u_min (fast_mpc_ineq_const.m:46-56); the VAR_1 class appends
+        the ramp rows (VAR_1/fast_mpc_ineq_const.m:58-76)."""
+        n, m, T = self._check()
+        s = n + m
+        P = np.zeros((2 * T * m, T * s)); h = np.zeros(2 * T * m)
+        for j in range(T):
+            P[2 * j * m:(2 * j + 1) * m, j * s:j * s + m] = np.eye(m)
+            P[(2 * j + 1) * m:(2 * j + 2) * m, j * s:j * s + m] = -np.eye(m)
+            h[2 * j * m:(2 * j + 1) * m] = self.u_max
+            h[(2 * j + 1) * m:(2 * j + 2) * m] = -self.u_min
+        return P, h
+
+    def equality_const(self):
+        """[C, b]: row block i (0-based) x_{i+1} - B u_i - [i>=1] A1 x_i - [i>=2] A2 x_{i-1} = b_i with the prediction in
+        b_0 = A1 x0 + A2 x0_pre + w_0, b_1 = A2 x0 + w_1 (fast_mpc_eq_const.m:38-49); terminal rows x_T = xf (:67-71).
+        The VAR_1 class has A2 = 0 (intended dynamics)."""
+        n, m, T = self._check()
+        s = n + m
+        A1 = self.A1
+        A2 = self.A2 if (self.var_order == 2 and self.A2 is not None) else np.zeros((n, n))
+        x0p = self.x0_pre if (self.var_order == 2 and self.x0_pre is not None) else np.zeros(n)
+        w = np.zeros(T * n) if self.w is None else self.w
+        nb = T + (1 if self.x_final is not None else 0)
+        C = np.zeros((nb * n, T * s)); b = np.zeros(nb * n)
+        for i in range(T):
+            rows = slice(i * n, (i + 1) * n)
+            C[rows, i * s:i * s + m] = -self.B
+            C[rows, i * s + m:(i + 1) * s] = np.eye(n)
+            if i >= 1:
+                C[rows, (i - 1) * s + m:i * s] = -A1
+            if i >= 2:
+                C[rows, (i - 2) * s + m:(i - 1) * s] = -A2
+            b[rows] = w[i * n:(i + 1) * n]
+        b[:n] += A1 @ self.x0 + A2 @ x0p
+        if T > 1:
+            b[n:2 * n] += A2 @ self.x0
+        if self.x_final is not None:
+            C[T * n:, (T - 1) * s + m:] = np.eye(n)
+            b[T * n:] = self.x_final
+        return C, b
+
     def matlab_solve(self):
         raise NotImplementedError("fmincon path (Fast_MPC2.m:76-87) is outside the fastMPC hot path")
 
@@ -276,6 +335,26 @@ class Fast_MPC2_VAR1(Fast_MPC2):
         if self.ramp:
             h.set_ramp(self.du_min, self.du_max)     # (bounds live in the cached handle; set per call, m doubles)
         return h
+
+    def inequality_const(self):
+        """Box rows as VAR_2, then per stage +-(u_j - u_{j-1}) <= +-du with u_{-1} = u_prev (VAR_1/fast_mpc_ineq_const.m:58-76)
+        when the ramp rows are on."""
+        P, h = super().inequality_const()
+        if not getattr(self, "ramp", True) or self.du_min is None or self.du_max is None or self.u_prev is None:
+            return P, h
+        n, m, T = self._check()
+        s = n + m
+        Pr = np.zeros((2 * T * m, T * s)); hr = np.zeros(2 * T * m)
+        for j in range(T):
+            Pr[2 * j * m:(2 * j + 1) * m, j * s:j * s + m] = np.eye(m)
+            Pr[(2 * j + 1) * m:(2 * j + 2) * m, j * s:j * s + m] = -np.eye(m)
+            if j >= 1:
+                Pr[2 * j * m:(2 * j + 1) * m, (j - 1) * s:(j - 1) * s + m] = -np.eye(m)
+                Pr[(2 * j + 1) * m:(2 * j + 2) * m, (j - 1) * s:(j - 1) * s + m] = np.eye(m)
+            up = self.u_prev if j == 0 else np.zeros(m)
+            hr[2 * j * m:(2 * j + 1) * m] = up + self.du_max
+            hr[(2 * j + 1) * m:(2 * j + 2) * m] = -up - self.du_min
+        return np.vstack([P, Pr]), np.concatenate([h, hr])
 
     def _u_prev_for_solve(self):
         return self.u_prev if self.ramp else None

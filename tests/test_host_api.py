@@ -159,3 +159,33 @@ def test_plain_c_client_builds_against_the_header_and_library(pkg, tmp_path):
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_client.c"),
                     "-o", exe, "-L" + lib_dir, "-lfastmpc", "-Wl,-rpath," + lib_dir, "-lm"], check=True)
     assert os.path.exists(exe)
+
+
+@pytest.mark.parametrize("var_order,xf,lin", [(2, False, False), (2, True, True), (1, False, True), (1, True, False)])
+def test_dense_builder_methods_of_the_class(pkg, var_order, xf, lin):
+    """objective_function / inequality_const / equality_const of the drop-in class (VAR_2/Fast_MPC2.m:56-67; host-side
+    numpy, the device never forms H, P, C) against the op-for-op restatement in oracle/dense_ref.py, VAR_2 and VAR_1
+    (ramp rows on), with and without terminal rows and linear costs."""
+    from oracle.dense_ref import DenseFastMPC
+    rng = np.random.default_rng(7)
+    n, m, T = 4, 3, 5
+    A1 = rng.standard_normal((n, n)); A2 = rng.standard_normal((n, n)); B = rng.standard_normal((n, m))
+    Q = np.diag(rng.random(n) + 1); R = np.diag(rng.random(m) + 1); Qf = np.diag(rng.random(n) + 2)
+    q = rng.standard_normal(n) if lin else None; r = rng.standard_normal(m) if lin else None; qf = rng.standard_normal(n) if lin else None
+    xmin, xmax, umin, umax = -np.ones(n), 2 * np.ones(n), -0.5 * np.ones(m), 0.7 * np.ones(m)
+    dumin, dumax, uprev = -0.1 * np.ones(m), 0.2 * np.ones(m), 0.05 * rng.standard_normal(m)
+    x0, x0p, w = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(T * n)
+    xfv = rng.standard_normal(n) if xf else None
+    if var_order == 2:
+        mine = pkg.Fast_MPC2(Q, R, None, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, x0p, uprev, A1, A2, B, w, xfv, None)
+        ref = DenseFastMPC(Q, R, None, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, x0p, uprev, A1, A2, B, w, xfv, None)
+    else:
+        mine = pkg.Fast_MPC2_VAR1(Q, R, None, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, uprev, A1, B, w, xfv, None)
+        ref = DenseFastMPC.var1(Q, R, None, Qf, q, r, qf, xmin, xmax, umin, umax, dumin, dumax, T, x0, uprev, A1, B, w, xfv, None)
+    for name in ("objective_function", "inequality_const", "equality_const"):
+        Mm, vm = getattr(mine, name)()
+        Mr, vr = getattr(ref, name)()
+        assert Mm.shape == np.asarray(Mr).shape, name
+        assert np.array_equal(Mm, np.asarray(Mr)), name
+        assert np.array_equal(vm, np.asarray(vr).reshape(-1)), name
+    assert np.array_equal(mine.initialize(), np.asarray(ref.initialize()).reshape(-1))
