@@ -12,6 +12,7 @@
 #include "../../include/fastmpc.h"
 #include "fmpc_device.h"
 #include "fmpc_panel.h"
+#include "fmpc_host.h"
 #include "fmpc_tiled.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
@@ -217,24 +218,6 @@ bool spd_inverse(const std::vector<double>& A, int n, std::vector<double>& inv) 
     return true;
 }
 
-// out (row-major n x n) += sign * A X B'   with A, B, X row-major n x n (X dense)
-void add_AXBt(std::vector<double>& out, const std::vector<double>& A, const std::vector<double>& X,
-              const std::vector<double>& B, int n, double sign) {
-    std::vector<double> AX((size_t)n * n, 0.0);
-    for (int a = 0; a < n; ++a)
-        for (int c = 0; c < n; ++c) {
-            double t = 0.0;
-            for (int k = 0; k < n; ++k) t += A[a * n + k] * X[k * n + c];
-            AX[a * n + c] = t;
-        }
-    for (int a = 0; a < n; ++a)
-        for (int b = 0; b < n; ++b) {
-            double t = 0.0;
-            for (int c = 0; c < n; ++c) t += AX[a * n + c] * B[b * n + c];
-            out[a * n + b] += sign * t;
-        }
-}
-
 }  // namespace
 
 extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
@@ -347,37 +330,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     //   Y2_i = -X_{i+1} A2'                          (rows i, i+2 < T)
     //   xf:   Yd_T = Xf, Y1_{T-1} = Xf
     std::vector<std::vector<double>> blocks;
-    std::vector<int> idxD(h->nb, -1), idx1(h->nb, -1), idx2(h->nb, -1);
-    auto intern = [&](const std::vector<double>& blk) {
-        for (size_t k = 0; k < blocks.size(); ++k)
-            if (memcmp(blocks[k].data(), blk.data(), nn * sizeof(double)) == 0) return (int)k;
-        blocks.push_back(blk);
-        return (int)blocks.size() - 1;
-    };
-    auto Xj = [&](int j) -> const std::vector<double>& { return j == T ? Xf : X; };
-    for (int i = 0; i < T; ++i) {
-        std::vector<double> d = Xj(i + 1);
-        if (i >= 1) add_AXBt(d, a1, Xj(i), a1, n, 1.0);
-        if (i >= 2 && var2) add_AXBt(d, a2, Xj(i - 1), a2, n, 1.0);
-        idxD[i] = intern(d);
-        std::vector<double> eye(nn, 0.0);
-        for (int a = 0; a < n; ++a) eye[a * n + a] = 1.0;
-        if (i + 1 < T) {
-            std::vector<double> o(nn, 0.0);
-            add_AXBt(o, eye, Xj(i + 1), a1, n, -1.0);              // -X_{i+1} A1'
-            if (i >= 1 && var2) add_AXBt(o, a1, Xj(i), a2, n, 1.0);
-            idx1[i] = intern(o);
-        }
-        if (i + 2 < T && var2) {
-            std::vector<double> o(nn, 0.0);
-            add_AXBt(o, eye, Xj(i + 1), a2, n, -1.0);              // -X_{i+1} A2'
-            idx2[i] = intern(o);
-        }
-    }
-    if (xf) {
-        idxD[T] = intern(Xf);
-        idx1[T - 1] = idxD[T];
-    }
+    std::vector<int> idxD, idx1, idx2;
+    fmpc_host_y_blocks(n, T, var2, xf != nullptr, a1, a2, X, Xf, blocks, idxD, idx1, idx2);      // (fmpc_host.cpp)
     // ---- pack the pool
     std::vector<double> pool;
     auto push = [&](const double* p, size_t cnt) {
@@ -526,19 +480,12 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
             const int pmp = (m + 15) & ~15;
             const size_t plds = fmpc_panel_lds_bytes(h->nb, pmp);
             if (n == FP_N && !(nopn && nopn[0] == '1') && plds <= FMPC_LDS_LIMIT) {
-                const FpVec V = fp_vec_layout(h->nb, T);
+                FmpcPanelIn PL;                                     // pool layout: fmpc_host_panel_layout (fmpc_host.cpp)
                 size_t o = 0;
-                h->pn_o_simg = o; o += (size_t)h->nb * FP_IMG + 3 * FP_IMG;          // Linv per stage, then the prediction images
-                h->pn_limg_cap = 9 * h->nb + 2;                                        // Linv' per stage, a zero image, the edges
-                h->pn_o_limg = o; o += (size_t)h->pn_limg_cap * FP_IMGL;
-                h->pn_o_bt = o;   o += (size_t)(pmp / 16) * FP_KS * 64;
-                h->pn_o_aimg = o; o += 5 * FP_IMG;
-                h->pn_o_vec = o;  o += V.total;
-                h->pn_o_ucon = o; o += 4 * (size_t)pmp;
-                h->pn_dz_len = fd_lds_layout(pmp).total_next;
-                h->pn_o_dz = o;   o += (size_t)h->pn_dz_len;
-                h->pn_doubles = o;
-                h->pn_o_dump = o; o += (size_t)T * (n + m) + (size_t)h->nb * n;
+                fmpc_host_panel_layout(n, m, T, h->nb, pmp, PL, &h->pn_o_dump, &o, &h->pn_dz_len);
+                h->pn_o_simg = PL.o_simg; h->pn_limg_cap = PL.limg_cap; h->pn_o_limg = PL.o_limg; h->pn_o_bt = PL.o_bt;
+                h->pn_o_aimg = PL.o_aimg; h->pn_o_vec = PL.o_vec; h->pn_o_ucon = PL.o_ucon; h->pn_o_dz = PL.o_dz;
+                h->pn_doubles = PL.pool_doubles;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_sched, (size_t)2 * FP_MAX_STEPS(h->nb) * FP_STEP_INTS * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
@@ -682,323 +629,26 @@ static int fmpc_upload_cold(fmpc_handle h, double k, hipStream_t stream) {
                ? FMPC_OK : FMPC_E_HIP;
 }
 
-// Constants of the panel kernel for barrier weight k (fmpc_panel.h).  Reads back the shared factor the
-// export launch just produced, inverts the diagonal blocks and forms the products W = Linv U', V = Linv' U
-// in extended precision on the host (30 stages x 27^3: microseconds), and packs every matrix as an MFMA
-// A-operand image.  Called once per (handle, k); synchronises the stream.
+// Constants of the panel kernel for barrier weight k: built on the host (fmpc_host_build_panel in fmpc_host.cpp: twisted block
+// factorisation of Y in long double, operator images, sweep schedules) and uploaded.  Called once per (handle, k).
 static int fmpc_upload_panel(fmpc_handle h, double k, hipStream_t stream) {
-    typedef long double ld;
-    const int n = h->n, m = h->m, T = h->T, nb = h->nb, mp = h->pn_mp;
-    const int nn = n * n;
-    h->pn_valid = 0;
     (void)stream;
-    std::vector<double> pool(h->pn_doubles, 0.0);
-    auto image = [&](const std::vector<ld>& M, double sign, double* out) {      // standard A-operand image of M (n x n row-major)
-        for (int I = 0; I < 2; ++I)
-            for (int ks = 0; ks < FP_KS; ++ks)
-                for (int l = 0; l < 64; ++l) {
-                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
-                    out[(I * FP_KS + ks) * 64 + l] = (r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
-                }
-    };
-    auto limage = [&](const std::vector<ld>& M, double sign, double* out) {     // the same, lane-major (FP_IMGL doubles)
-        for (int I = 0; I < 2; ++I)
-            for (int l = 0; l < 64; ++l)
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int r = 16 * I + (l & 15), c = 4 * ks + (l >> 4);
-                    out[(I * 64 + l) * 8 + ks] = (ks < FP_KS && r < n && c < n) ? (double)(sign * M[r * n + c]) : 0.0;
-                }
-    };
-    // ---- u constants (needed for G = B diag(wc) B')
-    double* uc = pool.data() + h->pn_o_ucon;
-    double sa_cu = 0.0;
-    for (int j = 0; j < m; ++j) {
-        const double sp = h->hm_umax[j] - h->hm_umid[j], sm = h->hm_umid[j] - h->hm_umin[j];
-        const double dp = 1.0 / sp, dm = 1.0 / sm;
-        const double hc = k * (dp * dp + dm * dm);
-        const double cu = h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] + k * (dp - dm);
-        uc[j] = cu; uc[mp + j] = 1.0 / (h->hm_R2[j] + hc); uc[2 * mp + j] = hc; uc[3 * mp + j] = h->hm_umid[j];
-        sa_cu += cu * cu;
-    }
-    const double* bt = h->hm_bt.data();                           // bt[c*n + r] = B[r][c]
-    // ---- Y = C Phi^-1 C' at the cold start, block by block: Y_ii = const + G (i < T), Y_{i,i+1}, Y_{i,i+2}
-    std::vector<ld> G(nn, 0.0L);
-    for (int a = 0; a < n; ++a)
-        for (int b = 0; b < n; ++b) {
-            ld t = 0.0L;
-            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + a] * (ld)uc[mp + j] * (ld)bt[(size_t)j * n + b];
-            G[a * n + b] = t;
-        }
-    // Elimination order ("twisted" factorisation): the stages 0 .. hs-1 top-down, then nb-1 .. hs+2 bottom-up, then
-    // hs, hs+1.  The two chains are independent until the middle, which halves the serial length of both sweeps.
-    const int hs = nb >= 8 ? nb / 2 - 1 : nb;
-    std::vector<int> perm, rank(nb);
-    for (int i = 0; i < (hs < nb ? hs : nb); ++i) perm.push_back(i);
-    if (hs < nb) { for (int i = nb - 1; i >= hs + 2; --i) perm.push_back(i); perm.push_back(hs); perm.push_back(hs + 1); }
-    for (int a = 0; a < nb; ++a) rank[perm[a]] = a;
-    // P[a][b] (a <= b in elimination rank): the block Y[perm[a]][perm[b]]
-    std::vector<std::vector<std::vector<ld>>> Pm(nb, std::vector<std::vector<ld>>(nb));
-    auto yblock = [&](int i, int j, std::vector<ld>& out) -> bool {     // Y_ij (|i-j| <= 2), false if structurally zero
-        out.assign(nn, 0.0L);
-        const int lo = i < j ? i : j, d = i < j ? j - i : i - j;
-        int id = -1;
-        if (d == 0) id = h->hm_idxD[lo]; else if (d == 1) id = h->hm_idx1[lo]; else if (d == 2) id = h->hm_idx2[lo];
-        if (d > 2 || id < 0) return false;
-        const double* src = h->hm_blocks.data() + (size_t)id * nn;
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) out[r * n + c] = i <= j ? (ld)src[r * n + c] : (ld)src[c * n + r];
-        if (d == 0 && i < T) for (int q = 0; q < nn; ++q) out[q] += G[q];
-        return true;
-    };
-    for (int a = 0; a < nb; ++a)
-        for (int b = a; b < nb; ++b) {
-            std::vector<ld> blk;
-            if (yblock(perm[a], perm[b], blk)) Pm[a][b] = blk;
-        }
-    std::vector<std::vector<ld>> Linv(nb, std::vector<ld>(nn, 0.0L));        // by rank
-    std::vector<std::vector<std::vector<ld>>> Um(nb, std::vector<std::vector<ld>>(nb));   // U[a][b] = L_a^-1 P[a][b], b > a
-    for (int a = 0; a < nb; ++a) {
-        // L = chol(P[a][a]) (lower), X = L^-1
-        std::vector<ld> Lm(nn, 0.0L);
-        const std::vector<ld>& S = Pm[a][a];
-        for (int c = 0; c < n; ++c) {
-            ld d = S[c * n + c];
-            for (int q = 0; q < c; ++q) d -= Lm[c * n + q] * Lm[c * n + q];
-            if (!(d > 0.0L)) return FMPC_OK;                          // not PD at the start point: the exact path reports it
-            const ld ldiag = sqrtl(d);
-            Lm[c * n + c] = ldiag;
-            for (int r = c + 1; r < n; ++r) {
-                ld t = S[r * n + c];
-                for (int q = 0; q < c; ++q) t -= Lm[r * n + q] * Lm[c * n + q];
-                Lm[r * n + c] = t / ldiag;
-            }
-        }
-        std::vector<ld>& X = Linv[a];
-        for (int c = 0; c < n; ++c) {
-            X[c * n + c] = 1.0L / Lm[c * n + c];
-            for (int r = c + 1; r < n; ++r) {
-                ld sacc = 0.0L;
-                for (int q = c; q < r; ++q) sacc += Lm[r * n + q] * X[q * n + c];
-                X[r * n + c] = -sacc / Lm[r * n + r];
-            }
-        }
-        for (int b = a + 1; b < nb; ++b) {
-            if (Pm[a][b].empty()) continue;
-            std::vector<ld> u(nn);
-            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                ld t = 0.0L;
-                for (int q = 0; q <= r; ++q) t += X[r * n + q] * Pm[a][b][q * n + c];
-                u[r * n + c] = t;
-            }
-            Um[a][b] = u;
-        }
-        for (int b1 = a + 1; b1 < nb; ++b1) {
-            if (Um[a][b1].empty()) continue;
-            for (int b2 = b1; b2 < nb; ++b2) {
-                if (Um[a][b2].empty()) continue;
-                if (Pm[b1][b2].empty()) Pm[b1][b2].assign(nn, 0.0L);
-                std::vector<ld>& dst = Pm[b1][b2];
-                const std::vector<ld>& u1 = Um[a][b1]; const std::vector<ld>& u2 = Um[a][b2];
-                for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                    ld t = 0.0L;
-                    for (int q = 0; q < n; ++q) t += u1[q * n + r] * u2[q * n + c];
-                    dst[r * n + c] -= t;
-                }
-            }
-        }
-    }
-    // ---- images: Linv (standard, by stage), Linv' (lane-major id = stage), a zero image (id nb), one per edge
-    std::vector<ld> M(nn);
-    double* limg = pool.data() + h->pn_o_limg;
-    for (int i = 0; i < nb; ++i) {
-        const std::vector<ld>& X = Linv[rank[i]];
-        image(X, 1.0, pool.data() + h->pn_o_simg + (size_t)i * FP_IMG);
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = X[c * n + r];
-        limage(M, 1.0, limg + (size_t)i * FP_IMGL);
-    }
-    int nimg = nb + 1;                                            // id nb stays all zero
-    struct Edge { int tgt, src, img; };
-    std::vector<Edge> ef, eb;                                     // forward: y_tgt += img y_src ; backward: nu_tgt += img nu_src
-    for (int a = 0; a < nb; ++a)
-        for (int b = a + 1; b < nb; ++b) {
-            if (Um[a][b].empty()) continue;
-            if (nimg + 2 > h->pn_limg_cap) return FMPC_OK;        // cannot happen for the penta-diagonal structure
-            const std::vector<ld>& u = Um[a][b];
-            // forward: -Linv_b U_ab'          (target rank b, source rank a)
-            const std::vector<ld>& Xb = Linv[b];
-            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                ld t = 0.0L;
-                for (int q = 0; q <= r; ++q) t += Xb[r * n + q] * u[c * n + q];
-                M[r * n + c] = t;
-            }
-            limage(M, -1.0, limg + (size_t)nimg * FP_IMGL);
-            ef.push_back({perm[b], perm[a], nimg++});
-            // backward: -Linv_a' U_ab         (target rank a, source rank b)
-            const std::vector<ld>& Xa = Linv[a];
-            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                ld t = 0.0L;
-                for (int q = r; q < n; ++q) t += Xa[q * n + r] * u[q * n + c];
-                M[r * n + c] = t;
-            }
-            limage(M, -1.0, limg + (size_t)nimg * FP_IMGL);
-            eb.push_back({perm[a], perm[b], nimg++});
-        }
-    // ---- schedules: list scheduling of the edges, <= 4 targets per step (one wave pair each), one edge per target and step
-    std::vector<int> sched((size_t)2 * FP_MAX_STEPS(nb) * FP_STEP_INTS, -1);
-    auto schedule = [&](const std::vector<Edge>& E, int* out) -> int {
-        const int ne = (int)E.size();
-        std::vector<int> done_step(nb, -1), pending(nb, 0), estep(ne, -1);
-        for (const Edge& e : E) pending[e.tgt]++;
-        for (int i = 0; i < nb; ++i) if (pending[i] == 0) done_step[i] = 0;       // final before the sweep starts
-        int left = ne, step = 0;
-        while (left > 0) {
-            ++step;
-            if (step > FP_MAX_STEPS(nb)) return -1;
-            int groups = 0; int gt[4];
-            int* row = out + (size_t)(step - 1) * FP_STEP_INTS;
-            std::vector<int> newly;
-            for (int e = 0; e < ne && true; ++e) {
-                if (estep[e] >= 0) continue;
-                const int sd = done_step[E[e].src];
-                if (sd < 0 || sd >= step) continue;                   // source not final before this step
-                bool taken = false;                                   // one edge per target and step
-                for (int q = 0; q < groups; ++q) if (gt[q] == E[e].tgt) taken = true;
-                if (taken || groups == 4) continue;
-                const int gi = groups; gt[groups++] = E[e].tgt;
-                for (int I = 0; I < 2; ++I) {
-                    int* ent = row + (2 * gi + I) * 3;
-                    ent[0] = E[e].tgt; ent[1] = E[e].src; ent[2] = E[e].img;
-                }
-                estep[e] = step; --left;
-                if (--pending[E[e].tgt] == 0) newly.push_back(E[e].tgt);
-            }
-            for (int t : newly) done_step[t] = step;
-        }
-        return step;
-    };
-    h->pn_nsf = schedule(ef, sched.data());
-    h->pn_nsb = schedule(eb, sched.data() + (size_t)FP_MAX_STEPS(nb) * FP_STEP_INTS);
-    if (h->pn_nsf < 0 || h->pn_nsb < 0) return FMPC_OK;
-    if (getenv("FMPC_PANEL_VERBOSE")) fprintf(stderr, "fastmpc panel: nb %d, split %d, %d images, %d forward / %d backward edges, %d / %d steps\n", nb, hs, nimg, (int)ef.size(), (int)eb.size(), h->pn_nsf, h->pn_nsb);
-    if (hipMemcpy(h->pn_sched, sched.data(), sched.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
-    // ---- the prediction terms of stages 0 and 1 folded into product images: -Linv_0 A1, -Linv_0 A2, -Linv_1 A2
-    {
-        double* dst = pool.data() + h->pn_o_simg + (size_t)nb * FP_IMG;
-        auto prod = [&](const std::vector<ld>& X, const std::vector<double>& A) {
-            for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-                ld a = 0.0L;
-                for (int q = 0; q <= r; ++q) a += X[r * n + q] * (ld)A[q * n + c];
-                M[r * n + c] = a;
-            }
-        };
-        prod(Linv[rank[0]], h->hm_a1); image(M, -1.0, dst);
-        prod(Linv[rank[0]], h->hm_a2); image(M, -1.0, dst + FP_IMG);
-        if (nb > 1) { prod(Linv[rank[1]], h->hm_a2); image(M, -1.0, dst + 2 * FP_IMG); }
-    }
-    // ---- model images
-    {
-        double* dst = pool.data() + h->pn_o_bt;
-        for (int J = 0; J < mp / 16; ++J)
-            for (int ks = 0; ks < FP_KS; ++ks)
-                for (int l = 0; l < 64; ++l) {
-                    const int c = 16 * J + (l & 15), q = 4 * ks + (l >> 4);
-                    dst[(J * FP_KS + ks) * 64 + l] = (c < m && q < n) ? bt[(size_t)c * n + q] : 0.0;
-                }
-        double* a = pool.data() + h->pn_o_aimg;
-        std::vector<ld> A(nn);
-        for (int i = 0; i < nn; ++i) A[i] = h->hm_a1[i];
-        image(A, 1.0, a + FP_AIMG_A1 * FP_IMG);
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = A[c * n + r];
-        image(M, 1.0, a + FP_AIMG_A1T * FP_IMG);
-        for (int i = 0; i < nn; ++i) A[i] = h->hm_a2[i];
-        image(A, 1.0, a + FP_AIMG_A2 * FP_IMG);
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) M[r * n + c] = A[c * n + r];
-        image(M, 1.0, a + FP_AIMG_A2T * FP_IMG);
-        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) {
-            ld t = 0.0L;
-            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + r] * (ld)bt[(size_t)j * n + c];
-            M[r * n + c] = t;
-        }
-        image(M, 1.0, a + FP_AIMG_BBT * FP_IMG);
-    }
-    // ---- vectors
-    const FpVec V = fp_vec_layout(nb, T);
-    double* vec = pool.data() + h->pn_o_vec;
-    std::vector<double> cbu(n), bu(n), a1x(n), a2x(n);
-    for (int a = 0; a < n; ++a) {
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-        for (int j = 0; j < m; ++j) {
-            t0 += bt[(size_t)j * n + a] * uc[mp + j] * uc[j];
-            t1 += bt[(size_t)j * n + a] * h->hm_umid[j];
-            t2 += bt[(size_t)j * n + a] * uc[j];
-        }
-        cbu[a] = t0; bu[a] = t1; vec[V.bcu + a] = t2;
-        double s1 = 0.0, s2 = 0.0;
-        for (int q = 0; q < n; ++q) { s1 += h->hm_a1[a * n + q] * h->hm_xmid[q]; s2 += h->hm_a2[a * n + q] * h->hm_xmid[q]; }
-        a1x[a] = s1; a2x[a] = s2;
-    }
-    std::vector<double> phx((size_t)T * n);
-    double rd2_0 = T * sa_cu;
-    for (int j = 0; j < T; ++j)
-        for (int r = 0; r < n; ++r) {
-            const bool last = j + 1 == T;
-            const double q2 = last ? h->hm_Qf2[r] : h->hm_Q2[r];
-            const double d0 = q2 * h->hm_xmid[r] + (last ? h->hm_qfl[r] : h->hm_ql[r]);
-            vec[V.dx0 + j * 32 + r] = d0;
-            vec[V.iq + j * 32 + r] = 1.0 / q2;
-            phx[(size_t)j * n + r] = d0 / q2;
-            vec[V.xc + j * 32 + r] = h->hm_xmid[r] - d0 / q2;
-            rd2_0 += d0 * d0;
-        }
-    const bool var2 = h->var_order == 2;
-    for (int i = 0; i < nb; ++i)
-        for (int r = 0; r < n; ++r) {
-            double cp, c0;
-            if (i < T) {
-                cp = h->hm_xmid[r] - bu[r] - (i >= 1 ? a1x[r] : 0.0) - (i >= 2 ? a2x[r] : 0.0);
-                c0 = phx[(size_t)i * n + r] - cbu[r];
-                if (i >= 1) for (int q = 0; q < n; ++q) c0 -= h->hm_a1[r * n + q] * phx[(size_t)(i - 1) * n + q];
-                if (i >= 2 && var2) for (int q = 0; q < n; ++q) c0 -= h->hm_a2[r * n + q] * phx[(size_t)(i - 2) * n + q];
-            } else {
-                cp = h->hm_xmid[r] - h->hm_xf[r];
-                c0 = phx[(size_t)(T - 1) * n + r];
-            }
-            vec[V.cp + i * 32 + r] = cp;
-            vec[V.ct + i * 32 + r] = cp - c0;
-        }
-    // rt_i = Linv_i ct_i and the w-free part of ||r_p||^2
-    double rp2c = 0.0;
-    for (int i = 0; i < nb; ++i)
-        for (int r = 0; r < n; ++r) {
-            ld a = 0.0L;
-            for (int q = 0; q <= r; ++q) a += Linv[rank[i]][r * n + q] * (ld)vec[V.ct + i * 32 + q];
-            vec[V.rt + i * 32 + r] = (double)a;
-            if (i >= 2) rp2c += vec[V.cp + i * 32 + r] * vec[V.cp + i * 32 + r];
-        }
-    h->pn_rp2c = rp2c;
-    h->pn_rd2_0 = rd2_0;
-    {   // LDS image of the d_z kernel, in LDS order
-        const FdLds D = fd_lds_layout(mp);
-        double* dz = pool.data() + h->pn_o_dz;
-        memcpy(dz + D.BT, pool.data() + h->pn_o_bt, (size_t)(mp / 16) * FP_KS * 64 * sizeof(double));
-        memcpy(dz + D.A1T, pool.data() + h->pn_o_aimg + FP_AIMG_A1T * FP_IMG, FP_IMG * sizeof(double));
-        memcpy(dz + D.A2T, pool.data() + h->pn_o_aimg + FP_AIMG_A2T * FP_IMG, FP_IMG * sizeof(double));
-        for (int j = 0; j < mp; ++j) {
-            dz[D.UC + j] = -uc[mp + j] * uc[j];
-            dz[D.UC + mp + j] = uc[mp + j]; dz[D.UC + 2 * mp + j] = uc[2 * mp + j]; dz[D.UC + 3 * mp + j] = uc[3 * mp + j];
-        }
-        for (int j = 0; j < mp; ++j) {                               // [c2 | 2R | hp | hm] for the next-exit-test variant
-            const bool in = j < m;
-            dz[D.UX + j] = in ? h->hm_R2[j] * h->hm_umid[j] + h->hm_rl[j] : 0.0;
-            dz[D.UX + mp + j] = in ? h->hm_R2[j] : 0.0;
-            dz[D.UX + 2 * mp + j] = in ? h->hm_umax[j] - h->hm_umid[j] : 1.0;
-            dz[D.UX + 3 * mp + j] = in ? h->hm_umid[j] - h->hm_umin[j] : 1.0;
-        }
-        for (int r = 0; r < 32; ++r) {
-            dz[D.XQ + r] = vec[V.xc + r]; dz[D.XQ + 32 + r] = vec[V.xc + (T - 1) * 32 + r];
-            dz[D.XQ + 64 + r] = vec[V.iq + r]; dz[D.XQ + 96 + r] = vec[V.iq + (T - 1) * 32 + r];
-        }
-    }
-    if (hipMemcpy(h->pn_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    h->pn_valid = 0;
+    FmpcPanelIn In;
+    In.n = h->n; In.m = h->m; In.T = h->T; In.nb = h->nb; In.mp = h->pn_mp; In.var_order = h->var_order;
+    In.pool_doubles = h->pn_doubles; In.o_simg = h->pn_o_simg; In.o_limg = h->pn_o_limg; In.o_bt = h->pn_o_bt;
+    In.o_aimg = h->pn_o_aimg; In.o_vec = h->pn_o_vec; In.o_ucon = h->pn_o_ucon; In.o_dz = h->pn_o_dz; In.limg_cap = h->pn_limg_cap;
+    In.umax = h->hm_umax.data(); In.umin = h->hm_umin.data(); In.umid = h->hm_umid.data(); In.xmid = h->hm_xmid.data();
+    In.R2 = h->hm_R2.data(); In.rl = h->hm_rl.data(); In.Q2 = h->hm_Q2.data(); In.Qf2 = h->hm_Qf2.data();
+    In.ql = h->hm_ql.data(); In.qfl = h->hm_qfl.data(); In.xf = h->hm_xf.data();
+    In.bt = h->hm_bt.data(); In.a1 = h->hm_a1.data(); In.a2 = h->hm_a2.data(); In.blocks = h->hm_blocks.data();
+    In.idxD = h->hm_idxD.data(); In.idx1 = h->hm_idx1.data(); In.idx2 = h->hm_idx2.data();
+    FmpcPanelOut Out;
+    fmpc_host_build_panel(In, k, Out);
+    if (!Out.valid) return FMPC_OK;                                // not PD at the start point: the exact path reports it
+    h->pn_nsf = Out.nsf; h->pn_nsb = Out.nsb; h->pn_rp2c = Out.rp2c; h->pn_rd2_0 = Out.rd2_0;
+    if (hipMemcpy(h->pn_sched, Out.sched.data(), Out.sched.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    if (hipMemcpy(h->pn_pool, Out.pool.data(), Out.pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
     h->pn_valid = 1;
     return FMPC_OK;
 }
@@ -1771,22 +1421,13 @@ extern "C" int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U,
 // here would allocate, upload and -- on the panel path -- factor again at every call.  fmpc_solve_once therefore keeps
 // the handles of the last few models it has seen, keyed on the exact bytes of every model argument.
 namespace {
-struct OnceEntry { std::vector<double> key; fmpc_handle h; std::vector<double> ramp; unsigned long long stamp; };
 std::mutex once_mu;
-std::vector<OnceEntry> once_cache;
-unsigned long long once_clock = 0;
-const size_t ONCE_CAPACITY = 4;
-
-void once_key_push(std::vector<double>& key, const double* p, size_t cnt) {
-    key.push_back(p ? (double)cnt : -1.0);                        // NULL and present arguments differ
-    if (p) key.insert(key.end(), p, p + cnt);
-}
+FmpcLru<fmpc_handle> once_cache(4);                            // (fmpc_host.h) the last 4 distinct models
 }  // namespace
 
 extern "C" int fmpc_solve_once_cache_clear(void) {
     std::lock_guard<std::mutex> lk(once_mu);
-    for (OnceEntry& e : once_cache) fmpc_destroy(e.h);
-    once_cache.clear();
+    once_cache.clear([](fmpc_handle hh) { fmpc_destroy(hh); });
     return FMPC_OK;
 }
 
@@ -1813,31 +1454,22 @@ extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
     std::vector<double> key;
     key.reserve((size_t)2 * n * n + (size_t)n * m + (size_t)m * m + 8 * (size_t)(n + m) + 32);
     const double dims[5] = {(double)n, (double)m, (double)T, (double)var_order, (double)device};
-    once_key_push(key, dims, 5);
+    fmpc_host_key_push(key, dims, 5);
     const size_t nn = (size_t)n * n;
-    once_key_push(key, A1, nn); once_key_push(key, var_order == 2 ? A2 : nullptr, nn); once_key_push(key, B, (size_t)n * m);
-    once_key_push(key, Q, nn); once_key_push(key, R, (size_t)m * m); once_key_push(key, Qf, nn);
-    once_key_push(key, q, n); once_key_push(key, r, m); once_key_push(key, qf, n);
-    once_key_push(key, x_min, n); once_key_push(key, x_max, n); once_key_push(key, u_min, m); once_key_push(key, u_max, m);
-    once_key_push(key, xf, n);
-    OnceEntry* ent = nullptr;
-    for (OnceEntry& e : once_cache)
-        if (e.key.size() == key.size() && memcmp(e.key.data(), key.data(), key.size() * sizeof(double)) == 0) { ent = &e; break; }
+    fmpc_host_key_push(key, A1, nn); fmpc_host_key_push(key, var_order == 2 ? A2 : nullptr, nn); fmpc_host_key_push(key, B, (size_t)n * m);
+    fmpc_host_key_push(key, Q, nn); fmpc_host_key_push(key, R, (size_t)m * m); fmpc_host_key_push(key, Qf, nn);
+    fmpc_host_key_push(key, q, n); fmpc_host_key_push(key, r, m); fmpc_host_key_push(key, qf, n);
+    fmpc_host_key_push(key, x_min, n); fmpc_host_key_push(key, x_max, n); fmpc_host_key_push(key, u_min, m); fmpc_host_key_push(key, u_max, m);
+    fmpc_host_key_push(key, xf, n);
+    FmpcLru<fmpc_handle>::Entry* ent = once_cache.find(key);
     int rc;
     if (!ent) {
         fmpc_handle h = nullptr;
         rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max, u_min, u_max, xf, device);
         if (rc != FMPC_OK) return rc;
-        if (once_cache.size() >= ONCE_CAPACITY) {             // evict the least recently used model
-            size_t old = 0;
-            for (size_t i = 1; i < once_cache.size(); ++i) if (once_cache[i].stamp < once_cache[old].stamp) old = i;
-            fmpc_destroy(once_cache[old].h);
-            once_cache.erase(once_cache.begin() + old);
-        }
-        once_cache.push_back(OnceEntry{std::move(key), h, {}, 0});
-        ent = &once_cache.back();
+        ent = once_cache.insert(std::move(key), h, [](fmpc_handle hh) { fmpc_destroy(hh); });   // evicts the least recently used model
     }
-    ent->stamp = ++once_clock;
+    once_cache.touch(ent);
     int st = 0;
     if (ramp) {
         // (the README shifts du_min/du_max by u_prev at every step, README.md:543-544: the bounds are per-call data)

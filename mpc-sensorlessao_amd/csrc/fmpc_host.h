@@ -1,0 +1,82 @@
+// Host-only builders of the library: everything that is computed on the CPU once per handle or per (handle, k) and then
+// uploaded -- the iteration-invariant Y blocks with their de-duplication, the panel path's twisted block factorisation in
+// long double with its operator images and sweep schedules, and the least-recently-used cache of the one-shot entry.
+// No HIP in here: fmpc_api.hip calls these and does the allocation / upload; tests/host_san builds the same file with
+// g++ -fsanitize=address,undefined and checks the factorisation against a dense solve (sanitizers on the CPU build).
+#pragma once
+#include <stddef.h>
+#include <string.h>
+#include <vector>
+
+#include "fmpc_panel_layout.h"
+
+// out (row-major n x n) += sign * A X B'   with A, B, X row-major n x n (X dense)
+void fmpc_host_add_AXBt(std::vector<double>& out, const std::vector<double>& A, const std::vector<double>& X,
+                        const std::vector<double>& B, int n, double sign);
+
+// Iteration-invariant blocks of Y = C Phi^-1 C' (SURVEY.md App. A.4), de-duplicated byte for byte:
+//   Yd_i = X_{i+1} + [i>=1] A1 X_i A1' + [i>=2] A2 X_{i-1} A2' ,  Y1_i = -X_{i+1} A1' + [i>=1] A1 X_i A2' ,  Y2_i = -X_{i+1} A2'
+//   (X_j = (2Q)^-1, X_T = (2Qf)^-1; terminal rows: Yd_T = Xf, Y1_{T-1} = Xf).  idx*[i] = block id or -1 (none).
+void fmpc_host_y_blocks(int n, int T, bool var2, bool has_xf, const std::vector<double>& a1, const std::vector<double>& a2,
+                        const std::vector<double>& X, const std::vector<double>& Xf,
+                        std::vector<std::vector<double>>& blocks, std::vector<int>& idxD, std::vector<int>& idx1, std::vector<int>& idx2);
+
+// Inputs of the panel-path builder: host copies of the model (row-major) and the layout of the constant pool.
+struct FmpcPanelIn {
+    int n, m, T, nb, mp, var_order;
+    size_t pool_doubles, o_simg, o_limg, o_bt, o_aimg, o_vec, o_ucon, o_dz;
+    int limg_cap;
+    const double *umax, *umin, *umid, *xmid, *R2, *rl, *Q2, *Qf2, *ql, *qfl, *xf;
+    const double *bt;                   // bt[c*n + r] = B[r][c]
+    const double *a1, *a2;              // n x n row-major
+    const double *blocks;               // unique Y blocks, n x n row-major each
+    const int *idxD, *idx1, *idx2;
+};
+struct FmpcPanelOut {
+    std::vector<double> pool;           // [simg | limg | btimg | aimg | vec | ucon | dump | dzimg] per the offsets above
+    std::vector<int> sched;             // forward schedule, then backward (FP_MAX_STEPS(nb) x FP_STEP_INTS each)
+    int nsf, nsb, nimg, valid;
+    double rp2c, rd2_0;
+};
+// Layout of the constant pool of the panel path (offsets in doubles): fills the o_* / pool_doubles / limg_cap fields of L;
+// *o_dump = offset of the dump area behind the uploaded constants, *total = doubles to allocate, *dz_len = length of the
+// d_z kernel's LDS image.
+void fmpc_host_panel_layout(int n, int m, int T, int nb, int mp, FmpcPanelIn& L, size_t* o_dump, size_t* total, int* dz_len);
+// Returns 0; Out.valid = 0 when Y is not positive definite at the start point (the exact path reports that) or the
+// edges do not fit the image capacity.
+int fmpc_host_build_panel(const FmpcPanelIn& In, double k, FmpcPanelOut& Out);
+
+// Key of the one-shot entry's model cache: every model argument byte for byte, NULL and present arguments distinct.
+inline void fmpc_host_key_push(std::vector<double>& key, const double* p, size_t cnt) {
+    key.push_back(p ? (double)cnt : -1.0);
+    if (p) key.insert(key.end(), p, p + cnt);
+}
+
+// Least-recently-used cache of a few payloads (device handles in the library, anything in the tests).
+template <class H>
+struct FmpcLru {
+    struct Entry { std::vector<double> key; H h; std::vector<double> ramp; unsigned long long stamp; };
+    std::vector<Entry> items;
+    unsigned long long clock = 0;
+    size_t capacity;
+    explicit FmpcLru(size_t cap) : capacity(cap) {}
+    Entry* find(const std::vector<double>& key) {
+        for (Entry& e : items)
+            if (e.key.size() == key.size() && memcmp(e.key.data(), key.data(), key.size() * sizeof(double)) == 0) return &e;
+        return nullptr;
+    }
+    template <class D>
+    Entry* insert(std::vector<double>&& key, H h, D destroy) {       // evicts the least recently used entry when full
+        if (items.size() >= capacity) {
+            size_t old = 0;
+            for (size_t i = 1; i < items.size(); ++i) if (items[i].stamp < items[old].stamp) old = i;
+            destroy(items[old].h);
+            items.erase(items.begin() + old);
+        }
+        items.push_back(Entry{std::move(key), h, {}, 0});
+        return &items.back();
+    }
+    void touch(Entry* e) { e->stamp = ++clock; }
+    template <class D>
+    void clear(D destroy) { for (Entry& e : items) destroy(e.h); items.clear(); }
+};
