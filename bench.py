@@ -597,7 +597,7 @@ def _main(real_out):
         ach_gbs = b_first * units / (kern_ms * 1e-3) / 1e9
         ex_fl = executed_mfma_flops_panel(m, T, dense) if path == pkg._lib.FMPC_PATH_PANEL else None
         # measured HBM traffic of one solve: from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS workload
-        # (scripts/profile_round.sh writes profiles/traffic_latest.json); not measured inside this run, and only
+        # (scripts/prof_round2.sh writes profiles/traffic_latest.json); not measured inside this run, and only
         # reported when it is consistent with the compulsory bytes
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")

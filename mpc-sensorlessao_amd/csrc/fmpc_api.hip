@@ -101,6 +101,7 @@ struct fmpc_handle_s {
     double pn_rd2_0, pn_rp2c;
     // dense form of the cold-start dual solve (fmpc_kernel_inv.hip): nu+ = nuc + J d, built per (handle, k) on first use
     int inv_enabled, inv_valid, inv_jks, inv_max_batch, inv_last; double inv_k;
+    int inv_failed; double inv_failed_k;                         // the build for this k gave a non-finite J: not retried
     double* inv_jimg; double* inv_nuc; double* inv_eimg;
     double* inv_jst; double* inv_nucst; int inv_fuse;            // per-stage rows of J_x and nuc: the dual solve fused into d_z (w = NULL, no xf, budget 1)
     double* inv_jimg2; int inv_jks2;     // J' = [J_x | -J_w M1 | -J_w M2]: closed-loop steps, w = -M1 B u1 - M2 B u2 (fmpc_loop_step_device)
@@ -288,7 +289,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
+    h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -746,11 +747,20 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     int grid = batch < cap ? batch : cap;
     if (grid_hint > 0 && grid_hint < grid) grid = grid_hint;           // (a list: as many workgroups as it is expected to be long)
     const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8, h->denseR);
-    const size_t need = L.total * (size_t)cap;
+    // one workspace slot per LAUNCHED workgroup (not per workgroup the chip could hold: a warm start of one problem or a
+    // continuation list of 200 would otherwise allocate 0.5-1.4 GB per handle); grown geometrically up to the full grid,
+    // so that a growing sequence of batch sizes reallocates (and synchronises) a logarithmic number of times
+    const size_t need = L.total * (size_t)grid, full = L.total * (size_t)cap;
     if (need > h->tl_ws_doubles) {
+        size_t want = 2 * h->tl_ws_doubles;
+        if (want < need) want = need;
+        if (want > full) want = full;
         if (h->tl_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->tl_ws); h->tl_ws = nullptr; h->tl_ws_doubles = 0; }
-        if (hipMalloc((void**)&h->tl_ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
-        h->tl_ws_doubles = need;
+        if (hipMalloc((void**)&h->tl_ws, want * sizeof(double)) != hipSuccess) {
+            if (want == need || hipMalloc((void**)&h->tl_ws, need * sizeof(double)) != hipSuccess) { h->tl_ws = nullptr; return FMPC_E_ALLOC; }
+            want = need;
+        }
+        h->tl_ws_doubles = want;
     }
     FtParams P;
     P.M = h->dev; P.V = X.V; P.batch = batch;
@@ -1022,10 +1032,13 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             // (a closed-loop step hands over [B u1 ; B u2], the 2 n numbers its w depends on: 28 k-steps at any batch)
             const bool lowrank = h->lp_hint && w != nullptr && h->lp_v != nullptr;
             const bool dense_form = h->inv_enabled && (w == nullptr || lowrank || batch <= h->inv_max_batch);
-            if (dense_form && (!h->inv_valid || h->inv_k != k)) {
+            if (dense_form && (!h->inv_valid || h->inv_k != k) && !(h->inv_failed && h->inv_failed_k == k)) {
                 if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;   // earlier solves may still read J
                 const int rcb = fmpc_build_inverse(h, k, (hipStream_t)stream);
                 if (rcb != FMPC_OK) return rcb;
+                // J or nuc not finite: the sweep form is taken, and the build (a stream synchronisation, allocations and a
+                // 5 ms launch) is not retried on every later solve with this k
+                h->inv_failed = h->inv_valid ? 0 : 1; h->inv_failed_k = k;
             }
             const int split = max_iter > 1;                           // budgets > 1: decide, compact, continue (two launches)
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
@@ -1077,7 +1090,9 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters,
                                                       step, u0_out, (hipStream_t)stream, 4, h->pn_list, h->pn_cnt + 1, h->pn_nuws, hint);
                     if (rc_t == FMPC_OK) continue;
-                    if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
+                    // (no workspace for the tiled kernel: the panel, d_z and decision kernels are already enqueued -- the
+                    // one-wavefront kernel below, whose workspace exists, finishes the solve instead of aborting it half-way)
+                    if (rc_t != FMPC_E_UNSUPPORTED && rc_t != FMPC_E_ALLOC) return rc_t;
                 }
                 e = fmpc_launch_wave(h->dev, h->wave, batch, g2, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                      z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
@@ -1177,7 +1192,7 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
         (void)hipDeviceSynchronize();
         if (h->lp_v) (void)hipFree(h->lp_v);
         h->lp_v = nullptr; h->lp_cap = 0;
-        if (hipMalloc((void**)&h->lp_v, (size_t)batch * 2 * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        if (hipMalloc((void**)&h->lp_v, (size_t)batch * 2 * h->n * sizeof(double)) != hipSuccess) { fmpc_guard_end(h, (hipStream_t)stream); return FMPC_E_ALLOC; }
         h->lp_cap = batch;
     }
     if (fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_k, x0_last, u1, u2,
