@@ -498,8 +498,24 @@ def _main(real_out):
                 assert int(loop.status.abs().sum()) == 0
                 cl["realisations_%d%s" % (R_, "" if keep_z else "_u0_only")] = {
                     "value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3, "sequential_steps": nsteps_}
+        for R_ in (1, 16):                                # a recorded stretch in ONE host call (fmpc_loop_run_device): the device-side step time
+            nst = 300
+            a_np = np.stack([pkg.synthetic.make_realisation(model, r=r_, steps=nst)[1:nst + 1] for r_ in range(R_)], axis=1)
+            a_t = torch.from_numpy(np.ascontiguousarray(a_np)).to(dev)
+            for rep in range(2):
+                loop = pkg.ClosedLoop(h, R_, n_newton=args.n_newton, k=K_BAR, keep_z=False)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                loop.run_recorded(a_t, want_x0=False)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            assert int(loop.status.abs().sum()) == 0
+            cl["realisations_%d_u0_only_recorded" % R_] = {"value": R_ * nst / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nst * 1e3,
+                                                           "sequential_steps": nst, "host_calls": 1}
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
-                                         "depends on the previous first move, so only realisations batch; one fmpc_loop_step_device call per step", **cl)
+                                         "depends on the previous first move, so only realisations batch; one fmpc_loop_step_device call per step. *_u0_only: z_out = NULL "
+                                         "(README.md:589 applies U(1:nu) only); up to 64 realisations that is the first-move form, ONE launch + an exact-path "
+                                         "launch that returns at once (fmpc_kernel_first.hip); *_recorded: the whole stretch in one host call (fmpc_loop_run_device)", **cl)
         # ------------------------------------------------------------------ configs[0] on the device: VAR(1), T = 10, ramp rows
         T0 = 10
         m0 = pkg.synthetic.make_model(n, m, T0, var_order=1)

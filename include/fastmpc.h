@@ -212,6 +212,21 @@ int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const dou
                           double* u0_out, void* stream);
 
 /*
+ * A recorded stretch of the loop in ONE host call (the reference's simulation knows its turbulence coefficients in advance:
+ * README.md:51-93 generates and fits all phase screens before the loop of :444-626 starts): `steps` consecutive
+ * fmpc_loop_step_device calls, the first moves fed back on the device.  a: n x batch x steps (one n x batch slab per step),
+ * nu0: nu_len x batch x steps or NULL, U0: m x batch x steps receives u[k] = U(1:nu) of every step (README.md:589), X0
+ * (nullable): n x batch x steps receives the residuals x0 of every step.  u_before1 / u_before2 (nullable): the first moves of
+ * the two steps before this stretch, have_x0_last != 0: x0 holds the previous step's residual (continuing an earlier stretch).
+ * z is not produced (first moves only); status / iters hold the last step's values.  The host then spends one call, not one
+ * per timestep: a sequential loop of a few realisations is otherwise bound by the host.
+ */
+int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, const double* nu0,
+                         const double* u_before1, const double* u_before2, int have_x0_last,
+                         int n_newton, double k, double* x0, double* x0_pre, double* w,
+                         double* U0, double* X0, int* status, int* iters, void* stream);
+
+/*
  * Ramp-rate rows of the VAR_1 variant (VAR_1/Fast_MPC2.m:26-27 arguments dumin, dumax, u_prev;
  * VAR_1/fast_mpc_ineq_const.m:58-76): per stage j   du_min <= u_j - u_{j-1} <= du_max,  u_{-1} = u_prev.
  * fmpc_set_ramp stores the bounds (m each, du_min < du_max) in the handle; fmpc_solve_ramp[_device] is

@@ -38,6 +38,32 @@ class ClosedLoop:
         self.steps_done = 0
         self.ramp = bool(ramp)
         self.fused = bool(fused)        # one C call per step (fmpc_loop_step_device) instead of two
+        # The fused step is one C call whose arguments, apart from a[k] and nu0, are this object's own buffers: their
+        # pointers are built once (a sequential loop of one realisation is bound by the HOST time per step otherwise:
+        # tensor checks and ctypes conversions cost more than the two launches of the first-move form).
+        import ctypes as C
+        self._C, self._torch, self._dev = C, torch, dev
+        vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._p = dict(x0=vp(self.x0), x0_pre=vp(self.x0_pre), w=vp(self.w), u=[vp(u) for u in self.u], z=vp(self.z),
+                       status=vp(self.status), iters=vp(self.iters))
+        self._fn = handle._lib.fmpc_loop_step_device
+        self._n_newton_c, self._k_c = int(self.n_newton), float(self.k)
+
+    def _step_fused(self, a_k, nu0, s):
+        torch, C = self._torch, self._C
+        if a_k.dtype != torch.float64 or not a_k.is_cuda or not a_k.is_contiguous() or a_k.shape[0] != self.batch or a_k.shape[-1] != self.h.n:
+            raise ValueError("a_k: need a contiguous float64 HIP tensor of shape (batch, n)")
+        if nu0 is not None and (nu0.dtype != torch.float64 or not nu0.is_contiguous() or nu0.numel() != self.batch * self.h.nu_len):
+            raise ValueError("nu0: need a contiguous float64 HIP tensor of shape (batch, nu_len)")
+        P = self._p
+        u = P["u"]
+        rc = self._fn(self.h._h, self.batch, C.c_void_p(a_k.data_ptr()), P["x0"] if s >= 1 else None, u[(s - 1) % 3] if s >= 1 else None,
+                      u[(s - 2) % 3] if s >= 2 else None, P["x0"], P["x0_pre"], P["w"], None if nu0 is None else C.c_void_p(nu0.data_ptr()),
+                      self._n_newton_c, self._k_c, P["z"], None, P["status"], P["iters"], None, u[s % 3],
+                      C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
+        if rc != 0:
+            from ._lib import FastMPCError
+            raise FastMPCError(rc, "fmpc_loop_step_device")
 
     def step(self, a_k, nu0=None):
         """One closed-loop step for all realisations.  a_k: (batch, n) device tensor.  Returns u[k] (batch, m),
@@ -51,11 +77,36 @@ class ClosedLoop:
                                 status=self.status, iters=self.iters, u_prev=u1 if self.ramp else None, u0_out=u_new,
                                 want_z=self.z is not None)
         else:
-            self.h.loop_step_device(a_k, self.x0 if s >= 1 else None, u1 if s >= 1 else None, u2 if s >= 2 else None,
-                                    self.x0, self.x0_pre, self.w, nu0, self.n_newton, self.k, z_out=self.z,
-                                    status=self.status, iters=self.iters, u0_out=u_new)
+            self._step_fused(a_k, nu0, s)
         self.steps_done = s + 1
         return u_new
+
+    def run_recorded(self, a, nu0=None, want_x0=True):
+        """The whole stretch a (steps, batch, n) in ONE C call (fmpc_loop_run_device): first moves only, fed back on the device.
+        Continues from this object's state.  Returns (U0 (steps, batch, m), X0 (steps, batch, n) or None)."""
+        torch, C = self._torch, self._C
+        if self.ramp or not self.fused:
+            raise ValueError("run_recorded: the fused step without ramp rows only")
+        steps = a.shape[0]
+        assert a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and tuple(a.shape[1:]) == (self.batch, self.h.n)
+        assert nu0 is None or (nu0.is_contiguous() and nu0.dtype == torch.float64 and nu0.numel() == steps * self.batch * self.h.nu_len)
+        U0 = torch.empty((steps, self.batch, self.h.m), dtype=torch.float64, device=a.device)
+        X0 = torch.empty((steps, self.batch, self.h.n), dtype=torch.float64, device=a.device) if want_x0 else None
+        s = self.steps_done
+        P = self._p
+        vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = self.h._lib.fmpc_loop_run_device(self.h._h, self.batch, steps, vp(a), vp(nu0), P["u"][(s - 1) % 3] if s >= 1 else None,
+                                              P["u"][(s - 2) % 3] if s >= 2 else None, 1 if s >= 1 else 0, self._n_newton_c, self._k_c,
+                                              P["x0"], P["x0_pre"], P["w"], vp(U0), vp(X0), P["status"], P["iters"],
+                                              C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
+        if rc != 0:
+            from ._lib import FastMPCError
+            raise FastMPCError(rc, "fmpc_loop_run_device")
+        # keep the ring consistent for a following step(): u[k-1], u[k-2] of the next step
+        for j in range(min(steps, 2)):
+            self.u[(s + steps - 1 - j) % 3].copy_(U0[steps - 1 - j])
+        self.steps_done = s + steps
+        return U0, X0
 
     def run(self, a, nu0=None):
         """a: (steps, batch, n) device tensor.  Returns (U0 (steps, batch, m), X0 (steps, batch, n))."""

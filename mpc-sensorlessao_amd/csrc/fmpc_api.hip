@@ -13,6 +13,7 @@
 #include "fmpc_device.h"
 #include "fmpc_panel.h"
 #include "fmpc_host.h"
+#include "fmpc_first.h"
 #include "fmpc_tiled.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
@@ -106,6 +107,10 @@ struct fmpc_handle_s {
     double* inv_jst; double* inv_nucst; int inv_fuse;            // per-stage rows of J_x and nuc: the dual solve fused into d_z (w = NULL, no xf, budget 1)
     double* inv_jimg2; int inv_jks2;     // J' = [J_x | -J_w M1 | -J_w M2]: closed-loop steps, w = -M1 B u1 - M2 B u2 (fmpc_loop_step_device)
     double* lp_v; size_t lp_cap; int lp_hint;                    // [B u1 ; B u2] per problem of the running loop step
+    // first-move form of the closed-loop step (fmpc_kernel_first.hip): host copies of J (columns [x0 | x0_pre | B u1 | B u2]) and
+    // nuc kept by fmpc_build_inverse, the derived matrices on the device per (handle, k), a flag per realisation
+    std::vector<double> hm_J4, hm_nuc; double hm_J4_k; int hm_J4_valid;
+    double* fm_pool; int fm_valid, fm_disabled; double fm_k; FmParams fm_P; int* fm_need; size_t fm_need_cap;
     std::vector<double> hm_m1, hm_m2;
     std::vector<double> hm_Q2, hm_Qf2, hm_ql, hm_qfl, hm_xf, hm_blocks;
     std::vector<int> hm_idxD, hm_idx1, hm_idx2;
@@ -289,6 +294,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
+    h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0;
+    { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
@@ -541,6 +548,8 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->inv_jst) (void)hipFree(h->inv_jst);
     if (h->inv_nucst) (void)hipFree(h->inv_nucst);
     if (h->inv_jimg2) (void)hipFree(h->inv_jimg2);
+    if (h->fm_pool) (void)hipFree(h->fm_pool);
+    if (h->fm_need) (void)hipFree(h->fm_need);
     if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
@@ -936,7 +945,88 @@ static int fmpc_build_inverse(fmpc_handle h, double k, hipStream_t stream) {
     if (hipMemcpy(h->inv_eimg, eimg.data(), eimg.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->inv_jimg, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->inv_nuc, nuc.data(), nuc.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    // host copy for the first-move form: J with the columns [x0 | x0_pre | B u1 | B u2], nuc
+    {
+        const int nc = 4 * n;
+        h->hm_J4.assign((size_t)nrow * nc, 0.0); h->hm_nuc.assign(nuc.begin(), nuc.begin() + nrow);
+        for (int r = 0; r < nrow; ++r)
+            for (int c = 0; c < nc; ++c) {
+                int pidx = -1;
+                if (c < n) pidx = 1 + c;
+                else if (c < 2 * n) pidx = var2 ? 1 + c : -1;
+                else pidx = 1 + ncol + (c - 2 * n);
+                if (pidx >= 0) h->hm_J4[(size_t)r * nc + c] = (at(pidx, r) - nuc[r]) / scale;
+            }
+        h->hm_J4_valid = 1; h->hm_J4_k = k; h->fm_valid = 0;
+    }
     h->inv_valid = 1; h->inv_k = k;
+    return FMPC_OK;
+}
+
+// Matrices of the first-move form for barrier weight k (fmpc_host_build_first_move), uploaded as one pool.
+static int fmpc_build_first_move(fmpc_handle h, double k) {
+    h->fm_valid = 0;
+    if (!h->hm_J4_valid || h->hm_J4_k != k) return FMPC_E_UNSUPPORTED;
+    const int n = h->n, m = h->m, T = h->T, TN = T * n;
+    FmpcFirstIn In;
+    In.n = n; In.m = m; In.T = T; In.nb = h->nb; In.var2 = h->var_order == 2 ? 1 : 0; In.has_xf = h->has_xf;
+    In.bt = h->hm_bt.data(); In.umax = h->hm_umax.data(); In.umin = h->hm_umin.data(); In.umid = h->hm_umid.data();
+    In.xmid = h->hm_xmid.data(); In.R2 = h->hm_R2.data(); In.rl = h->hm_rl.data(); In.a1 = h->hm_a1.data(); In.a2 = h->hm_a2.data();
+    In.m1 = h->hm_m1.data(); In.m2 = h->hm_m2.data(); In.xf = h->hm_xf.empty() ? h->hm_xmid.data() : h->hm_xf.data();
+    In.J = h->hm_J4.data(); In.nuc = h->hm_nuc.data(); In.k = k;
+    FmpcFirstOut O;
+    fmpc_host_build_first_move(In, O);
+    for (double v : O.K0t) if (!std::isfinite(v)) return FMPC_E_UNSUPPORTED;
+    for (double v : O.E) if (!std::isfinite(v)) return FMPC_E_UNSUPPORTED;
+    std::vector<double> pool;
+    auto push = [&](const std::vector<double>& v) { const size_t o = pool.size(); pool.insert(pool.end(), v.begin(), v.end()); while (pool.size() % 2) pool.push_back(0.0); return o; };
+    std::vector<double> m12t((size_t)2 * n * TN), dx0T(n);
+    for (int e = 0; e < TN; ++e)
+        for (int q = 0; q < n; ++q) { m12t[(size_t)q * TN + e] = h->hm_m1[(size_t)e * n + q]; m12t[(size_t)(n + q) * TN + e] = h->hm_m2[(size_t)e * n + q]; }
+    for (int r = 0; r < n; ++r) dx0T[r] = h->hm_Qf2[r] * h->hm_xmid[r] + h->hm_qfl[r];
+    const size_t oK = push(O.K0t), ou = push(O.u0c), oE = push(O.E), oe = push(O.e), oEp = push(O.Ep), oep = push(O.ep), om = push(m12t), od = push(dx0T);
+    if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
+    if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+    if (hipMemcpy(h->fm_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    FmParams& P = h->fm_P;
+    memset(&P, 0, sizeof(P));
+    P.n = n; P.m = m; P.T = T; P.nb = h->nb; P.var2 = In.var2; P.has_xf = h->has_xf;
+    P.bt = h->dev.Bt; P.K0t = h->fm_pool + oK; P.u0c = h->fm_pool + ou; P.E = h->fm_pool + oE; P.e = h->fm_pool + oe;
+    P.Ep = h->fm_pool + oEp; P.ep = h->fm_pool + oep; P.m12t = h->fm_pool + om; P.dx0T = h->fm_pool + od;
+    P.e0 = O.e0; P.ep0 = O.ep0; P.normE = O.normE; P.norme = O.norme; P.normEp = O.normEp; P.normep = O.normep; P.rd2_0 = h->pn_rd2_0;
+    h->fm_valid = 1; h->fm_k = k;
+    return FMPC_OK;
+}
+
+// The wave kernel's workspace: one slot per resident wavefront of the whole chip.  Caller holds h->mu.
+static int fmpc_ensure_wave_ws(fmpc_handle h, size_t* stride_out) {
+    const int wpw = fmpc_wave_waves_per_wg();
+    const size_t stride = fmpc_wave_ws_doubles(h->n, h->m, h->wave.mp, h->T, h->nb);
+    const size_t need = stride * (size_t)h->num_cu * wpw;
+    if (need > h->ws_doubles) {
+        if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_doubles = 0; }
+        if (hipMalloc((void**)&h->ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->ws_doubles = need;
+    }
+    *stride_out = stride;
+    return FMPC_OK;
+}
+
+// Cold-start constants of barrier weight k: the shared factor (an export launch of the wave kernel on one problem), the
+// k-dependent constants of the exact path and of the panel path.  Once per (handle, k).  Caller holds h->mu.
+static int fmpc_ensure_cold(fmpc_handle h, double k, size_t stride, hipStream_t stream) {
+    if (h->sh_valid && h->sh_k == k) return FMPC_OK;
+    // earlier solves (ordered before this point on `stream` by the guard) may still read the constants of
+    // the previous k, which the blocking uploads below overwrite
+    if (h->sh_valid && hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
+    double* scr = h->sh_scratch;                 // a zero state: x0 = x0_pre = 0, w = nu0 = 0
+    const hipError_t e = fmpc_launch_wave(h->dev, h->wave, 1, 1, scr, scr, nullptr, nullptr, nullptr, 1, k,
+                                          scr + ((h->n + 15) & ~15), nullptr, nullptr, nullptr, nullptr, 1, h->ws, stride,
+                                          h->wave_lds, stream, 2, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
+    if (e != hipSuccess) return FMPC_E_HIP;
+    if (fmpc_upload_cold(h, k, stream) != FMPC_OK) return FMPC_E_HIP;
+    if (h->pn_enabled && fmpc_upload_panel(h, k, stream) != FMPC_OK) return FMPC_E_HIP;
+    h->sh_valid = 1; h->sh_k = k;
     return FMPC_OK;
 }
 
@@ -974,29 +1064,13 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         const int wpw = fmpc_wave_waves_per_wg();
         int grid = (batch + wpw - 1) / wpw;
         if (grid > h->num_cu) grid = h->num_cu;
-        const size_t stride = fmpc_wave_ws_doubles(h->n, h->m, h->wave.mp, h->T, h->nb);
-        const size_t need = stride * (size_t)h->num_cu * wpw;
-        if (need > h->ws_doubles) {
-            if (h->ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ws); h->ws = nullptr; h->ws_doubles = 0; }
-            if (hipMalloc((void**)&h->ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
-            h->ws_doubles = need;
-        }
+        size_t stride = 0;
+        { const int rcw = fmpc_ensure_wave_ws(h, &stride); if (rcw != FMPC_OK) return rcw; }
         int mode = 0;
         if (h->sh_enabled && z_init == nullptr) {
             // cold start: the first Newton step of every problem shares one factor (depends on k only)
-            if (!h->sh_valid || h->sh_k != k) {
-                // earlier solves (ordered before this point on `stream` by the guard) may still read the constants of
-                // the previous k, which the blocking uploads below overwrite
-                if (h->sh_valid && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
-                double* scr = h->sh_scratch;                 // a zero state: x0 = x0_pre = 0, w = nu0 = 0
-                e = fmpc_launch_wave(h->dev, h->wave, 1, 1, scr, scr, nullptr, nullptr, nullptr, 1, k,
-                                     scr + ((h->n + 15) & ~15), nullptr, nullptr, nullptr, nullptr, 1, h->ws, stride,
-                                     h->wave_lds, (hipStream_t)stream, 2, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d);
-                if (e != hipSuccess) return FMPC_E_HIP;
-                if (fmpc_upload_cold(h, k, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
-                if (h->pn_enabled && fmpc_upload_panel(h, k, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
-                h->sh_valid = 1; h->sh_k = k;
-            }
+            const int rce = fmpc_ensure_cold(h, k, stride, (hipStream_t)stream);
+            if (rce != FMPC_OK) return rce;
             mode = 1;
         }
         if (mode == 1 && h->pn_enabled && h->pn_valid) {
@@ -1173,6 +1247,62 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
                                   u0_out, stream);
 }
 
+// Closed-loop step of a few realisations in the first-move form (fmpc_kernel_first.hip): ONE launch computes the loop inputs,
+// the first moves and the step-length decision; a second one (the exact path in flag mode) returns at once unless a
+// realisation was not clear-cut.  FMPC_E_UNSUPPORTED: the caller takes the four-launch path.  Caller holds h->mu.
+#define FMPC_FIRST_MOVE_MAX_BATCH 64
+static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
+                                double* x0, double* x0_pre, double* w, const double* nu0, double k,
+                                int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+    if (h->fm_disabled || !h->use_wave || !h->sh_enabled || !h->pn_enabled || !h->inv_enabled || h->n != FP_N || batch > FMPC_FIRST_MOVE_MAX_BATCH)
+        return FMPC_E_UNSUPPORTED;
+    size_t stride = 0;
+    int rc = fmpc_ensure_wave_ws(h, &stride);
+    if (rc != FMPC_OK) return rc;
+    rc = fmpc_ensure_cold(h, k, stride, stream);
+    if (rc != FMPC_OK) return rc;
+    if (!h->pn_valid) return FMPC_E_UNSUPPORTED;
+    if (!h->inv_valid || h->inv_k != k) {
+        if (h->inv_failed && h->inv_failed_k == k) return FMPC_E_UNSUPPORTED;
+        if (hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
+        rc = fmpc_build_inverse(h, k, stream);
+        if (rc != FMPC_OK) return rc;
+        h->inv_failed = h->inv_valid ? 0 : 1; h->inv_failed_k = k;
+        if (!h->inv_valid) return FMPC_E_UNSUPPORTED;
+    }
+    if (!h->fm_valid || h->fm_k != k) {
+        if (hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
+        rc = fmpc_build_first_move(h, k);
+        if (rc != FMPC_OK) return rc;
+    }
+    // scratch iterate for realisations the exact path redoes, one flag per realisation
+    const size_t needz = (size_t)batch * h->T * (h->n + h->m);
+    if (needz > h->zs_doubles) {
+        if (h->zs) { (void)hipDeviceSynchronize(); (void)hipFree(h->zs); h->zs = nullptr; h->zs_doubles = 0; }
+        if (hipMalloc((void**)&h->zs, needz * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->zs_doubles = needz;
+    }
+    if ((size_t)batch > h->fm_need_cap) {
+        if (h->fm_need) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_need); h->fm_need = nullptr; h->fm_need_cap = 0; }
+        if (hipMalloc((void**)&h->fm_need, FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+        h->fm_need_cap = FMPC_FIRST_MOVE_MAX_BATCH;
+    }
+    FmParams P = h->fm_P;
+    P.step_ld = fmpc_step_ld(1);
+    P.a_k = a_k; P.x0_last = x0_last; P.u1 = u1; P.u2 = u2; P.nu0 = nu0;
+    P.x0 = x0; P.x0_pre = x0_pre; P.w = w; P.u0out = u0_out; P.status = status; P.iters = iters; P.step = step; P.need = h->fm_need;
+    P.handed = h->pn_cnt;                          // zeroed by the kernel; the exact path (next launch) counts what it redoes
+    if (fmpc_launch_first_move(P, batch, stream) != hipSuccess) return FMPC_E_HIP;
+    // the exact path for flagged realisations (cold start with the shared factor), first moves from its own z
+    const int wpw = fmpc_wave_waves_per_wg();
+    const int grid = (batch + wpw - 1) / wpw;
+    if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
+                         fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                         nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;
+    h->last_path = FMPC_PATH_PANEL; h->inv_last = 1;
+    return FMPC_OK;
+}
+
 // One closed-loop step: fmpc_loop_inputs_device + fmpc_solve_u0_device under one lock, with the knowledge that
 // w = -M1 (B u1) - M2 (B u2) has only 2 n degrees of freedom.
 extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
@@ -1188,6 +1318,12 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
     int rc = fmpc_guard_begin(h, (hipStream_t)stream);
     if (rc != FMPC_OK) return rc;
     const bool lr = h->inv_enabled && h->inv_jimg2 != nullptr && h->n == FP_N;
+    if (lr && !z_out && !nu_out && n_newton == 1) {
+        // first moves only, a few realisations: one launch instead of four (falls through when the form does not apply)
+        rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream);
+        if (rc != FMPC_E_UNSUPPORTED) { fmpc_guard_end(h, (hipStream_t)stream); return rc; }
+        rc = FMPC_OK;
+    }
     if (lr && (size_t)batch > h->lp_cap) {
         (void)hipDeviceSynchronize();
         if (h->lp_v) (void)hipFree(h->lp_v);
@@ -1205,6 +1341,28 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
     }
     fmpc_guard_end(h, (hipStream_t)stream);
     return rc;
+}
+
+// A recorded stretch of the loop in ONE host call: steps consecutive fmpc_loop_step_device calls with the first moves fed back
+// on the device (u[k] = U0[k], u[k-1] = U0[k-1], ...).  See include/fastmpc.h.
+extern "C" int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, const double* nu0,
+                                    const double* u_before1, const double* u_before2, int have_x0_last,
+                                    int n_newton, double k, double* x0, double* x0_pre, double* w,
+                                    double* U0, double* X0, int* status, int* iters, void* stream) {
+    if (!h || !a || !x0 || !x0_pre || !w || !U0) return FMPC_E_NULL;
+    if (batch < 0 || steps < 0) return FMPC_E_DIM;
+    if (batch == 0 || steps == 0) return FMPC_OK;
+    const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
+    for (int s = 0; s < steps; ++s) {
+        const double* u1 = s >= 1 ? U0 + (size_t)(s - 1) * sm : u_before1;
+        const double* u2 = s >= 2 ? U0 + (size_t)(s - 2) * sm : (s == 1 ? u_before1 : u_before2);
+        const int rc = fmpc_loop_step_device(h, batch, a + (size_t)s * sn, (s >= 1 || have_x0_last) ? x0 : nullptr, u1, u2, x0, x0_pre, w,
+                                             nu0 ? nu0 + (size_t)s * snu : nullptr, n_newton, k, nullptr, nullptr, status, iters, nullptr,
+                                             U0 + (size_t)s * sm, stream);
+        if (rc != FMPC_OK) return rc;
+        if (X0 && hipMemcpyAsync(X0 + (size_t)s * sn, x0, sn * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+    }
+    return FMPC_OK;
 }
 
 extern "C" int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled) {

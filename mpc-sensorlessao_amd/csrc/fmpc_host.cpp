@@ -399,3 +399,110 @@ int fmpc_host_build_panel(const FmpcPanelIn& In, double k, FmpcPanelOut& Out) {
     return 0;
 }
 
+
+void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out) {
+    typedef long double ld;
+    const int n = In.n, m = In.m, T = In.T, nb = In.nb, nc = 4 * n;
+    const bool var2 = In.var2 != 0;
+    Out.nc = nc;
+    std::vector<double> cu(m), wc(m), av(m);
+    for (int j = 0; j < m; ++j) {
+        const double sp = In.umax[j] - In.umid[j], sm = In.umid[j] - In.umin[j];
+        const double dp = 1.0 / sp, dm = 1.0 / sm;
+        const double hc = In.k * (dp * dp + dm * dm);
+        cu[j] = In.R2[j] * In.umid[j] + In.rl[j] + In.k * (dp - dm);
+        wc[j] = 1.0 / (In.R2[j] + hc);
+        av[j] = hc * wc[j];
+    }
+    const double* bt = In.bt;                                     // bt[c*n + r] = B[r][c]
+    // ---- u0 = u0c + K0 d
+    Out.K0t.assign((size_t)nc * m, 0.0); Out.u0c.assign(m, 0.0);
+    for (int j = 0; j < m; ++j) {
+        ld t = 0.0L;
+        for (int r = 0; r < n; ++r) t += (ld)bt[(size_t)j * n + r] * (ld)In.nuc[r];
+        Out.u0c[j] = (double)((ld)In.umid[j] + (ld)wc[j] * (t - (ld)cu[j]));
+        for (int c = 0; c < nc; ++c) {
+            ld s = 0.0L;
+            for (int r = 0; r < n; ++r) s += (ld)bt[(size_t)j * n + r] * (ld)In.J[(size_t)r * nc + c];
+            Out.K0t[(size_t)c * m + j] = (double)((ld)wc[j] * s);
+        }
+    }
+    // ---- ||e||^2 = d'E d + 2 e'd + e0 :  per stage s, g_s = a o (B' nuc_s - cu), G_s = diag(a) B' J_s
+    //      E = sum J_s' Ma2 J_s, e = sum J_s' B (a o g_s), e0 = sum |g_s|^2,  Ma2 = B diag(a^2) B'
+    std::vector<ld> Ma2((size_t)n * n, 0.0L);
+    for (int r = 0; r < n; ++r)
+        for (int q = 0; q < n; ++q) {
+            ld t = 0.0L;
+            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + r] * (ld)av[j] * (ld)av[j] * (ld)bt[(size_t)j * n + q];
+            Ma2[(size_t)r * n + q] = t;
+        }
+    std::vector<ld> E((size_t)nc * nc, 0.0L), e(nc, 0.0L), tmp((size_t)n * nc), bg(n), g(m);
+    ld e0 = 0.0L;
+    for (int s = 0; s < T; ++s) {
+        const double* Js = In.J + (size_t)s * n * nc;
+        const double* ncs = In.nuc + (size_t)s * n;
+        for (int j = 0; j < m; ++j) {
+            ld t = 0.0L;
+            for (int r = 0; r < n; ++r) t += (ld)bt[(size_t)j * n + r] * (ld)ncs[r];
+            g[j] = (ld)av[j] * (t - (ld)cu[j]);
+            e0 += g[j] * g[j];
+        }
+        for (int r = 0; r < n; ++r) {
+            ld t = 0.0L;
+            for (int j = 0; j < m; ++j) t += (ld)bt[(size_t)j * n + r] * (ld)av[j] * g[j];
+            bg[r] = t;
+        }
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < nc; ++c) {
+                ld t = 0.0L;
+                for (int q = 0; q < n; ++q) t += Ma2[(size_t)r * n + q] * (ld)Js[(size_t)q * nc + c];
+                tmp[(size_t)r * nc + c] = t;
+            }
+        for (int c1 = 0; c1 < nc; ++c1) {
+            ld t = 0.0L;
+            for (int r = 0; r < n; ++r) t += (ld)Js[(size_t)r * nc + c1] * bg[r];
+            e[c1] += t;
+            for (int c2 = 0; c2 < nc; ++c2) {
+                ld u = 0.0L;
+                for (int r = 0; r < n; ++r) u += (ld)Js[(size_t)r * nc + c1] * tmp[(size_t)r * nc + c2];
+                E[(size_t)c1 * nc + c2] += u;
+            }
+        }
+    }
+    // ---- ||r_p||^2 = |cp - Pb d|^2:  rows of stage 0 [A1 | A2 | -M1_0 | -M2_0], stage 1 [A2 | 0 | -M1_1 | -M2_1], i >= 2 [0 | 0 | -M1_i | -M2_i]
+    std::vector<ld> Ep((size_t)nc * nc, 0.0L), ep(nc, 0.0L), row(nc);
+    ld ep0 = 0.0L;
+    std::vector<ld> bu(n, 0.0L), a1x(n, 0.0L), a2x(n, 0.0L);
+    for (int r = 0; r < n; ++r) {
+        for (int j = 0; j < m; ++j) bu[r] += (ld)bt[(size_t)j * n + r] * (ld)In.umid[j];
+        for (int q = 0; q < n; ++q) { a1x[r] += (ld)In.a1[r * n + q] * (ld)In.xmid[q]; a2x[r] += (ld)In.a2[r * n + q] * (ld)In.xmid[q]; }
+    }
+    for (int i = 0; i < nb; ++i)
+        for (int r = 0; r < n; ++r) {
+            ld cp;
+            for (int c = 0; c < nc; ++c) row[c] = 0.0L;
+            if (i < T) {
+                cp = (ld)In.xmid[r] - bu[r] - (i >= 1 ? a1x[r] : 0.0L) - (i >= 2 ? a2x[r] : 0.0L);
+                if (i == 0) for (int q = 0; q < n; ++q) { row[q] = In.a1[r * n + q]; row[n + q] = var2 ? (ld)In.a2[r * n + q] : 0.0L; }
+                if (i == 1 && var2) for (int q = 0; q < n; ++q) row[q] = In.a2[r * n + q];
+                for (int q = 0; q < n; ++q) {
+                    row[2 * n + q] = -(ld)In.m1[((size_t)i * n + r) * n + q];
+                    row[3 * n + q] = -(ld)In.m2[((size_t)i * n + r) * n + q];
+                }
+            } else {
+                cp = (ld)In.xmid[r] - (ld)In.xf[r];
+            }
+            ep0 += cp * cp;
+            for (int c1 = 0; c1 < nc; ++c1) {
+                if (row[c1] == 0.0L) continue;
+                ep[c1] += row[c1] * cp;
+                for (int c2 = 0; c2 < nc; ++c2) Ep[(size_t)c1 * nc + c2] += row[c1] * row[c2];
+            }
+        }
+    auto fro = [](const std::vector<ld>& v) { ld s = 0.0L; for (ld x : v) s += x * x; return (double)sqrtl(s); };
+    Out.E.resize(E.size()); Out.Ep.resize(Ep.size()); Out.e.resize(nc); Out.ep.resize(nc);
+    for (size_t i = 0; i < E.size(); ++i) { Out.E[i] = (double)E[i]; Out.Ep[i] = (double)Ep[i]; }   // symmetric: [c][r] == [r][c]
+    for (int c = 0; c < nc; ++c) { Out.e[c] = (double)e[c]; Out.ep[c] = (double)ep[c]; }
+    Out.e0 = (double)e0; Out.ep0 = (double)ep0;
+    Out.normE = fro(E); Out.norme = fro(e); Out.normEp = fro(Ep); Out.normep = fro(ep);
+}

@@ -80,3 +80,26 @@ struct FmpcLru {
     template <class D>
     void clear(D destroy) { for (Entry& e : items) destroy(e.h); items.clear(); }
 };
+
+// ---- first-move form of the cold-start step (fmpc_kernel_first.hip; closed-loop steps of a few realisations, z_out = NULL)
+// With the data d = [x0 ; x0_pre ; B u1 ; B u2] (4 n numbers; w = -M1 B u1 - M2 B u2, README.md:490-497) the new dual
+// variable of the full step is nu+ = nuc + J d (fmpc_kernel_inv.hip).  What the caller applies is the first move only:
+//     u0 = ubar + wc o (B' nu+_0 - cu) = u0c + K0 d ,            K0 = diag(wc) B' J_0              (m x 4n)
+// and the step-length / exit decision (backtracking_inf_newton.m:2-11, inf_newton_solver.m:19-22) needs
+//     ||e||^2   = sum_j || hc o wc o (B' nu+_j - cu) ||^2 = d'E d + 2 e'd + e0
+//     ||r_p||^2 = sum_i || cp_i - b_i ||^2               = d'Ep d - 2 ep'd + ep0       (b affine in d: fast_mpc_eq_const.m:39-47)
+// Matrices are stored [column][row] (consecutive threads = consecutive rows of a product).
+#define FM_NC_MAX 108
+struct FmpcFirstIn {
+    int n, m, T, nb, var2, has_xf;
+    const double *bt, *umax, *umin, *umid, *xmid, *R2, *rl, *a1, *a2, *m1, *m2, *xf;
+    const double *J;                    // nb n x 4n row-major: columns [x0 | x0_pre | B u1 | B u2]
+    const double *nuc;                  // nb n
+    double k;
+};
+struct FmpcFirstOut {
+    int nc;                             // 4 n
+    std::vector<double> K0t, u0c, E, e, Ep, ep;
+    double e0, ep0, normE, norme, normEp, normep;
+};
+void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out);

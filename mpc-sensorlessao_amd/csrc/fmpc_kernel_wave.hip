@@ -1639,7 +1639,8 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     const int batch = P->batch;
     const bool panel_mode = P->gate != nullptr;
     const int wave_g = blockIdx.x * FW_WAVES + wv, nwaves = gridDim.x * FW_WAVES;
-    const int pphase = panel_mode ? P->pphase : 0;
+    // pphase 3 ("flag mode", behind fmpc_first_move): list[p] != 0 marks the problems to solve exactly, from scratch
+    const int pphase = (panel_mode || P->pphase == 3) ? P->pphase : 0;
     const int nlist = pphase == 2 ? P->handed[1] : 0;          // written by the pphase-1 launch
     const int rounds = pphase == 2 ? (nlist + nwaves - 1) / nwaves : (batch + nwaves - 1) / nwaves;
     if (panel_mode && pphase != 2) {
@@ -1661,6 +1662,11 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         if (!__syncthreads_or(need)) return;
     }
     if (pphase == 2 && nlist == 0) return;
+    if (pphase == 3) {                               // nothing flagged among this workgroup's problems (the usual case): leave
+        int any = 0;
+        for (int rnd = 0; rnd < rounds; ++rnd) { const int q = wave_g + rnd * nwaves; if (q < batch && P->list[q] != 0) any = 1; }
+        if (!__syncthreads_or(any)) return;
+    }
     for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
     {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
         double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
@@ -1689,6 +1695,10 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             accepted = entry >= 0 && !(entry & FW_LIST_HANDED);
             active = entry >= 0;
             p = entry >= 0 ? (entry & (FW_LIST_HANDED - 1)) : batch;
+        } else if (pphase == 3) {
+            accepted = false;
+            active = p < batch && P->list[p] != 0;
+            if (active && lane == 0 && P->handed) atomicAdd(P->handed, 1);
         } else {
             accepted = p < batch && panel_mode && fw_panel_decide(P, p, false);
             active = p < batch && !(accepted && (max_iter <= 1 || fw_panel_converged(P, p)));

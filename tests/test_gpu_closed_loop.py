@@ -161,23 +161,82 @@ def test_loop_step_with_a_newton_budget_and_no_nu0(pkg, gpu):
     h.close()
 
 
-@pytest.mark.parametrize("R,T", [(1, 30), (40, 30), (37, 10)])
-def test_closed_loop_first_moves_only(pkg, gpu, R, T):
+@pytest.mark.parametrize("R,T,first_move", [(1, 30, True), (40, 30, True), (37, 10, True), (5, 30, False), (100, 30, None)])
+def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     """ClosedLoop(keep_z=False): z_out = NULL at the C ABI (fmpc_loop_step_device), only u[k] = U(1:nu) leaves the solve
-    (README.md:589).  Trajectories bit for bit those of the loop that keeps z."""
+    (README.md:589).  Up to 64 realisations the step is ONE launch in the first-move form (fmpc_kernel_first.hip: u0 = u0c + K0 d,
+    the decision from two quadratic forms; same algebra, different rounding): trajectories within 1e-11 of the loop that keeps z.
+    With the form switched off (FMPC_NO_FIRST_MOVE=1) or more realisations (d_z without z stores): bit for bit."""
     import torch
     md = pkg.synthetic.make_model(27, 144, T)
-    steps = 6
+    steps = 8
     a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
     at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
     nu0 = torch.from_numpy(np.random.default_rng(1).random((steps, R, T * 27))).to(at.device)
-    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    h1 = handle_from_model(pkg, md)
+    if first_move is False:
+        monkeypatch.setenv("FMPC_NO_FIRST_MOVE", "1")
+    h2 = handle_from_model(pkg, md)
+    monkeypatch.delenv("FMPC_NO_FIRST_MOVE", raising=False)
     la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
     lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
     Ua, Xa = la.run(at, nu0)
     Ub, Xb = lb.run(at, nu0)
     torch.cuda.synchronize()
-    assert lb.z is None and h2.last_dispatch()[0] == pkg.FMPC_PATH_PANEL
+    assert lb.z is None and h2.last_dispatch() == (pkg.FMPC_PATH_PANEL, 0)
     assert int(la.status.abs().sum()) == 0 and int(lb.status.abs().sum()) == 0
-    assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb) and torch.equal(la.iters, lb.iters)
+    assert torch.equal(la.iters, lb.iters)
+    if first_move:
+        assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
+        assert rel_err(lb.w.cpu().numpy(), la.w.cpu().numpy()) <= 1e-11
+    else:
+        assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb)
+    h1.close(); h2.close()
+
+
+def test_first_move_form_hands_unclear_realisations_to_the_exact_path(pkg, gpu):
+    """Tight bounds: the barrier is active at the start, the line search does not accept t = 1 with a wide margin, and the
+    first-move kernel must flag those realisations; the exact path (flag mode of fmpc_newton_wave) redoes them.  Against the
+    oracle loop (1e-8 over the fed-back steps) and against the four-launch path."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10)
+    md["u_min"] = -0.05 * np.ones(144); md["u_max"] = 0.05 * np.ones(144)
+    R, steps = 6, 5
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa = la.run(at)
+    Ub, Xb = lb.run(at)
+    torch.cuda.synchronize()
+    assert h2.last_dispatch()[1] > 0, "no realisation was handed over: the case does not test the fallback"
+    assert torch.equal(la.status, lb.status) and torch.equal(la.iters, lb.iters)
+    assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
+    U0, X0 = Ub.cpu().numpy(), Xb.cpu().numpy()
+    for r in range(R):
+        ref = closed_loop(md, a[:, r], 1, 1e-2)
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    h1.close(); h2.close()
+
+
+@pytest.mark.parametrize("R", [1, 7])
+def test_recorded_stretch_in_one_call(pkg, gpu, R):
+    """fmpc_loop_run_device: a recorded stretch of the loop in one host call == the same steps one call at a time, bit for bit
+    (same kernels in the same order), also when the stretch continues an earlier one."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 30)
+    steps = 9
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    nu0 = torch.from_numpy(np.random.default_rng(2).random((steps, R, 30 * 27))).to(at.device)
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2, keep_z=False)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa = la.run(at, nu0)
+    U1, X1 = lb.run_recorded(at[:4].contiguous(), nu0[:4].contiguous())
+    U2, X2 = lb.run_recorded(at[4:].contiguous(), nu0[4:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([U1, U2]), Ua) and torch.equal(torch.cat([X1, X2]), Xa)
+    assert int(lb.status.abs().sum()) == 0
     h1.close(); h2.close()
