@@ -23,6 +23,16 @@
 #include "fmpc_first.h"
 #include "../../include/fastmpc.h"
 
+#ifdef FW_TIMING
+// diagnostic build: time stamps (constant 100 MHz clock) of wavefront 0 of the role-0 workgroup of realisation 0, last launch
+__device__ unsigned long long fm_trace[8];
+extern "C" int fmpc_debug_first_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fm_trace), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#define FM_TICK(k) do { if (p == 0 && role == 0 && tid == 0) fm_trace[k] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define FM_TICK(k)
+#endif
 #define FM_THREADS 1024                 // role 0: 576 + 216 + 216 partial rows; every partial row = ONE batch of <= 27 loads (the kernel is a chain
                                         // of memory round trips: 12.9 us with 9-load chunks on 512 threads)
 #define FM_WROWS (FM_THREADS / 2)       // rows of w per w-workgroup (two threads per row)
@@ -60,6 +70,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     // dependent steps through LDS, and each memory round trip in that chain would cost more than all its arithmetic
     // (12.9 us with the loads where they are used, measured).  Inputs; the B entries of the v = B u products; this
     // thread's partial row of K0 / E / Ep (role 0) or of [M1 M2] (role >= 1).
+    FM_TICK(0);
     double in_u1 = 0.0, in_u2 = 0.0, in_a = 0.0, in_xl = 0.0;
     if (tid < m) { in_u1 = P.u1 ? P.u1[(size_t)p * m + tid] : 0.0; in_u2 = P.u2 ? P.u2[(size_t)p * m + tid] : 0.0; }
     if (tid < n) { in_a = P.a_k[(size_t)p * n + tid]; in_xl = P.x0_last ? P.x0_last[(size_t)p * n + tid] : 0.0; }
@@ -97,6 +108,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     if (tid < m) { su[0][tid] = in_u1; su[1][tid] = in_u2; }
     if (tid < n) { sx[0][tid] = in_a; sx[1][tid] = in_xl; }
     __syncthreads();
+    FM_TICK(1);
     // ---- v1 = B u1, v2 = B u2: output (which, r) split over 16 threads, fixed-order shuffle sum
     {
         double acc = 0.0;
@@ -108,6 +120,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     __syncthreads();
     if (tid < n) { sd[tid] = sx[0][tid] + sd[2 * n + tid]; sd[n + tid] = P.var2 ? sx[1][tid] : 0.0; }
     __syncthreads();
+    FM_TICK(2);
     if (role >= 1) {
         // ---- w = -M1 (B u1) - M2 (B u2), one row per thread (README.md:490-497)
         double acc = fm_row_fma(mv, sd + 2 * n, wh * n, (wh + 1) * n);
@@ -121,6 +134,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     else if (kind == 1) partv = (fm_row_fma(mv, sd, c0, c1) + 2.0 * ev) * sd[rr];        // d_r ((E d)_r + 2 e_r), in two halves
     else if (kind == 2) partv = (fm_row_fma(mv, sd, c0, c1) - 2.0 * ev) * sd[rr];        // d_r ((Ep d)_r - 2 ep_r)
     spart[tid] = partv;
+    FM_TICK(3);
     // lower bound of ||r_d(nu0)||^2: its x entries of the last stage (no product needed), as the gate of the panel path
     if (wv == 15) {
         double rdl = 0.0, d2 = 0.0;
@@ -138,6 +152,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     // first moves (every realisation: a problem that is handed over gets its u0 overwritten by the exact path)
     if (tid < m) P.u0out[(size_t)p * m + tid] = u0c + ((spart[tid] + spart[m + tid]) + (spart[2 * m + tid] + spart[3 * m + tid]));
     if (tid < n) { P.x0[(size_t)p * n + tid] = sd[tid]; P.x0_pre[(size_t)p * n + tid] = sx[1][tid]; }
+    FM_TICK(4);
     if (p == 0 && tid == 0 && P.handed) *P.handed = 0;
     if (wv == 0) {
         // fixed-order sums of the two quadratic forms
@@ -164,6 +179,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
             }
         }
     }
+    FM_TICK(5);
 }
 
 hipError_t fmpc_launch_first_move(const FmParams& P, int batch, hipStream_t stream) {

@@ -16,3 +16,11 @@ loop.run_recorded(at, want_x0=False)
 torch.cuda.synchronize()
 assert int(loop.status.abs().sum()) == 0
 print("done", h.last_dispatch())
+
+lib = pkg.load()
+if hasattr(lib, "fmpc_debug_first_trace"):
+    import ctypes as C
+    tr = (C.c_ulonglong * 8)()
+    lib.fmpc_debug_first_trace(tr)
+    t = [(tr[i] - tr[0]) * 0.01 for i in range(6)]
+    print("first-move kernel, wavefront 0 (us since kernel entry): loads landed %.2f, d ready %.2f, rows done %.2f, sums ready %.2f, end %.2f" % tuple(t[1:6]))
