@@ -438,7 +438,7 @@ def _main(real_out):
         ex4 = executed_mfma_flops_tiled(n4, m, T4)
         extra["configs4_n65_T60_fp32"] = {
             "what": "configs[4]: VAR(2), n=65 (radial order 10), m=144, T=60, batch 1024, fp32 factor + fp64 residuals "
-                    "(fmpc_newton_tiled<float,5,8>), n_newton = 1",
+                    "(fmpc_newton_tiled<float,5,4,1>: two workgroups of 4 wavefronts per CU), n_newton = 1",
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "ms_per_step": e_ / s_ * 1e3, "kernel_ms": k_, "dtype": "f32 factor / f64 residuals",
             "path": h4.last_dispatch()[0],
             "roofline": {"bound": "mfma", "achieved": fl4 * it4 / (k_ * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

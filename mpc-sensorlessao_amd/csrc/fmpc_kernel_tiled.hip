@@ -649,27 +649,32 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             }
             __syncthreads();
             // zero the three U slots: stages 0 and 1 then need no special cases
-            for (int q = tid; q < 3 * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
+            for (int q = tid; q < 2 * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
             if (tid == 0) sflag[0] = 0;
             __syncthreads();
             FT_TICK(2);
 
             // ================= P3: factor + forward sweep
-            int ua = 0, ub = 1, uc = 2;                               // roles of the three LDS slots
+            // TWO U slots: Ua = U1_{i-1}, Ub = U2_{i-1}.  The third term of S_i, U2_{i-2}' U2_{i-2}, is applied ONE STAGE AHEAD:
+            // stage i - 1 holds U2_{i-2} as its Ub and subtracts Ub'Ub from the S0 tiles of stage i, which are already in
+            // registers by then (requested two stages ahead).  After phase A both slots are dead and take U1_i, U2_i in place --
+            // no rotation, and a third of the factor phase's LDS is gone (95 -> 70 KB at n = 65: two workgroups per CU).
             bool fail = false;
             // Loads queue behind the stores a wave has issued (vmcnt is in order), so everything stage i + 1 needs from
             // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
             // before that stage's factor tiles are stored.
-            v4 nS[SS], nM1[MS];
-            auto request = [&](int i) {
-                const R* Y1 = yimg + (size_t)V.i1[i] * NQ * FT_TILE;
+            v4 nS[SS], fS[SS], nM1[MS];                          // S0 tiles of stage i + 1 (loaded, updated in phase A) and i + 2 (in flight)
+            auto requestS = [&](int i, v4 (&dst)[SS]) {
 #pragma unroll
                 for (int sl = 0; sl < SS; ++sl)
                     if (sI[sl] >= 0) {
                         const R* gt = gws + ((size_t)i * NS + firstS + sl * NW) * FT_TILE;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) nS[sl][r] = gt[TT::row(g, r) * 16 + c];
+                        for (int r = 0; r < 4; ++r) dst[sl][r] = gt[TT::row(g, r) * 16 + c];
                     }
+            };
+            auto requestM = [&](int i) {
+                const R* Y1 = yimg + (size_t)V.i1[i] * NQ * FT_TILE;
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) {
                     const int q1 = firstM1 + sl * NW;
@@ -680,17 +685,19 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     }
                 }
             };
-            request(0);
+            v4 cS[SS];                                             // S tiles of the current stage (S0_i - U2_{i-2}' U2_{i-2})
+            requestS(0, cS);
+            requestS(nb > 1 ? 1 : 0, nS);
+            requestM(0);
             for (int i = 0; i < nb; ++i) {
-                R* UA = sSLOT + (size_t)ua * NQ * FT_TILE;
-                R* UB = sSLOT + (size_t)ub * NQ * FT_TILE;
-                R* UC = sSLOT + (size_t)uc * NQ * FT_TILE;
+                R* UA = sSLOT;
+                R* UB = sSLOT + (size_t)NQ * FT_TILE;
                 R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
                 const R* Y2 = yimg + (size_t)V.i2[i] * NQ * FT_TILE;
                 // ---------------- phase A: all tiles of the stage, independent
                 v4 aS[SS], aM1[MS];
 #pragma unroll
-                for (int sl = 0; sl < SS; ++sl) aS[sl] = nS[sl];
+                for (int sl = 0; sl < SS; ++sl) aS[sl] = cS[sl];
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
 #pragma unroll
@@ -700,7 +707,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll 1
                         for (int j = 0; j < NB; ++j) {
                             ft_xtz_sub<R>(aS[sl], UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
-                            ft_xtz_sub<R>(aS[sl], UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
+                            ft_xtz_sub<R>(nS[sl], UB + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);   // for S_{i+1}
                         }
                     }
                 }
@@ -714,10 +721,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                             ft_xtz_sub<R>(aM1[sl], UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
                     }
                 }
-                ft_lds_barrier();                                      // Ua, Uc are dead from here: their slots take U1_i, U2_i
+                ft_lds_barrier();                                      // Ua, Ub are dead from here: their slots take U1_i, U2_i
                 FT_TICK(3);
-                R* U1N = UA; R* U2N = UC;
-                if (i + 1 < nb) request(i + 1);
+                R* U1N = UA; R* U2N = UB;
+                if (i + 1 < nb) requestM(i + 1);
+                requestS(i + 2 < nb ? i + 2 : nb - 1, fS);             // (harmless re-read at the end of the horizon)
                 v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) {
@@ -848,8 +856,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                     if (sflag[0]) { fail = true; break; }              // uniform: read after the barrier
                 }
                 if (fail) break;
-                // next stage: Ua <- U1_i (slot ua), Ub <- U2_i (slot uc), Uc <- old Ub (slot ub)
-                const int t = ub; ub = uc; uc = t;
+                // next stage: its S tiles are the updated set, the set in flight becomes the next one
+#pragma unroll
+                for (int sl = 0; sl < SS; ++sl) { cS[sl] = nS[sl]; nS[sl] = fS[sl]; }
             }
             if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
             __syncthreads();                                           // the factor stream and y are in HBM (same workgroup reads them)
@@ -1016,6 +1025,7 @@ static hipError_t ft_prepare(size_t lds) {
     if (!is_float && nlast == 11 && NB == 2 && NW == 2) return fn<double, 2, 2, 11>(__VA_ARGS__);  \
     if (is_float && nlast == 11 && NB == 2 && NW == 4) return fn<float, 2, 4, 11>(__VA_ARGS__);    \
     if (is_float && nlast == 1 && NB == 5 && NW == 8) return fn<float, 5, 8, 1>(__VA_ARGS__);      \
+    if (is_float && nlast == 1 && NB == 5 && NW == 4) return fn<float, 5, 4, 1>(__VA_ARGS__);      \
     if (!is_float) {                                                                           \
         if (NB == 1 && NW == 2) return fn<double, 1, 2>(__VA_ARGS__);                          \
         if (NB == 2 && NW == 2) return fn<double, 2, 2>(__VA_ARGS__);                          \
@@ -1038,7 +1048,10 @@ static hipError_t ft_prepare(size_t lds) {
 // Wavefronts per problem.  Few waves per problem = many problems per CU (the factorisation is a chain of dependent
 // steps that only other problems can hide) at two waves per SIMD, i.e. the full 256-register budget per lane.
 static int ft_default_nw(int NB, int is_float) {
-    int NW = is_float ? (NB >= 4 ? 8 : (NB >= 2 ? 4 : 2)) : (NB >= 3 ? 4 : 2);
+    // (n = 65, NB = 5: since the factor phase keeps two U slots instead of three its LDS is 70 KB, so TWO workgroups of 4
+    // wavefronts share a CU -- one problem's pivot chains and barriers overlap the other's products: 7.98 ms per Newton step
+    // of BASELINE configs[4] against 9.11 ms with one workgroup of 8)
+    int NW = is_float ? (NB == 5 ? 4 : (NB >= 4 ? 8 : (NB >= 2 ? 4 : 2))) : (NB >= 3 ? 4 : 2);
     const char* e = getenv("FMPC_TILED_NW");                      // experiments
     if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8')) {
         const int w = e[0] - '0';
