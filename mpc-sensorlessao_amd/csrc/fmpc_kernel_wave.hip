@@ -46,6 +46,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) double* fw_lds_t;
 typedef const __attribute__((address_space(3))) double* fw_clds_t;
 #define FW_FN __device__ __noinline__
+#define FW_IN __device__ __forceinline__          // sub-phase of a merged phase function (below)
 
 // Diagnostic build only (-DFW_TIMING): per-phase cycle totals, never in the shipped library.
 #ifdef FW_TIMING
@@ -220,7 +221,7 @@ struct FwView {
 // ------------------------------------------------------------------------------------------------
 // P0: start point, nu, b   (fast_mpc_init.m:12-27, fast_mpc_eq_const.m:39,44,47,68)
 template <int N>
-FW_FN void fw_phase_init(FwKP Pin, int p, int write_z) {
+FW_IN void fw_phase_init(FwKP Pin, int p, int write_z) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     const FwView<N> W(P, p);
@@ -281,7 +282,7 @@ FW_FN void fw_phase_init(FwKP Pin, int p, int write_z) {
 //                the step length t = 1 (the usual outcome; fw_phase_zfix corrects it otherwise);
 //                out3 = { <r_d,e>, ||e||^2, - } with e = k P'DP d_z (line search); k P'DP = Rt - 2R.
 template <int N, int MODE>
-FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first) {
+FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     first = __builtin_amdgcn_readfirstlane(first);
@@ -309,8 +310,10 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
             const int j = j0 + 16 * (e >> 2) + 4 * (e & 3) + g;
             sok[e] = j < T; sj[e] = sok[e] ? j : 0;
         }
-        // A fragments (stage on the row index): v_j[k], v_{j+1}[k], v_{j+2}[k] for stage j = j0+16I+c16
-        double an[2][7], a1[2][7], a2[2][7];
+        // A fragments (stage on the row index): v_j[k] for stage j = j0+16I+c16.  (v_{j+1}, v_{j+2} are only needed by the x
+        // entries: loaded behind the u entries -- kept live across them, the 42 fragment values were spilled to scratch and
+        // every reload waited for all outstanding loads and stores.)
+        double an[2][7];
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -318,28 +321,28 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
                 const int j = j0 + 16 * I + c16, k = 4 * ks + g;
                 const bool kk = k < N;
                 const double t0 = vec[(kk && j < T ? j : 0) * N + (kk ? k : 0)];
-                const double t1 = vec[(kk && j + 1 < T ? j + 1 : 0) * N + (kk ? k : 0)];
-                const double t2 = vec[(kk && j + 2 < T ? j + 2 : 0) * N + (kk ? k : 0)];
                 an[I][ks] = (kk && j < T) ? t0 : 0.0;
-                a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
-                a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
             }
         // ---- u entries: G[j][c] = sum_k v_j[k] B[k][c].  The inputs of column block J + 1 are requested before the
         //      results of block J are stored (a load issued behind a store waits for it: vmcnt is in order).
         const int NJ = (m + 15) >> 4;
-        double zu[8], in0[8], zun[8], in0n[8];
-        {
-            const int cc = c16 < m ? c16 : 0;
+        // Element offsets of this lane's 8 values in z (stride s) and in the m-wide workspace array (stride m), as plain ints:
+        // column block J adds the constant 16 J, which ends up in the instruction's offset field.  The columns of a partial
+        // last block (c >= m) are read as they lie -- z has the x entries of the stage there, the workspace its next row --
+        // and masked afterwards: a select on the index gave every block its own 64-bit addresses, which were spilled and
+        // reloaded around every load.
+        int zo[8], ro[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                zu[e] = zs[sj[e] * s + cc];
-                in0[e] = MODE == 1 ? W.rdu[sj[e] * m + cc] : 0.0;
-            }
+        for (int e = 0; e < 8; ++e) { zo[e] = sj[e] * s + c16; ro[e] = sj[e] * m + c16; }
+        double zu[8], in0[8], zun[8], in0n[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            zu[e] = zs[zo[e]];
+            in0[e] = MODE == 1 ? W.rdu[ro[e]] : 0.0;
         }
-        for (int J = 0; J < NJ; ++J) {
+        auto utile = [&](const int J) {
             const int c = 16 * J + c16;
             const bool cok = c < m;
-            const int cc = cok ? c : 0;
             d4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
             const fw_clds_t br = sBt + c * FW_LDB + g;            // rows >= m of B' are zero padding
 #pragma unroll
@@ -348,14 +351,14 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
                 g0 = MFMA64(an[0][ks], bb, g0);
                 g1 = MFMA64(an[1][ks], bb, g1);
             }
-            const double cmax = umaxp[cc], cmin = uminp[cc], cr2 = R2p[cc], crl = MODE == 0 ? rlp[cc] : 0.0;
+            // (per-column constants by the same rule: lane offset + constant; beyond m they read the pool's next array, masked)
+            const double cmax = umaxp[c16 + 16 * J], cmin = uminp[c16 + 16 * J], cr2 = R2p[c16 + 16 * J], crl = MODE == 0 ? rlp[c16 + 16 * J] : 0.0;
             {
-                const int cn = 16 * (J + 1 < NJ ? J + 1 : J) + c16;
-                const int ccn = cn < m ? cn : 0;
+                const int jn = 16 * (J + 1 < NJ ? J + 1 : J);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    zun[e] = zs[sj[e] * s + ccn];
-                    in0n[e] = MODE == 1 ? W.rdu[sj[e] * m + ccn] : 0.0;
+                    zun[e] = zs[zo[e] + jn];
+                    in0n[e] = MODE == 1 ? W.rdu[ro[e] + jn] : 0.0;
                 }
             }
             double o0[8], o1[8];
@@ -384,14 +387,37 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (cok && sok[e]) {
-                    W.rdu[sj[e] * m + c] = o0[e];
-                    if (MODE == 1) W.zp[sj[e] * s + c] = o1[e];
+                    W.rdu[ro[e] + 16 * J] = o0[e];
+                    if (MODE == 1) W.zp[zo[e] + 16 * J] = o1[e];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { zu[e] = zun[e]; in0[e] = in0n[e]; }
+        };
+        // The first 9 column blocks (m <= 144: all of them) are straight-line code: across a loop's back-edge the compiler waits
+        // for vmcnt(0), i.e. for the 16 stores of the previous block, before it touches the values requested for this one.
+#ifdef FW_CT_UNROLL
+#pragma unroll
+        for (int J = 0; J < 9; ++J) {
+            if (J < NJ) utile(J);
         }
+        for (int J = 9; J < NJ; ++J) utile(J);
+#else
+        for (int J = 0; J < NJ; ++J) utile(J);
+#endif
         // ---- x entries (x_jx, jx = j+1 for stage column j): H[j][r] = sum_k v_{j+1}[k] A1[k][r] + v_{j+2}[k] A2[k][r]
+        double a1[2][7], a2[2][7];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
+                const bool kk = k < N;
+                const double t1 = vec[(kk && j + 1 < T ? j + 1 : 0) * N + (kk ? k : 0)];
+                const double t2 = vec[(kk && j + 2 < T ? j + 2 : 0) * N + (kk ? k : 0)];
+                a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
+                a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
+            }
         d4 h[2][2];
         double cq2[2], cqf2[2], cql[2], cqfl[2], vprev[2][8], vxf[2][8], xin[2][8], zx[2][8];
 #pragma unroll
@@ -468,7 +494,7 @@ FW_FN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
 // Both products share the operand tiles of B (LDS), A1, A2; the exit test that sits between them in the reference
 // (inf_newton_solver.m:19-22) is taken by the caller from out1 -- rhs is then simply not used.
 template <int N>
-FW_FN void fw_phase_C2(FwKP Pin, int p, double* lds_g, double* out1_g, int first) {
+FW_IN void fw_phase_C2(FwKP Pin, int p, double* lds_g, double* out1_g, int first) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     first = __builtin_amdgcn_readfirstlane(first);
@@ -1028,7 +1054,7 @@ FW_FN void fw_cold_nu_update(FwKP Pin, int p, double* lds_g, double t) {
 // ------------------------------------------------------------------------------------------------
 // P3: block-penta-diagonal Cholesky of Y fused with the forward sweep (inf_newton_solver.m:27,30-31)
 template <int N>
-FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
+FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
     using C = FwCfg<N>;
     constexpr int LD = C::LD, LDG = C::LDG, RC = C::RC;
     const FwKP P = fw_uniform(Pin);
@@ -1063,22 +1089,36 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
         const double* img = imgs + (size_t)P->V.iD[i] * C::IMG_STRIDE + lane;
         const double* img1 = imgs + (size_t)P->V.i1[i] * C::IMG_STRIDE + C::IMG_D + lane;
         const double* img2 = imgs + (size_t)P->V.i2[i] * C::IMG_STRIDE + C::IMG_D + C::IMG_1;
-        d4 S00, S01, S11;
+        // Everything this stage reads from memory is REQUESTED here and CONSUMED behind the 108 products below (3.7 us): the
+        // constant tiles and the rhs column are added to S afterwards.  (A load waits for every older store of the wave --
+        // vmcnt is in order -- and the previous stage has just issued 54 factor stores: consumed here, each stage would
+        // stand still until those are written.)
+        d4 I00, I01, I11;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            S00[r] = img[(0 * 4 + r) * 64];
-            S01[r] = img[(1 * 4 + r) * 64];
-            S11[r] = img[(2 * 4 + r) * 64];
+            I00[r] = img[(0 * 4 + r) * 64];
+            I01[r] = img[(1 * 4 + r) * 64];
+            I11[r] = img[(2 * 4 + r) * 64];
         }
-        if (c16 == RC - 16) {                    // rhs_i rides in column n of the tile
+        d4 M00, M01, M10, M11;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            M00[r] = img1[(0 * 4 + r) * 64];
+            M01[r] = img1[(1 * 4 + r) * 64];
+            M10[r] = img1[(2 * 4 + r) * 64];
+            M11[r] = img1[(3 * 4 + r) * 64];
+        }
+        double rh0[4], rh1[4];                   // rhs_i rides in column n of the tile
+        {
             const double* rh = W.rhs + i * N;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                S01[r] = rh[4 * r + g];
+                rh0[r] = rh[4 * r + g];
                 const int row1 = 16 + 4 * r + g;
-                S11[r] = rh[row1 < N ? row1 : N - 1];
+                rh1[r] = rh[row1 < N ? row1 : N - 1];
             }
         }
+        d4 S00 = {0, 0, 0, 0}, S01 = {0, 0, 0, 0}, S11 = {0, 0, 0, 0};
         // ---- S += B Rt_i^-1 B'  (K = m; three subtiles by symmetry; chunks of FW_KCH k-steps).
         //      (No software pipelining against the VALU loop below: on gfx950 the fp64 MFMA and
         //      VALU instructions of a SIMD do not execute concurrently -- measured, see DESIGN.md.)
@@ -1122,15 +1162,17 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
                 }
             }
         }
-        // ---- S -= Ua'Ua + Uc'Uc ;  M1 = Y_{i,i+1} - Ua'Ub
-        d4 M00, M01, M10, M11;
+        // ---- S += constant part (column n: the rhs; B has no row n, so the products left that column zero)
+        {
+            const bool isr = c16 == RC - 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            M00[r] = img1[(0 * 4 + r) * 64];
-            M01[r] = img1[(1 * 4 + r) * 64];
-            M10[r] = img1[(2 * 4 + r) * 64];
-            M11[r] = img1[(3 * 4 + r) * 64];
+            for (int r = 0; r < 4; ++r) {
+                S00[r] += I00[r];
+                S01[r] = isr ? rh0[r] : S01[r] + I01[r];
+                S11[r] = isr ? rh1[r] : S11[r] + I11[r];
+            }
         }
+        // ---- S -= Ua'Ua + Uc'Uc ;  M1 = Y_{i,i+1} - Ua'Ub
 #pragma unroll
         for (int Ix = 0; Ix < 2; ++Ix)
 #pragma unroll
@@ -1339,7 +1381,7 @@ FW_FN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
 // The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
 // and turned to the row-/column-per-lane layouts through this wave's LDS tile.
 template <int N>
-FW_FN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
+FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, LD = C::LD;
     const FwKP P = fw_uniform(Pin);
@@ -1527,7 +1569,7 @@ FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
 // ------------------------------------------------------------------------------------------------
 // nu += t d_nu   (backtracking_inf_newton.m:11); every load before the first store
 template <int N>
-FW_FN void fw_phase_nu_update(FwKP Pin, int p, double t) {
+FW_IN void fw_phase_nu_update(FwKP Pin, int p, double t) {
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     const FwView<N> W(P, p);
@@ -1585,6 +1627,60 @@ FW_FN void fw_phase_zcopy(FwKP Pin, int p) {
     }
     fw_mem_fence();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The phases of a Newton iteration as THREE non-inlined functions (own register allocation each).  A non-inlined function
+// that uses all 256 registers saves and restores the ~112 callee-saved ones on every call: 57 KB of scratch traffic per
+// call and problem, which is HBM traffic at 2048 resident problems -- seven calls per iteration were 0.4 MB per problem,
+// a quarter of everything the kernel moved (rocprofv3 FETCH_SIZE / WRITE_SIZE against the byte count of the algorithm).
+//   pre : [start point,] r_d, r_p, norms, right-hand side          out: red[0] = |r_d|^2, red[1] = |r_p|^2, red[2] = Phi not PD
+//   mid : factorisation + forward sweep, backward sweep             returns "Y not PD"
+//   post: d_z with the new iterate for t = 1, line-search dots, nu += t d_nu (the caller passes t back in a second call
+//         only in the rare case t != 1: fw_phase_zfix)
+template <int N>
+FW_FN void fw_phase_pre(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
+    do_init = __builtin_amdgcn_readfirstlane(do_init);
+    if (do_init >= 0) fw_phase_init<N>(Pin, p, do_init);
+    fw_phase_CT<N, 0>(Pin, p, lds_g, red_g, first);
+    fw_phase_C2<N>(Pin, p, lds_g, red_g + 1, first);
+}
+template <int N>
+FW_FN int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
+    const int npd = fw_phase_factor<N>(Pin, p, lds_g, first);
+    const FwKP P = fw_uniform(Pin);
+    if (P->mode == FW_MODE_EXPORT && (threadIdx.x & 63) == 0) *P->sh_ok = npd ? 0 : 1;
+    if (npd) return 1;
+    fw_phase_backward<N>(Pin, p, lds_g);
+    return 0;
+}
+template <int N> FW_FN void fw_phase_zfix(FwKP Pin, int p, double t);
+// out: red[0] = accepted step length t, red[1] = 1 if the search collapsed (FMPC_W_LINESEARCH)
+template <int N>
+FW_FN void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int first, double rho2) {
+    fw_phase_CT<N, 1>(Pin, p, lds_g, red_g, first);
+    const fw_lds_t red = (fw_lds_t)red_g;
+    fw_wave_fence();
+    const double beta_e = red[0], eps2 = red[1];
+    fw_wave_fence();
+    double t = 1.0, collapsed = 0.0;
+    {
+        const double al = 1e-4;
+        int halv = 0;
+        while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
+            const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2 - 2.0 * (1.0 - t) * beta_e + t * eps2;
+            if (gq <= 0.0) break;
+            t *= 0.5;
+            if (++halv >= FW_MAX_HALVINGS) { t = 0.0; collapsed = 1.0; break; }
+        }
+    }
+    if (t != 1.0) fw_phase_zfix<N>(Pin, p, t);
+    fw_phase_nu_update<N>(Pin, p, t);
+    if ((threadIdx.x & 63) == 0) { red[0] = t; red[1] = collapsed; }
+    fw_wave_fence();
+}
+// the start point / b / nu of a problem outside the merged functions (cold-start path)
+template <int N>
+FW_FN void fw_phase_init_fn(FwKP Pin, int p, int write_z) { fw_phase_init<N>(Pin, p, write_z); }
 
 // Panel path: step-length / exit decision of problem p from what the two panel kernels left behind.
 // The line search (backtracking_inf_newton.m:2-11) accepts t = 1 iff ||e||^2 <= (1-alpha)^2 rho^2
@@ -1719,7 +1815,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             double rho2 = 0.0;
             int go = 0;
             if (active && !accepted) {
-                fw_phase_init<N>(P, p, 0);
+                fw_phase_init_fn<N>(P, p, 0);
                 FW_KTICK(0);
                 fw_cold_resid<N>(P, p, lds, red);
                 fw_wave_fence();
@@ -1768,7 +1864,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             }
             if (active && accepted) {
                 // continue after the panel kernels' step: b, the step record, and nu+ from the panel workspace
-                fw_phase_init<N>(P, p, 0);
+                fw_phase_init_fn<N>(P, p, 0);
                 const FwView<N> W(P, p);
                 const int nbn = W.nb * N;
                 const double* src = P->nuws + ((size_t)(p >> 4) * nbn) * 16 + (p & 15);
@@ -1778,56 +1874,35 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
                 nsteps = 1;
             }
             it0 = 1;
-        } else if (active) {
-            fw_phase_init<N>(P, p, P->zinit ? 0 : 1);       // an explicit start point is read where it lies (FwView::zs)
-            FW_KTICK(0);
         }
+        int do_init = (!cold_mode && active) ? (P->zinit ? 0 : 1) : -1;       // an explicit start point is read where it lies (FwView::zs)
         for (int it = it0; it < max_iter && !done; ++it) {
             const int first = (P->zinit != nullptr && nsteps == 0) ? 1 : 0;     // z_out not written yet: read z_init
-            fw_phase_CT<N, 0>(P, p, lds, red, first);       // r_d
+            fw_phase_pre<N>(P, p, lds, red, first, do_init);               // [start,] r_d, r_p, right-hand side
+            do_init = -1;
             fw_wave_fence();
-            const double rd2 = red[0];
+            const double rd2 = red[0], rp2 = red[1];
             const bool bad = red[2] != 0.0;
-            fw_wave_fence();
-            fw_phase_C2<N>(P, p, lds, red, first);          // r_p and the right-hand side
-            fw_wave_fence();
-            const double rp2 = red[0];
             fw_wave_fence();
             FW_KTICK(1);
             const double rho2 = rd2 + rp2;
             if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
             FW_KTICK(2);
-            const int npd = fw_phase_factor<N>(P, p, lds, first);
-            if (P->mode == FW_MODE_EXPORT && lane == 0) *P->sh_ok = npd ? 0 : 1;
+            const int npd = fw_phase_mid<N>(P, p, lds, first);
             if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
-            FW_KTICK(3);
-            fw_phase_backward<N>(P, p, lds);
             FW_KTICK(4);
-            fw_phase_CT<N, 1>(P, p, lds, red, first);       // d_z, the line-search dots, z + d_z
+            fw_phase_post<N>(P, p, lds, red, first, rho2);  // d_z and z + d_z, line search, nu += t d_nu
             fw_wave_fence();
-            const double beta_e = red[0], eps2 = red[1];
+            const double t = red[0];
+            if (red[1] != 0.0) st = FMPC_W_LINESEARCH;
             fw_wave_fence();
-            double t = 1.0;
-            {
-                const double al = 1e-4;
-                int halv = 0;
-                while (true) {      // closed form of backtracking_inf_newton.m:2-11 (frozen d)
-                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2
-                                      - 2.0 * (1.0 - t) * beta_e + t * eps2;
-                    if (gq <= 0.0) break;
-                    t *= 0.5;
-                    if (++halv >= FW_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
-                }
-            }
-            if (t != 1.0) fw_phase_zfix<N>(P, p, t);
-            fw_phase_nu_update<N>(P, p, t);
             if (P->step && lane == 0 && it < P->step_ld) P->step[(size_t)p * P->step_ld + it] = t;
             ++nsteps;
             FW_KTICK(5);
         }
         if (!active) continue;
-        if (cold_mode && nsteps == 0) fw_phase_init<N>(P, p, 2);       // left before stepping: z is the start point
+        if (cold_mode && nsteps == 0) fw_phase_init_fn<N>(P, p, 2);       // left before stepping: z is the start point
         if (!cold_mode && nsteps == 0 && P->zinit) fw_phase_zcopy<N>(P, p);
         FW_KTICK(6);
         if (P->nuout) {
