@@ -649,7 +649,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             }
             __syncthreads();
             // zero the three U slots: stages 0 and 1 then need no special cases
-            for (int q = tid; q < 2 * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
+            constexpr bool TS = !(sizeof(R) == 8 && NW == 2);       // two U slots (ft_u_slots): see below
+            for (int q = tid; q < (TS ? 2 : 3) * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
             if (tid == 0) sflag[0] = 0;
             __syncthreads();
             FT_TICK(2);
@@ -659,6 +660,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // stage i - 1 holds U2_{i-2} as its Ub and subtracts Ub'Ub from the S0 tiles of stage i, which are already in
             // registers by then (requested two stages ahead).  After phase A both slots are dead and take U1_i, U2_i in place --
             // no rotation, and a third of the factor phase's LDS is gone (95 -> 70 KB at n = 65: two workgroups per CU).
+            // !TS (fp64 with 2 wavefronts, short of registers for the extra tile set): three slots, Uc = U2_{i-2} kept in LDS
+            // and subtracted in the stage itself.
+            int ub = 1, uc = 2;                                     // !TS: roles of the slots 1 and 2
             bool fail = false;
             // Loads queue behind the stores a wave has issued (vmcnt is in order), so everything stage i + 1 needs from
             // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
@@ -686,18 +690,19 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 }
             };
             v4 cS[SS];                                             // S tiles of the current stage (S0_i - U2_{i-2}' U2_{i-2})
-            requestS(0, cS);
-            requestS(nb > 1 ? 1 : 0, nS);
+            if (TS) { requestS(0, cS); requestS(nb > 1 ? 1 : 0, nS); }
+            else requestS(0, nS);                                  // (!TS: no third set, nS is the current stage's at the top of a stage)
             requestM(0);
             for (int i = 0; i < nb; ++i) {
                 R* UA = sSLOT;
-                R* UB = sSLOT + (size_t)NQ * FT_TILE;
+                R* UB = sSLOT + (size_t)(TS ? 1 : ub) * NQ * FT_TILE;
+                R* UC = sSLOT + (size_t)(TS ? 1 : uc) * NQ * FT_TILE;
                 R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
                 const R* Y2 = yimg + (size_t)V.i2[i] * NQ * FT_TILE;
                 // ---------------- phase A: all tiles of the stage, independent
                 v4 aS[SS], aM1[MS];
 #pragma unroll
-                for (int sl = 0; sl < SS; ++sl) aS[sl] = cS[sl];
+                for (int sl = 0; sl < SS; ++sl) aS[sl] = TS ? cS[sl] : nS[sl];
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
 #pragma unroll
@@ -707,7 +712,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
 #pragma unroll 1
                         for (int j = 0; j < NB; ++j) {
                             ft_xtz_sub<R>(aS[sl], UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
-                            ft_xtz_sub<R>(nS[sl], UB + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);   // for S_{i+1}
+                            if (TS) ft_xtz_sub<R>(nS[sl], UB + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);   // for S_{i+1}
+                            else ft_xtz_sub<R>(aS[sl], UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
                         }
                     }
                 }
@@ -723,9 +729,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 }
                 ft_lds_barrier();                                      // Ua, Ub are dead from here: their slots take U1_i, U2_i
                 FT_TICK(3);
-                R* U1N = UA; R* U2N = UB;
+                R* U1N = UA; R* U2N = TS ? UB : UC;
+                if (!TS && i + 1 < nb) requestS(i + 1, nS);
                 if (i + 1 < nb) requestM(i + 1);
-                requestS(i + 2 < nb ? i + 2 : nb - 1, fS);             // (harmless re-read at the end of the horizon)
+                if (TS) requestS(i + 2 < nb ? i + 2 : nb - 1, fS);     // (harmless re-read at the end of the horizon)
                 v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) {
@@ -858,7 +865,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
                 if (fail) break;
                 // next stage: its S tiles are the updated set, the set in flight becomes the next one
 #pragma unroll
-                for (int sl = 0; sl < SS; ++sl) { cS[sl] = nS[sl]; nS[sl] = fS[sl]; }
+                for (int sl = 0; sl < SS; ++sl) { if (TS) { cS[sl] = nS[sl]; nS[sl] = fS[sl]; } }
+                if (!TS) { const int t = ub; ub = uc; uc = t; }        // Ub <- U2_i (slot uc), Uc <- old Ub
             }
             if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
             __syncthreads();                                           // the factor stream and y are in HBM (same workgroup reads them)

@@ -71,15 +71,18 @@ __host__ __device__ static inline FtWs ft_ws_layout(int n, int m, int T, int nb,
 // LDS map in bytes.  One region is used three ways, by phases separated by workgroup barriers:
 //   residual phases   nu / d_nu as [stage][state]: (16 ceil(nb/16) + 2) rows of 16 NB + 1 doubles
 //   G pre-pass        the B' tiles [mb][NB] (B W_i B' for all stages, ahead of the serial factorisation)
-//   factor + sweeps   two U slots (NB^2 tiles each), the R tiles of the stage, W' of the diagonal tile, small vectors
+//   factor + sweeps   two or three U slots (NB^2 tiles each), the R tiles of the stage, W' of the diagonal tile, small vectors
 struct FtLds { size_t bt, slot, lt, wt, ysh, xv, part, wl, red, flag, total; };
 // pr_doubles: dense R only -- the packed lower triangle of Rt_j, the m x (n + 1) right-hand sides, m reciprocal pivots
 __host__ __device__ static inline size_t ft_pr_doubles(int n, int m) { return (size_t)m * (m + 1) / 2 + (size_t)m * (n + 1) + m; }
+// U slots of the factor phase: two (the U2'U2 term of S_i applied one stage ahead, on tiles in registers) except for the
+// fp64 instances with 2 wavefronts, where the extra tile set costs registers the kernel does not have (measured: +9 %)
+__host__ __device__ static inline int ft_u_slots(int real_bytes, int NW) { return (real_bytes == 8 && NW == 2) ? 3 : 2; }
 __host__ __device__ static inline FtLds ft_lds_layout(int NB, int mb, int NW, int real_bytes, int nb, size_t pr_doubles = 0) {
     FtLds L; size_t o = 0;
     const size_t tile = (size_t)FT_TILE * real_bytes;
     L.bt = 0; L.slot = 0;
-    o = 2 * (size_t)NB * NB * tile;                               // two U slots (fmpc_kernel_tiled.hip, P3)
+    o = (size_t)ft_u_slots(real_bytes, NW) * NB * NB * tile;      // the U slots (fmpc_kernel_tiled.hip, P3)
     L.lt = o;   o += (size_t)(NB * (NB + 1) / 2) * tile;
     L.wt = o;   o += (size_t)16 * FT_WLD * real_bytes;
     L.ysh = o;  o += 16 * real_bytes;
