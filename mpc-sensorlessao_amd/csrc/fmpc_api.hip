@@ -76,6 +76,8 @@ struct fmpc_handle_s {
     int wg_per_cu;
     // wave kernel (n = 27): used when available unless FMPC_FORCE_GENERIC=1
     int use_wave;
+    double* fm_forms;            // diagnostic: where the one-step first-move kernel leaves the bounds its decision used (fmpc_debug_first_move_forms)
+    double* fm_compact;          // compact batch of the stopped realisations of a walk (fmpc_loop_run_walk)
     FwModel wave;
     double* wave_pool_d;
     int* wave_pool_i;
@@ -294,7 +296,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0;
+    h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr;
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -550,6 +552,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->inv_jimg2) (void)hipFree(h->inv_jimg2);
     if (h->fm_pool) (void)hipFree(h->fm_pool);
     if (h->fm_need) (void)hipFree(h->fm_need);
+    if (h->fm_compact) (void)hipFree(h->fm_compact);
     if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
@@ -984,7 +987,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
     for (int e = 0; e < TN; ++e)
         for (int q = 0; q < n; ++q) { m12t[(size_t)q * TN + e] = h->hm_m1[(size_t)e * n + q]; m12t[(size_t)(n + q) * TN + e] = h->hm_m2[(size_t)e * n + q]; }
     for (int r = 0; r < n; ++r) dx0T[r] = h->hm_Qf2[r] * h->hm_xmid[r] + h->hm_qfl[r];
-    const size_t oK = push(O.K0t), ou = push(O.u0c), oE = push(O.E), oe = push(O.e), oEp = push(O.Ep), oep = push(O.ep), om = push(m12t), od = push(dx0T);
+    const size_t oK = push(O.K0t), ou = push(O.u0c), oE = push(O.Ec), oe = push(O.e), oEp = push(O.Epc), oep = push(O.ep), om = push(m12t), od = push(dx0T);
     if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
     if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
     if (hipMemcpy(h->fm_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
@@ -1251,9 +1254,7 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
 // the first moves and the step-length decision; a second one (the exact path in flag mode) returns at once unless a
 // realisation was not clear-cut.  FMPC_E_UNSUPPORTED: the caller takes the four-launch path.  Caller holds h->mu.
 #define FMPC_FIRST_MOVE_MAX_BATCH 64
-static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
-                                double* x0, double* x0_pre, double* w, const double* nu0, double k,
-                                int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_t stream, size_t* stride_out) {
     if (h->fm_disabled || !h->use_wave || !h->sh_enabled || !h->pn_enabled || !h->inv_enabled || h->n != FP_N || batch > FMPC_FIRST_MOVE_MAX_BATCH)
         return FMPC_E_UNSUPPORTED;
     size_t stride = 0;
@@ -1284,13 +1285,24 @@ static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, con
     }
     if ((size_t)batch > h->fm_need_cap) {
         if (h->fm_need) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_need); h->fm_need = nullptr; h->fm_need_cap = 0; }
-        if (hipMalloc((void**)&h->fm_need, FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+        if (hipMalloc((void**)&h->fm_need, 3 * FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;   // flags; start, stop of a walk
         h->fm_need_cap = FMPC_FIRST_MOVE_MAX_BATCH;
     }
+    *stride_out = stride;
+    return FMPC_OK;
+}
+
+static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
+                                double* x0, double* x0_pre, double* w, const double* nu0, double k,
+                                int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+    size_t stride = 0;
+    int rc = fmpc_first_move_ensure(h, batch, k, stream, &stride);
+    if (rc != FMPC_OK) return rc;
     FmParams P = h->fm_P;
     P.step_ld = fmpc_step_ld(1);
     P.a_k = a_k; P.x0_last = x0_last; P.u1 = u1; P.u2 = u2; P.nu0 = nu0;
     P.x0 = x0; P.x0_pre = x0_pre; P.w = w; P.u0out = u0_out; P.status = status; P.iters = iters; P.step = step; P.need = h->fm_need;
+    P.forms = h->fm_forms;
     P.handed = h->pn_cnt;                          // zeroed by the kernel; the exact path (next launch) counts what it redoes
     if (fmpc_launch_first_move(P, batch, stream) != hipSuccess) return FMPC_E_HIP;
     // the exact path for flagged realisations (cold start with the shared factor), first moves from its own z
@@ -1345,6 +1357,81 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
 
 // A recorded stretch of the loop in ONE host call: steps consecutive fmpc_loop_step_device calls with the first moves fed back
 // on the device (u[k] = U0[k], u[k-1] = U0[k-1], ...).  See include/fastmpc.h.
+// The steps [0, upto) of a recorded stretch as ONE launch per walk (fmpc_first_move_run): every realisation walks until a step
+// is not clear-cut; the host has that step redone by the one-step call (its exact path) and starts the walk again behind it.
+// Synchronises the stream once per walk (it has to see where the walks stopped).  FMPC_E_UNSUPPORTED: not applicable, nothing done.
+static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, const double* a, const double* nu0,
+                              const double* ub1, const double* ub2, int have_x0_last, double k,
+                              double* x0, double* x0_pre, double* w, double* U0, double* X0, int* status, int* iters, hipStream_t stream) {
+    const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
+    std::vector<int> start(batch, 0), stop(batch, 0), idx, stp;      // (host sides of asynchronous copies: alive until the function returns)
+    for (;;) {
+        {
+            if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+            std::lock_guard<std::mutex> lk(h->mu);
+            int rc = fmpc_guard_begin(h, stream);
+            if (rc != FMPC_OK) return rc;
+            size_t stride = 0;
+            rc = fmpc_first_move_ensure(h, batch, k, stream, &stride);
+            if (rc != FMPC_OK) { fmpc_guard_end(h, stream); return rc; }
+            int* d_start = h->fm_need + FMPC_FIRST_MOVE_MAX_BATCH;
+            int* d_stop = h->fm_need + 2 * FMPC_FIRST_MOVE_MAX_BATCH;
+            FmParams P = h->fm_P;
+            P.step_ld = fmpc_step_ld(1);
+            P.x0 = x0; P.x0_pre = x0_pre; P.status = status; P.iters = iters; P.handed = h->pn_cnt; P.forms = nullptr;
+            FmRun R;
+            R.steps = upto; R.batch = batch; R.have_x0_last = have_x0_last; R.start = d_start; R.stop = d_stop;
+            R.a = a; R.nu0 = nu0; R.U0 = U0; R.X0 = X0; R.ub1 = ub1; R.ub2 = ub2;
+            bool ok = hipMemcpyAsync(d_start, start.data(), batch * sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess;
+            ok = ok && fmpc_launch_first_move_run(P, R, stream) == hipSuccess;
+            ok = ok && hipMemcpyAsync(stop.data(), d_stop, batch * sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess;
+            h->last_path = FMPC_PATH_PANEL; h->inv_last = 1;
+            fmpc_guard_end(h, stream);
+            if (!ok || hipStreamSynchronize(stream) != hipSuccess) return FMPC_E_HIP;
+        }
+        // the stopped realisations, each at its own step, as ONE compact batch through the one-step call (its exact path redoes
+        // them), results scattered back; then the walks go on behind those steps
+        idx.clear(); stp.clear();
+        for (int p = 0; p < batch; ++p) {
+            if (stop[p] >= upto) { start[p] = upto; continue; }
+            idx.push_back(p); stp.push_back(stop[p]);
+            start[p] = stop[p] + 1;
+        }
+        const bool done = idx.empty();
+        if (!done) {
+            const int cnt = (int)idx.size();
+            FmCompact C;
+            C.cnt = cnt; C.n = h->n; C.m = h->m; C.T = h->T; C.nb = h->nb; C.batch = batch; C.have_x0_last = have_x0_last;
+            C.a = a; C.nu0 = nu0; C.U0 = U0; C.X0 = X0; C.ub1 = ub1; C.ub2 = ub2;
+            C.x0 = x0; C.x0_pre = x0_pre; C.w = w; C.status = status; C.iters = iters;
+            {
+                std::lock_guard<std::mutex> lk(h->mu);
+                if (!h->fm_compact) {
+                    const size_t nd = fmpc_compact_doubles(h->n, h->m, h->T, h->nb, FMPC_FIRST_MOVE_MAX_BATCH);
+                    if (hipMalloc((void**)&h->fm_compact, nd * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                }
+                int* d_idx = h->fm_need + FMPC_FIRST_MOVE_MAX_BATCH;          // start / stop slots: free between walks
+                int* d_stp = h->fm_need + 2 * FMPC_FIRST_MOVE_MAX_BATCH;
+                fmpc_compact_carve(C, h->fm_compact, FMPC_FIRST_MOVE_MAX_BATCH);
+                C.idx = d_idx; C.stp = d_stp;
+                if (hipMemcpyAsync(d_idx, idx.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(d_stp, stp.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    fmpc_launch_walk_gather(C, stream) != hipSuccess) return FMPC_E_HIP;
+            }
+            const int rc = fmpc_loop_step_device(h, cnt, C.ca, C.cx0, C.cu1, C.cu2, C.cx0, C.cx0p, C.cw, nu0 ? C.cnu : nullptr, 1, k,
+                                                 nullptr, nullptr, C.cst, C.cit, nullptr, C.cu0, stream);
+            if (rc != FMPC_OK) return rc;
+            if (fmpc_launch_walk_scatter(C, stream) != hipSuccess) return FMPC_E_HIP;
+        }
+        if (getenv("FMPC_DEBUG_WALK")) {
+            int nstop = 0;
+            for (int p = 0; p < batch; ++p) nstop += stop[p] < upto ? 1 : 0;
+            fprintf(stderr, "[fastmpc] walk over %d realisations up to step %d: %d stopped\n", batch, upto, nstop);
+        }
+        if (done) return FMPC_OK;                    // (a restarted walk begins at a step >= 1 of the stretch: x0 holds its predecessor's residual)
+    }
+}
+
 extern "C" int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, const double* nu0,
                                     const double* u_before1, const double* u_before2, int have_x0_last,
                                     int n_newton, double k, double* x0, double* x0_pre, double* w,
@@ -1353,7 +1440,16 @@ extern "C" int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const d
     if (batch < 0 || steps < 0) return FMPC_E_DIM;
     if (batch == 0 || steps == 0) return FMPC_OK;
     const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
-    for (int s = 0; s < steps; ++s) {
+    int s_begin = 0;
+    if (n_newton == 1 && steps >= 3 && batch <= FMPC_FIRST_MOVE_MAX_BATCH && h->n == FP_N && h->inv_jimg2 != nullptr) {
+        // all steps but the last in one launch; the last one by the one-step call, which leaves x0, x0_pre, w, status and
+        // iters exactly as a step-by-step run does
+        const int rc = fmpc_loop_run_walk(h, batch, steps, steps - 1, a, nu0, u_before1, u_before2, have_x0_last, k, x0, x0_pre, w, U0, X0,
+                                          status, iters, (hipStream_t)stream);
+        if (rc == FMPC_OK) s_begin = steps - 1;
+        else if (rc != FMPC_E_UNSUPPORTED) return rc;
+    }
+    for (int s = s_begin; s < steps; ++s) {
         const double* u1 = s >= 1 ? U0 + (size_t)(s - 1) * sm : u_before1;
         const double* u2 = s >= 2 ? U0 + (size_t)(s - 2) * sm : (s == 1 ? u_before1 : u_before2);
         const int rc = fmpc_loop_step_device(h, batch, a + (size_t)s * sn, (s >= 1 || have_x0_last) ? x0 : nullptr, u1, u2, x0, x0_pre, w,
@@ -1362,6 +1458,15 @@ extern "C" int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const d
         if (rc != FMPC_OK) return rc;
         if (X0 && hipMemcpyAsync(X0 + (size_t)s * sn, x0, sn * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
     }
+    return FMPC_OK;
+}
+
+// Diagnostic (tests): the one-step first-move kernel writes, per realisation, the bounds its decision used -- upper bound of
+// ||e||^2, lower bounds of ||r_p||^2 and of rho^2 -- to dev_forms[3 p ..] (device memory, NULL: off).
+extern "C" int fmpc_debug_first_move_forms(fmpc_handle h, double* dev_forms) {
+    if (!h) return FMPC_E_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->fm_forms = dev_forms;
     return FMPC_OK;
 }
 

@@ -504,5 +504,17 @@ void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out) {
     for (size_t i = 0; i < E.size(); ++i) { Out.E[i] = (double)E[i]; Out.Ep[i] = (double)Ep[i]; }   // symmetric: [c][r] == [r][c]
     for (int c = 0; c < nc; ++c) { Out.e[c] = (double)e[c]; Out.ep[c] = (double)ep[c]; }
     Out.e0 = (double)e0; Out.ep0 = (double)ep0;
+    // circulant halves for the kernel: d'E d = sum_r d_r sum_{j=0}^{nc/2} Ec[j][r] d[(r + j) mod nc]  (every unordered pair once;
+    // the pairs at distance nc/2 would come twice: kept for r < nc/2)
+    const int H = nc / 2 + 1;
+    Out.Ec.assign((size_t)H * nc, 0.0); Out.Epc.assign((size_t)H * nc, 0.0);
+    for (int j = 0; j < H; ++j)
+        for (int r = 0; r < nc; ++r) {
+            const int c = (r + j) % nc;
+            const ld wgt = j == 0 ? 1.0L : ((j == nc / 2 && r >= nc / 2) ? 0.0L : 2.0L);
+            const ld se = (E[(size_t)r * nc + c] + E[(size_t)c * nc + r]) * 0.5L, sp = (Ep[(size_t)r * nc + c] + Ep[(size_t)c * nc + r]) * 0.5L;
+            Out.Ec[(size_t)j * nc + r] = (double)(wgt * se);
+            Out.Epc[(size_t)j * nc + r] = (double)(wgt * sp);
+        }
     Out.normE = fro(E); Out.norme = fro(e); Out.normEp = fro(Ep); Out.normep = fro(ep);
 }

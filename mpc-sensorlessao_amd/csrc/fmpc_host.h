@@ -99,7 +99,8 @@ struct FmpcFirstIn {
 };
 struct FmpcFirstOut {
     int nc;                             // 4 n
-    std::vector<double> K0t, u0c, E, e, Ep, ep;
+    std::vector<double> K0t, u0c, E, e, Ep, ep;     // E, Ep: full symmetric nc x nc (checks); the kernel reads the circulant halves:
+    std::vector<double> Ec, Epc;                    // [nc/2 + 1][nc]: Ec[j][r] = w_j E[r][(r + j) mod nc]
     double e0, ep0, normE, norme, normEp, normep;
 };
 void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out);

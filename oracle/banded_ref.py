@@ -285,6 +285,9 @@ class BandedFastMPC:
             if info is not None:
                 info.setdefault("t", []).append(t)
                 info.setdefault("halvings", []).append(halv)
+                info.setdefault("eps2", []).append(eps2)          # the sums the step-length decision rests on
+                info.setdefault("rp2", []).append(float(np.sum(rp * rp)))
+                info.setdefault("rho2", []).append(rho2)
             U += t * du
             Xs += t * dx
             NU += t * dnu

@@ -35,14 +35,16 @@ for R in (1, 16, 64, 512):
         h.close()
 
     h = mk()
-    for rep in range(2):
-        loop = pkg.ClosedLoop(h, R, n_newton=1, k=1e-2, keep_z=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        loop.run_recorded(at, want_x0=False)
-        t_enq = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print("realisations %4d  %-34s %.2f us per loop step  (%.3g MPC steps/s; host enqueue %.2f us per step)"
-          % (R, "recorded stretch, one host call", dt / steps * 1e6, R * steps / dt, t_enq / steps * 1e6))
+    for lsteps in (steps, 4 * steps):
+        al = at.repeat((lsteps + steps - 1) // steps, 1, 1)[:lsteps].contiguous()
+        for rep in range(2):
+            loop = pkg.ClosedLoop(h, R, n_newton=1, k=1e-2, keep_z=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop.run_recorded(al, want_x0=False)
+            t_enq = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print("realisations %4d  %-34s %.2f us per loop step  (%.3g MPC steps/s; %d steps in %.3f ms)"
+              % (R, "recorded stretch, one host call", dt / lsteps * 1e6, R * lsteps / dt, lsteps, dt * 1e3))
     h.close()

@@ -181,6 +181,37 @@ int main(int argc, char** argv) {
     // a zero image (id nb) must be all zero
     for (int q = 0; q < FP_IMGL; ++q) if (limg[(size_t)nb * FP_IMGL + q] != 0.0) return fail("zero image");
 
+    // ---- first-move form (fmpc_host_build_first_move): sizes, symmetry of E / Ep, and the circulant halves the kernel reads:
+    //      sum_r d_r sum_j Ec[j][r] d[(r + j) mod nc] == d'E d  (a random J: the identity does not depend on what J means)
+    {
+        const int nc = 4 * n, H = nc / 2 + 1;
+        std::vector<double> J((size_t)nb * n * nc), nuc((size_t)nb * n), m1((size_t)T * nn), m2((size_t)T * nn);
+        for (auto& v : J) v = 0.1 * N01(rng);
+        for (auto& v : nuc) v = 0.1 * N01(rng);
+        for (auto& v : m1) v = 0.3 * N01(rng);
+        for (auto& v : m2) v = 0.3 * N01(rng);
+        FmpcFirstIn Fi;
+        Fi.n = n; Fi.m = m; Fi.T = T; Fi.nb = nb; Fi.var2 = var2 ? 1 : 0; Fi.has_xf = has_xf;
+        Fi.bt = bt.data(); Fi.umax = umax.data(); Fi.umin = umin.data(); Fi.umid = umid.data(); Fi.xmid = xmid.data(); Fi.R2 = R2.data(); Fi.rl = rl.data();
+        Fi.a1 = a1.data(); Fi.a2 = a2.data(); Fi.m1 = m1.data(); Fi.m2 = m2.data(); Fi.xf = xf.data(); Fi.J = J.data(); Fi.nuc = nuc.data(); Fi.k = k;
+        FmpcFirstOut Fo;
+        fmpc_host_build_first_move(Fi, Fo);
+        if (Fo.nc != nc || Fo.K0t.size() != (size_t)nc * m || Fo.u0c.size() != (size_t)m || Fo.E.size() != (size_t)nc * nc || Fo.Ep.size() != (size_t)nc * nc ||
+            Fo.e.size() != (size_t)nc || Fo.ep.size() != (size_t)nc || Fo.Ec.size() != (size_t)H * nc || Fo.Epc.size() != (size_t)H * nc) return fail("first-move form: sizes");
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<double>& F = pass ? Fo.Ep : Fo.E; const std::vector<double>& Fc = pass ? Fo.Epc : Fo.Ec;
+            ld asym = 0.0L, nrmF = 0.0L;
+            for (int r = 0; r < nc; ++r) for (int c = 0; c < nc; ++c) { const ld d = (ld)F[(size_t)r * nc + c] - (ld)F[(size_t)c * nc + r]; asym += d * d; nrmF += (ld)F[(size_t)r * nc + c] * F[(size_t)r * nc + c]; }
+            if (!(nrmF > 0.0L) || sqrtl(asym / nrmF) > 1e-12L) return fail("first-move form: E / Ep not symmetric");
+            std::vector<ld> d(nc);
+            for (auto& v : d) v = N01(rng);
+            ld full = 0.0L, circ = 0.0L, scale = 0.0L;
+            for (int r = 0; r < nc; ++r) for (int c = 0; c < nc; ++c) { const ld t = d[r] * (ld)F[(size_t)r * nc + c] * d[c]; full += t; scale += fabsl(t); }
+            for (int r = 0; r < nc; ++r) { ld srow = 0.0L; for (int j = 0; j < H; ++j) srow += (ld)Fc[(size_t)j * nc + r] * d[(r + j) % nc]; circ += d[r] * srow; }
+            if (fabsl(full - circ) > 1e-12L * scale) { fprintf(stderr, "d'Ed %.17Lg vs circulant %.17Lg\n", full, circ); return fail("first-move form: circulant half does not reproduce d'E d"); }
+        }
+    }
+
     // ---- the model cache of the one-shot entry: capacity 4, least recently used goes first
     {
         int destroyed = 0, last = -1;

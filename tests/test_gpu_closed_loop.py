@@ -239,4 +239,86 @@ def test_recorded_stretch_in_one_call(pkg, gpu, R):
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([U1, U2]), Ua) and torch.equal(torch.cat([X1, X2]), Xa)
     assert int(lb.status.abs().sum()) == 0
+    # the state a following step starts from is the step-by-step run's
+    assert torch.equal(lb.x0, la.x0) and torch.equal(lb.x0_pre, la.x0_pre) and torch.equal(lb.w, la.w)
+    assert torch.equal(lb.iters, la.iters)
+    ua = la.step(at[0]); ub = lb.step(at[0])
+    torch.cuda.synchronize()
+    assert torch.equal(ua, ub)
     h1.close(); h2.close()
+
+
+def test_recorded_stretch_with_steps_the_exact_path_redoes(pkg, gpu):
+    """Tight bounds (see test_first_move_form_hands_unclear_realisations_to_the_exact_path): the one-launch walk of
+    fmpc_loop_run_device stops at the steps that are not clear-cut, the exact path redoes them and the walk goes on behind
+    them -- same results as one call per step, bit for bit, and the oracle loop to 1e-8."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10)
+    # bounds at the width where the decision tips (+-0.22: every step of every realisation is handed over, +-0.25: none) and
+    # realisations of different strength: single realisations stop at single steps
+    md["u_min"] = -0.24 * np.ones(144); md["u_max"] = 0.24 * np.ones(144)
+    R, steps = 5, 12
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    a *= np.array([0.05, 0.3, 1.0, 2.0, 5.0])[None, :, None]
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2, keep_z=False)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa, handed = [], [], []
+    for s_ in range(steps):
+        Ua.append(la.step(at[s_]).clone()); Xa.append(la.x0.clone())
+        torch.cuda.synchronize()
+        handed.append(h1.last_dispatch()[1])
+    Ua, Xa = torch.stack(Ua), torch.stack(Xa)
+    assert 0 < sum(1 for c_ in handed[:-1] if c_ > 0), "no step before the last was handed over: the case does not test the stops"
+    assert any(c_ == 0 for c_ in handed), "every step stops some realisation: the walk never walks (%s)" % handed
+    assert any(0 < c_ < R for c_ in handed[:-1]), "no step stops only part of the realisations: %s" % handed
+    Ub, Xb = lb.run_recorded(at)
+    torch.cuda.synchronize()
+    assert torch.equal(Ub, Ua) and torch.equal(Xb, Xa)
+    assert torch.equal(lb.x0, la.x0) and torch.equal(lb.x0_pre, la.x0_pre) and torch.equal(lb.w, la.w)
+    assert torch.equal(lb.status, la.status) and torch.equal(lb.iters, la.iters)
+    U0, X0 = Ub.cpu().numpy(), Xb.cpu().numpy()
+    for r in range(R):
+        ref = closed_loop(md, a[:, r], 1, 1e-2)
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    h1.close(); h2.close()
+
+
+@pytest.mark.parametrize("ub", [0.4, 2.0])
+def test_first_move_decision_forms_against_the_oracle(pkg, gpu, ub):
+    """The two quadratic forms the first-move kernel decides on -- ||e||^2 (k P'DP d_z of the full step) and ||r_p||^2 -- against
+    the same sums of the oracle's Newton step, realisation by realisation over a few fed-back steps (diagnostic output of the
+    kernel: upper bound of the first, lower bound of the second, both within the rounding guard)."""
+    import ctypes as C
+    import torch
+    from oracle.banded_ref import BandedFastMPC
+    md = pkg.synthetic.make_model(27, 144, 10)
+    md["u_min"] = -ub * np.ones(144); md["u_max"] = ub * np.ones(144)
+    R, steps = 4, 4
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    h = handle_from_model(pkg, md)
+    forms = torch.zeros((R, 3), dtype=torch.float64, device=at.device)
+    fn = h._lib.fmpc_debug_first_move_forms
+    fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
+    assert fn(h._h, C.c_void_p(forms.data_ptr())) == 0
+    lp = pkg.ClosedLoop(h, R, n_newton=1, k=1e-2, keep_z=False)
+    orc = BandedFastMPC(md["A1"], md["A2"], md["B"], md["Q"], md["R"], md["Qf"], md["u_min"], md["u_max"], md["x_min"], md["x_max"], 10)
+    worst_e, worst_p = 0.0, 0.0
+    for s_ in range(steps):
+        lp.step(at[s_])
+        torch.cuda.synchronize()
+        f = forms.cpu().numpy()
+        x0, x0p, w = lp.x0.cpu().numpy(), lp.x0_pre.cpu().numpy(), lp.w.cpu().numpy()
+        for r in range(R):
+            info = {}
+            orc.solve(x0[r], x0p[r], w[r], 1, 1e-2, info=info)
+            eps2, rp2 = info["eps2"][0], info["rp2"][0]
+            guard = 1e-9 * (eps2 + rp2 + 1.0)
+            assert f[r, 0] >= eps2 - guard and f[r, 1] <= rp2 + guard, (s_, r, f[r], eps2, rp2)
+            worst_e = max(worst_e, abs(f[r, 0] - eps2) / (eps2 + 1e-30)); worst_p = max(worst_p, abs(f[r, 1] - rp2) / (rp2 + 1e-30))
+            assert f[r, 2] <= info["rho2"][0] * (1 + 1e-9)
+    assert fn(h._h, None) == 0
+    assert worst_e <= 1e-6 and worst_p <= 1e-6, (worst_e, worst_p)
+    h.close()
