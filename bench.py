@@ -510,7 +510,7 @@ def _main(real_out):
                 assert int(loop.status.abs().sum()) == 0
                 cl["realisations_%d%s" % (R_, "" if keep_z else "_u0_only")] = {
                     "value": R_ * nsteps_ / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / nsteps_ * 1e3, "sequential_steps": nsteps_}
-        for R_ in (1, 16, 64):                            # a recorded stretch in ONE host call (fmpc_loop_run_device): all steps but the last
+        for R_ in (1, 16, 64, 512):                       # a recorded stretch in ONE host call (fmpc_loop_run_device): all steps but the last
             nst = 1000                                        # in ONE launch (the walk of fmpc_kernel_first.hip), the last by the one-step call
             a_np = np.stack([pkg.synthetic.make_realisation(model, r=r_, steps=nst)[1:nst + 1] for r_ in range(R_)], axis=1)
             a_t = torch.from_numpy(np.ascontiguousarray(a_np)).to(dev)

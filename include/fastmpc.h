@@ -220,10 +220,11 @@ int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const dou
  * the two steps before this stretch, have_x0_last != 0: x0 holds the previous step's residual (continuing an earlier stretch).
  * z is not produced (first moves only); status / iters hold the last step's values.  The host then spends one call, not one
  * per timestep: a sequential loop of a few realisations is otherwise bound by the host.
- * Up to 64 realisations with n_newton = 1 (and the first-move form available) all steps but the last run in ONE launch: the
+ * Up to 4096 realisations with n_newton = 1 (and the first-move form available) all steps but the last run in ONE launch: the
  * workgroup of a realisation keeps its rows of the first-move form in registers and walks through the steps (3 us per step
  * at (27, 144, 30)); a step whose step-length decision is not clear-cut ends that walk, the exact path redoes the step and the
- * walk goes on behind it -- same results as one call per step, bit for bit.  In that case the call SYNCHRONISES the stream
+ * walk goes on behind it -- same results as one call per step (bit for bit up to 64 realisations, where the one-step call
+ * uses the same form; to rounding, 1e-13, beyond).  In that case the call SYNCHRONISES the stream
  * (the host has to see where the walks stopped): the results are complete when it returns.
  */
 int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, const double* nu0,

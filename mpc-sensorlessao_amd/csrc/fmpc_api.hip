@@ -78,6 +78,7 @@ struct fmpc_handle_s {
     int use_wave;
     double* fm_forms;            // diagnostic: where the one-step first-move kernel leaves the bounds its decision used (fmpc_debug_first_move_forms)
     double* fm_compact;          // compact batch of the stopped realisations of a walk (fmpc_loop_run_walk)
+    int* fm_walk_i; size_t fm_walk_cap;   // start / stop step per realisation of a walk
     FwModel wave;
     double* wave_pool_d;
     int* wave_pool_i;
@@ -296,7 +297,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
-    h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr;
+    h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -553,6 +554,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->fm_pool) (void)hipFree(h->fm_pool);
     if (h->fm_need) (void)hipFree(h->fm_need);
     if (h->fm_compact) (void)hipFree(h->fm_compact);
+    if (h->fm_walk_i) (void)hipFree(h->fm_walk_i);
     if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
@@ -1254,6 +1256,7 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
 // the first moves and the step-length decision; a second one (the exact path in flag mode) returns at once unless a
 // realisation was not clear-cut.  FMPC_E_UNSUPPORTED: the caller takes the four-launch path.  Caller holds h->mu.
 #define FMPC_FIRST_MOVE_MAX_BATCH 64
+#define FMPC_WALK_MAX_BATCH 4096          // realisations of a one-launch walk (fmpc_loop_run_walk): one workgroup each
 static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_t stream, size_t* stride_out) {
     if (h->fm_disabled || !h->use_wave || !h->sh_enabled || !h->pn_enabled || !h->inv_enabled || h->n != FP_N || batch > FMPC_FIRST_MOVE_MAX_BATCH)
         return FMPC_E_UNSUPPORTED;
@@ -1285,7 +1288,7 @@ static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_
     }
     if ((size_t)batch > h->fm_need_cap) {
         if (h->fm_need) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_need); h->fm_need = nullptr; h->fm_need_cap = 0; }
-        if (hipMalloc((void**)&h->fm_need, 3 * FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;   // flags; start, stop of a walk
+        if (hipMalloc((void**)&h->fm_need, FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
         h->fm_need_cap = FMPC_FIRST_MOVE_MAX_BATCH;
     }
     *stride_out = stride;
@@ -1372,10 +1375,21 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
             int rc = fmpc_guard_begin(h, stream);
             if (rc != FMPC_OK) return rc;
             size_t stride = 0;
-            rc = fmpc_first_move_ensure(h, batch, k, stream, &stride);
+            rc = fmpc_first_move_ensure(h, 1, k, stream, &stride);
+            if (rc == FMPC_OK && (size_t)batch > h->fm_walk_cap) {
+                (void)hipDeviceSynchronize();
+                if (h->fm_walk_i) (void)hipFree(h->fm_walk_i);
+                if (h->fm_compact) (void)hipFree(h->fm_compact);
+                h->fm_walk_i = nullptr; h->fm_compact = nullptr; h->fm_walk_cap = 0;
+                size_t cap = 64;
+                while (cap < (size_t)batch) cap *= 2;
+                const size_t nd = fmpc_compact_doubles(h->n, h->m, h->T, h->nb, (int)cap);
+                if (hipMalloc((void**)&h->fm_walk_i, 2 * cap * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->fm_compact, nd * sizeof(double)) != hipSuccess) rc = FMPC_E_ALLOC;
+                else h->fm_walk_cap = cap;
+            }
             if (rc != FMPC_OK) { fmpc_guard_end(h, stream); return rc; }
-            int* d_start = h->fm_need + FMPC_FIRST_MOVE_MAX_BATCH;
-            int* d_stop = h->fm_need + 2 * FMPC_FIRST_MOVE_MAX_BATCH;
+            int* d_start = h->fm_walk_i;
+            int* d_stop = h->fm_walk_i + h->fm_walk_cap;
             FmParams P = h->fm_P;
             P.step_ld = fmpc_step_ld(1);
             P.x0 = x0; P.x0_pre = x0_pre; P.status = status; P.iters = iters; P.handed = h->pn_cnt; P.forms = nullptr;
@@ -1406,13 +1420,9 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
             C.x0 = x0; C.x0_pre = x0_pre; C.w = w; C.status = status; C.iters = iters;
             {
                 std::lock_guard<std::mutex> lk(h->mu);
-                if (!h->fm_compact) {
-                    const size_t nd = fmpc_compact_doubles(h->n, h->m, h->T, h->nb, FMPC_FIRST_MOVE_MAX_BATCH);
-                    if (hipMalloc((void**)&h->fm_compact, nd * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
-                }
-                int* d_idx = h->fm_need + FMPC_FIRST_MOVE_MAX_BATCH;          // start / stop slots: free between walks
-                int* d_stp = h->fm_need + 2 * FMPC_FIRST_MOVE_MAX_BATCH;
-                fmpc_compact_carve(C, h->fm_compact, FMPC_FIRST_MOVE_MAX_BATCH);
+                int* d_idx = h->fm_walk_i;                                     // start / stop slots: free between walks
+                int* d_stp = h->fm_walk_i + h->fm_walk_cap;
+                fmpc_compact_carve(C, h->fm_compact, (int)h->fm_walk_cap);
                 C.idx = d_idx; C.stp = d_stp;
                 if (hipMemcpyAsync(d_idx, idx.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
                     hipMemcpyAsync(d_stp, stp.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
@@ -1441,7 +1451,7 @@ extern "C" int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const d
     if (batch == 0 || steps == 0) return FMPC_OK;
     const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
     int s_begin = 0;
-    if (n_newton == 1 && steps >= 3 && batch <= FMPC_FIRST_MOVE_MAX_BATCH && h->n == FP_N && h->inv_jimg2 != nullptr) {
+    if (n_newton == 1 && steps >= 3 && batch <= FMPC_WALK_MAX_BATCH && h->n == FP_N && h->inv_jimg2 != nullptr) {
         // all steps but the last in one launch; the last one by the one-step call, which leaves x0, x0_pre, w, status and
         // iters exactly as a step-by-step run does
         const int rc = fmpc_loop_run_walk(h, batch, steps, steps - 1, a, nu0, u_before1, u_before2, have_x0_last, k, x0, x0_pre, w, U0, X0,

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 model = pkg.synthetic.make_model(27, 144, 30)
 mk = lambda: pkg.FastMPCHandle(model["A1"], model["A2"], model["B"], model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"],
                                model["x_min"], model["x_max"], 30)
-for R in (1, 16, 64, 512):
+for R in (1, 64, 512, 2048):
     a = np.stack([pkg.synthetic.make_realisation(model, r=r, steps=steps)[1:steps + 1] for r in range(min(R, 8))], axis=1)
     a = np.ascontiguousarray(np.tile(a, (1, (R + a.shape[1] - 1) // a.shape[1], 1))[:, :R])
     at = torch.from_numpy(a).to(dev)

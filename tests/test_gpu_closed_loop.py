@@ -220,7 +220,7 @@ def test_first_move_form_hands_unclear_realisations_to_the_exact_path(pkg, gpu):
     h1.close(); h2.close()
 
 
-@pytest.mark.parametrize("R", [1, 7])
+@pytest.mark.parametrize("R", [1, 7, 130])
 def test_recorded_stretch_in_one_call(pkg, gpu, R):
     """fmpc_loop_run_device: a recorded stretch of the loop in one host call == the same steps one call at a time, bit for bit
     (same kernels in the same order), also when the stretch continues an earlier one."""
@@ -237,14 +237,20 @@ def test_recorded_stretch_in_one_call(pkg, gpu, R):
     U1, X1 = lb.run_recorded(at[:4].contiguous(), nu0[:4].contiguous())
     U2, X2 = lb.run_recorded(at[4:].contiguous(), nu0[4:].contiguous())
     torch.cuda.synchronize()
-    assert torch.equal(torch.cat([U1, U2]), Ua) and torch.equal(torch.cat([X1, X2]), Xa)
     assert int(lb.status.abs().sum()) == 0
-    # the state a following step starts from is the step-by-step run's
-    assert torch.equal(lb.x0, la.x0) and torch.equal(lb.x0_pre, la.x0_pre) and torch.equal(lb.w, la.w)
-    assert torch.equal(lb.iters, la.iters)
-    ua = la.step(at[0]); ub = lb.step(at[0])
-    torch.cuda.synchronize()
-    assert torch.equal(ua, ub)
+    if R <= 64:
+        assert torch.equal(torch.cat([U1, U2]), Ua) and torch.equal(torch.cat([X1, X2]), Xa)
+        # the state a following step starts from is the step-by-step run's
+        assert torch.equal(lb.x0, la.x0) and torch.equal(lb.x0_pre, la.x0_pre) and torch.equal(lb.w, la.w)
+        assert torch.equal(lb.iters, la.iters)
+        ua = la.step(at[0]); ub = lb.step(at[0])
+        torch.cuda.synchronize()
+        assert torch.equal(ua, ub)
+    else:
+        # beyond 64 realisations one call per step is the four-launch form, the walk the first-move form: same algebra, other rounding
+        close = lambda x, y: rel_err(x.cpu().numpy(), y.cpu().numpy()) <= 1e-11
+        assert close(torch.cat([U1, U2]), Ua) and close(torch.cat([X1, X2]), Xa)
+        assert close(lb.x0, la.x0) and close(lb.x0_pre, la.x0_pre) and close(lb.w, la.w) and torch.equal(lb.iters, la.iters)
     h1.close(); h2.close()
 
 
