@@ -1,0 +1,20 @@
+// Parameter block of the affine cold-start kernel (fmpc_kernel_affine.hip).  Internal to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fmpc_host.h"
+
+struct FaParams {
+    int n, m, T, nb, has_xf, batch, rows, tiles, step_ld;
+    int tiles_used, wgs_per_group;    // set by the launcher (flags: knock-out experiments, FMPC_AFFINE_FLAGS)
+    const double* img;                  // [tiles][FA_KS][64]: A-operand images of [Kz | zc | 0]
+    const double* imgE; const double* imgEp;               // [4][FA_KS][64]: the (x0, x0_pre) blocks of E, Ep (64 rows, zero padded)
+    const double* elin; const double* eplin;               // 2 e, -2 ep (64 entries, zero padded)
+    const double* dx0T;                 // 2 Qf xbar + qf (n)
+    double e0, ep0, normE, norme, normEp, normep, rd2_0;
+    const double* x0; const double* x0p; const double* nu0;
+    double* zout; double* u0out; int* status; int* iters; double* step;
+    int* need; int* handed;
+    double* dump;                       // 4096 doubles nobody reads: where lanes without a valid target store (no branch around a store)
+};
+
+hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream);

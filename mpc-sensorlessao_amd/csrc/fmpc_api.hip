@@ -14,6 +14,7 @@
 #include "fmpc_panel.h"
 #include "fmpc_host.h"
 #include "fmpc_first.h"
+#include "fmpc_affine.h"
 #include "fmpc_tiled.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
@@ -79,6 +80,8 @@ struct fmpc_handle_s {
     double* fm_forms;            // diagnostic: where the one-step first-move kernel leaves the bounds its decision used (fmpc_debug_first_move_forms)
     double* fm_compact;          // compact batch of the stopped realisations of a walk (fmpc_loop_run_walk)
     int* fm_walk_i; size_t fm_walk_cap;   // start / stop step per realisation of a walk
+    // affine form of the cold-start step without w (fmpc_kernel_affine.hip), built with the first-move form
+    FaParams fa_P; int fa_valid, fa_disabled; int* fa_need; size_t fa_need_cap;
     FwModel wave;
     double* wave_pool_d;
     int* wave_pool_i;
@@ -298,6 +301,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
+    h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0;
+    { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -553,6 +558,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->inv_jimg2) (void)hipFree(h->inv_jimg2);
     if (h->fm_pool) (void)hipFree(h->fm_pool);
     if (h->fm_need) (void)hipFree(h->fm_need);
+    if (h->fa_need) (void)hipFree(h->fa_need);
     if (h->fm_compact) (void)hipFree(h->fm_compact);
     if (h->fm_walk_i) (void)hipFree(h->fm_walk_i);
     if (h->lp_v) (void)hipFree(h->lp_v);
@@ -990,6 +996,32 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         for (int q = 0; q < n; ++q) { m12t[(size_t)q * TN + e] = h->hm_m1[(size_t)e * n + q]; m12t[(size_t)(n + q) * TN + e] = h->hm_m2[(size_t)e * n + q]; }
     for (int r = 0; r < n; ++r) dx0T[r] = h->hm_Qf2[r] * h->hm_xmid[r] + h->hm_qfl[r];
     const size_t oK = push(O.K0t), ou = push(O.u0c), oE = push(O.Ec), oe = push(O.e), oEp = push(O.Epc), oep = push(O.ep), om = push(m12t), od = push(dx0T);
+    // affine form of the whole step without w: [Kz | zc] as matrix-core images; the (x0, x0_pre) blocks of E, Ep likewise
+    h->fa_valid = 0;
+    FmpcAffineOut AO;
+    size_t oA = 0, oAE = 0, oAEp = 0, oAl = 0, oAlp = 0, oAd = 0;
+    bool fa_ok = !h->fa_disabled && 2 * n + 2 <= FA_KC;
+    if (fa_ok) {
+        FmpcAffineIn AI;
+        AI.n = n; AI.m = m; AI.T = T; AI.nb = h->nb; AI.has_xf = h->has_xf; AI.ncJ = 4 * n;
+        AI.bt = In.bt; AI.umax = In.umax; AI.umin = In.umin; AI.umid = In.umid; AI.xmid = In.xmid; AI.R2 = In.R2; AI.rl = In.rl;
+        AI.Q2 = h->hm_Q2.data(); AI.Qf2 = h->hm_Qf2.data(); AI.ql = h->hm_ql.data(); AI.qfl = h->hm_qfl.data(); AI.a1 = In.a1; AI.a2 = In.a2;
+        AI.J = In.J; AI.nuc = In.nuc; AI.k = k;
+        fmpc_host_build_affine(AI, AO);
+        for (double v : AO.img) if (!std::isfinite(v)) { fa_ok = false; break; }
+    }
+    if (fa_ok) {
+        const int nc = 4 * n, nd = 2 * n;
+        std::vector<double> E64((size_t)64 * FA_KC, 0.0), Ep64((size_t)64 * FA_KC, 0.0), el(64, 0.0), epl(64, 0.0), imgE, imgEp;
+        for (int r = 0; r < nd; ++r) {
+            for (int c = 0; c < nd; ++c) { E64[(size_t)r * FA_KC + c] = O.E[(size_t)r * nc + c]; Ep64[(size_t)r * FA_KC + c] = O.Ep[(size_t)r * nc + c]; }
+            el[r] = 2.0 * O.e[r]; epl[r] = -2.0 * O.ep[r];
+        }
+        fmpc_host_mfma_a_images(E64.data(), 64, imgE);
+        fmpc_host_mfma_a_images(Ep64.data(), 64, imgEp);
+        oA = push(AO.img); oAE = push(imgE); oAEp = push(imgEp); oAl = push(el); oAlp = push(epl);
+        oAd = push(std::vector<double>(4096, 0.0));
+    }
     if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
     if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
     if (hipMemcpy(h->fm_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
@@ -1000,6 +1032,14 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
     P.Ep = h->fm_pool + oEp; P.ep = h->fm_pool + oep; P.m12t = h->fm_pool + om; P.dx0T = h->fm_pool + od;
     P.e0 = O.e0; P.ep0 = O.ep0; P.normE = O.normE; P.norme = O.norme; P.normEp = O.normEp; P.normep = O.normep; P.rd2_0 = h->pn_rd2_0;
     h->fm_valid = 1; h->fm_k = k;
+    if (fa_ok) {
+        FaParams& A = h->fa_P;
+        memset(&A, 0, sizeof(A));
+        A.n = n; A.m = m; A.T = T; A.nb = h->nb; A.has_xf = h->has_xf; A.rows = AO.rows; A.tiles = AO.tiles;
+        A.img = h->fm_pool + oA; A.imgE = h->fm_pool + oAE; A.imgEp = h->fm_pool + oAEp; A.elin = h->fm_pool + oAl; A.eplin = h->fm_pool + oAlp; A.dump = h->fm_pool + oAd;
+        A.dx0T = P.dx0T; A.e0 = O.e0; A.ep0 = O.ep0; A.normE = O.normE; A.norme = O.norme; A.normEp = O.normEp; A.normep = O.normep; A.rd2_0 = h->pn_rd2_0;
+        h->fa_valid = 1;
+    }
     return FMPC_OK;
 }
 
@@ -1118,6 +1158,37 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 // J or nuc not finite: the sweep form is taken, and the build (a stream synchronisation, allocations and a
                 // 5 ms launch) is not retried on every later solve with this k
                 h->inv_failed = h->inv_valid ? 0 : 1; h->inv_failed_k = k;
+            }
+            // Without w, with a budget of 1 and no nu requested the whole step is ONE product on the matrix cores (affine form,
+            // fmpc_kernel_affine.hip) + the exact path in flag mode for the problems whose decision is not clear-cut
+            if (dense_form && h->inv_valid && w == nullptr && max_iter == 1 && nu_out == nullptr && !h->fa_disabled && h->n == FP_N) {
+                if (!h->fm_valid || h->fm_k != k) {
+                    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+                    const int rcf = fmpc_build_first_move(h, k);
+                    if (rcf != FMPC_OK && rcf != FMPC_E_UNSUPPORTED) return rcf;
+                }
+                if (h->fm_valid && h->fm_k == k && h->fa_valid) {
+                    if ((size_t)batch > h->fa_need_cap) {
+                        (void)hipDeviceSynchronize();
+                        if (h->fa_need) (void)hipFree(h->fa_need);
+                        h->fa_need = nullptr; h->fa_need_cap = 0;
+                        size_t cap = 256;
+                        while (cap < (size_t)batch) cap *= 2;
+                        if (hipMalloc((void**)&h->fa_need, cap * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+                        h->fa_need_cap = cap;
+                    }
+                    FaParams A = h->fa_P;
+                    A.batch = batch; A.step_ld = fmpc_step_ld(n_newton);
+                    A.x0 = x0; A.x0p = x0_pre; A.nu0 = nu0; A.zout = z_null ? nullptr : z_out; A.u0out = u0_out;
+                    A.status = status; A.iters = iters; A.step = step; A.need = h->fa_need; A.handed = h->pn_cnt;
+                    if (fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+                    int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
+                    e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nullptr, status, iters, step,
+                                         fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,
+                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need);
+                    h->last_path = FMPC_PATH_PANEL; h->inv_last = 2;
+                    return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+                }
             }
             const int split = max_iter > 1;                           // budgets > 1: decide, compact, continue (two launches)
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;

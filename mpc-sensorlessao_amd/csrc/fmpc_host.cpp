@@ -518,3 +518,62 @@ void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out) {
         }
     Out.normE = fro(E); Out.norme = fro(e); Out.normEp = fro(Ep); Out.normep = fro(ep);
 }
+
+void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img) {
+    const int tiles = (rows + 15) / 16;
+    img.assign((size_t)tiles * FA_KS * 64, 0.0);
+    for (int t = 0; t < tiles; ++t)
+        for (int q = 0; q < FA_KS; ++q)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 16 * t + r;
+                    if (row < rows) img[((size_t)t * FA_KS + q) * 64 + g * 16 + r] = M[(size_t)row * FA_KC + 4 * q + g];
+                }
+}
+
+// z+ = zc + Kz d, d = [x0 ; x0_pre], from nu+ = nuc + J d (rows of stage s: u_s, then x_{s+1}):
+//   u_s+   = umid + wc o (B' nu+_s - cu)                                            (inf_newton_solver.m:34-35 on the u entries)
+//   x_j+   = xmid + X_j (-(2 Q_j xmid + q_j) - nu+_{j-1} + A1' nu+_j + A2' nu+_{j+1} [- nu+_T])   j = 1..T, X_j = (2 Q_j)^-1
+void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out) {
+    typedef long double ld;
+    const int n = In.n, m = In.m, T = In.T, s = n + m, nd = 2 * n, ncJ = In.ncJ;
+    Out.rows = T * s; Out.tiles = (Out.rows + 15) / 16;
+    Out.Kz.assign((size_t)Out.rows * FA_KC, 0.0);
+    std::vector<ld> cu(m), wc(m);
+    for (int j = 0; j < m; ++j) {
+        const ld sp = (ld)In.umax[j] - (ld)In.umid[j], sm = (ld)In.umid[j] - (ld)In.umin[j];
+        const ld dp = 1.0L / sp, dm = 1.0L / sm;
+        cu[j] = (ld)In.R2[j] * (ld)In.umid[j] + (ld)In.rl[j] + (ld)In.k * (dp - dm);
+        wc[j] = 1.0L / ((ld)In.R2[j] + (ld)In.k * (dp * dp + dm * dm));
+    }
+    // nu+ as an affine function of d: column c < nd of J, column nd = nuc
+    auto nuv = [&](int blk, int r, int c) -> ld {
+        return c < nd ? (ld)In.J[((size_t)blk * n + r) * ncJ + c] : (ld)In.nuc[(size_t)blk * n + r];
+    };
+    for (int st = 0; st < T; ++st) {
+        for (int j = 0; j < m; ++j) {
+            double* row = &Out.Kz[((size_t)st * s + j) * FA_KC];
+            for (int c = 0; c <= nd; ++c) {
+                ld t = 0.0L;
+                for (int r = 0; r < n; ++r) t += (ld)In.bt[(size_t)j * n + r] * nuv(st, r, c);
+                if (c == nd) t = (ld)In.umid[j] + wc[j] * (t - cu[j]); else t *= wc[j];
+                row[c] = (double)t;
+            }
+        }
+        const int jx = st + 1;                                     // x_jx lives in stage st
+        const bool last = jx == T;
+        for (int r = 0; r < n; ++r) {
+            double* row = &Out.Kz[((size_t)st * s + m + r) * FA_KC];
+            const ld q2 = last ? (ld)In.Qf2[r] : (ld)In.Q2[r], ql = last ? (ld)In.qfl[r] : (ld)In.ql[r];
+            for (int c = 0; c <= nd; ++c) {
+                ld v = -nuv(jx - 1, r, c);
+                if (jx < T) for (int q = 0; q < n; ++q) v += (ld)In.a1[q * n + r] * nuv(jx, q, c);
+                if (jx + 1 < T) for (int q = 0; q < n; ++q) v += (ld)In.a2[q * n + r] * nuv(jx + 1, q, c);
+                if (last && In.has_xf) v -= nuv(T, r, c);
+                if (c == nd) v = (ld)In.xmid[r] + (v - (q2 * (ld)In.xmid[r] + ql)) / q2; else v /= q2;
+                row[c] = (double)v;
+            }
+        }
+    }
+    fmpc_host_mfma_a_images(Out.Kz.data(), Out.rows, Out.img);
+}

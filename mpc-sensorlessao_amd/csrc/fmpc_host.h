@@ -104,3 +104,22 @@ struct FmpcFirstOut {
     double e0, ep0, normE, norme, normEp, normep;
 };
 void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out);
+
+// ---- affine form of the whole cold-start step without w (fmpc_kernel_affine.hip):  z+ = zc + Kz [x0 ; x0_pre]
+// (nu+ = nuc + J d is affine in the data, and so is d_z = -Phi^-1 (r_d + C' nu+) from the fixed cold-start point).
+#define FA_KS 14                        // k-steps of 4: 2 n = 54 data columns, column 54 = the constant zc (times 1), column 55 = 0
+#define FA_KC (4 * FA_KS)
+struct FmpcAffineIn {
+    int n, m, T, nb, has_xf, ncJ;       // J: nb n rows x ncJ columns row-major, the first 2 n columns are used
+    const double *bt, *umax, *umin, *umid, *xmid, *R2, *rl, *Q2, *Qf2, *ql, *qfl, *a1, *a2;
+    const double *J, *nuc;
+    double k;
+};
+struct FmpcAffineOut {
+    int rows, tiles;                    // T (n + m); 16-row tiles
+    std::vector<double> Kz;             // rows x FA_KC row-major (checks)
+    std::vector<double> img;            // matrix-core operand images: [tile][k-step][lane = 16 (k mod 4) + (row mod 16)]
+};
+void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
+// operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)
+void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img);
