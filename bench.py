@@ -337,7 +337,9 @@ def _main(real_out):
         lanes.close()
     iters_head = head.check()
     path, handed = h.last_dispatch()
-    dense = bool(h.last_dual_form()) if path == pkg._lib.FMPC_PATH_PANEL else False
+    dual_form = h.last_dual_form() if path == pkg._lib.FMPC_PATH_PANEL else 0
+    dense = bool(dual_form)
+    affine = dual_form == 2          # the whole step as one product (fmpc_kernel_affine.hip)
     shared = path in (pkg._lib.FMPC_PATH_PANEL, pkg._lib.FMPC_PATH_SHARED)
 
     extra = {}
@@ -627,6 +629,8 @@ def _main(real_out):
         ach_tf = f_first * units / (kern_ms * 1e-3) / 1e12
         ach_gbs = b_first * units / (kern_ms * 1e-3) / 1e9
         ex_fl = executed_mfma_flops_panel(m, T, dense) if path == pkg._lib.FMPC_PATH_PANEL else None
+        if affine:      # 14 k-steps per 16 x 16 tile of z (T (n + m) rows), + the two decision forms (4 row tiles each); per problem = / 16
+            ex_fl = (((T * (n + m) + 15) // 16) * 14 + 2 * 4 * 14) * 2048.0 / 16.0
         # measured HBM traffic of one solve: from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS workload
         # (scripts/prof_round2.sh writes profiles/traffic_latest.json); not measured inside this run, and only
         # reported when it is consistent with the compulsory bytes
@@ -642,18 +646,21 @@ def _main(real_out):
                 traffic = None
         roof_cold = {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": (("fmpc_cold_inv_rg<2,4,1,false> (dense form of the dual solve: nu+ = nuc + J [x0; x0_pre], w = NULL)" if dense else "fmpc_cold_panel")
-                                + " + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
-                               if path == pkg._lib.FMPC_PATH_PANEL else "path %d" % path,
+                     "kernel": ("fmpc_cold_affine<true> (the whole step as one product z+ = zc + Kz [x0; x0_pre] on the matrix cores, decision forms included) "
+                                "+ fmpc_newton_wave<27> (flag mode: %d problems redone exactly)" % handed) if affine else
+                               ((("fmpc_cold_inv_rg<2,4,1,false> (dense form of the dual solve: nu+ = nuc + J [x0; x0_pre], w = NULL)" if dense else "fmpc_cold_panel")
+                                 + " + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
+                                if path == pkg._lib.FMPC_PATH_PANEL else "path %d" % path),
                      "kernel_ms": kern_ms, "flops_per_unit": f_first, "units_per_launch": units,
                      "executed": None if ex_fl is None else {"mfma_flops_per_unit": ex_fl, "tflops": ex_fl * units / (kern_ms * 1e-3) / 1e12,
                                                               "frac_of_peak": ex_fl * units / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                      "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_unit": b_first},
                      "note": "the headline's own kernels: SURVEY 8d's shared-factor figure (1.60 MFLOP, 48 KB per unit) x units / device time "
                              "of one solve (all its kernels, HIP events); `executed` = MFMAs actually issued on padded tiles. With w = NULL "
-                             "the dual solve is a product with the 56 columns of d nu+ / d [x0; x0_pre]: most of the survey's 1.60 MFLOP "
-                             "(the banded substitutions) are never executed, so `frac` measures speed in the survey's unit of work, not "
-                             "matrix-core utilisation -- `executed.frac_of_peak` does"}
+                             "the step is affine in [x0; x0_pre]: most of the survey's 1.60 MFLOP (the banded substitutions) are never "
+                             "executed -- the affine form issues 321 x 14 matrix instructions per 16 problems (0.58 MFLOP per problem) "
+                             "and is bound by the matrix pipes -- so `frac` measures speed in the survey's unit of work, not "
+                             "matrix-core utilisation; `executed.frac_of_peak` does"}
         out = {
             "metric": "MPC steps/sec (n=27, VAR(2), T=30)",
             "value": world * B * steps_done / elapsed,
@@ -668,7 +675,9 @@ def _main(real_out):
                        "batch_per_gpu": B, "n_newton": args.n_newton, "k": K_BAR,
                        "newton_iters_per_problem": iters_head / B, "in_flight": depth,
                        "cold_start_factor": "shared: one factorisation per (handle, k), SURVEY regime (ii)" if shared else "per problem",
-                       "cold_start_dual_solve": ("dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
+                       "cold_start_dual_solve": ("affine form of the whole step: z+ = zc + Kz [x0; x0_pre] (w = NULL, one Newton step), Kz built once per (handle, k) "
+                                                 "on the host from the shared factor; one matrix product per batch" if shared and affine else
+                                                 "dense form: nu+ = nuc + J [x0; x0_pre] (w = NULL), J built once per (handle, k) from the shared factor"
                                                  if shared and dense else "two sweeps through the shared block factor (panels of 16 problems)") if shared else None,
                        "gather": ("all-gather of the first moves u0 (RCCL), one collective per %d steps (and at the end of the timed region), two buffers in turn" % GROUP) if dist_on else "none (1 GPU)",
                        "steps_requested": args.steps,

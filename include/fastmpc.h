@@ -304,7 +304,12 @@ int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
  * form is the same.
  *   fmpc_set_dense_form: enabled 0/1, max_batch_with_w < 0 keeps the bound.  FMPC_E_UNSUPPORTED if the handle has
  *                        no panel path (n != 27).
- *   fmpc_last_dual_form: 1 if the last solve took the dense form, 0 otherwise. */
+ *   fmpc_last_dual_form: 0 = the sweeps, 1 = the dense form of the dual solve, 2 = the AFFINE FORM of the whole step: with
+ *                        w == NULL, n_newton == 1 and nu_out == NULL (the reference's replay call, README.md:548-556) the
+ *                        step from the cold start is z+ = zc + Kz [x0; x0_pre], one product per batch on the matrix cores
+ *                        (Kz built once per (handle, k) with J; the step-length decision from two quadratic forms of the
+ *                        data, problems that are not clear-cut redone by the exact path: tests/test_gpu_affine.py).
+ *                        FMPC_NO_AFFINE=1 or fmpc_set_dense_form(h, 0, ..) switch it off. */
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)

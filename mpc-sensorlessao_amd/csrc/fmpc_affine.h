@@ -5,6 +5,7 @@
 
 struct FaParams {
     int n, m, T, nb, has_xf, batch, rows, tiles, step_ld;
+    int nu_rows, nu_tiles;              // nu+ as further tiles behind those of z (written when nuout != NULL)
     int tiles_used, wgs_per_group;    // set by the launcher (flags: knock-out experiments, FMPC_AFFINE_FLAGS)
     const double* img;                  // [tiles][FA_KS][64]: A-operand images of [Kz | zc | 0]
     const double* imgE; const double* imgEp;               // [4][FA_KS][64]: the (x0, x0_pre) blocks of E, Ep (64 rows, zero padded)
@@ -12,7 +13,7 @@ struct FaParams {
     const double* dx0T;                 // 2 Qf xbar + qf (n)
     double e0, ep0, normE, norme, normEp, normep, rd2_0;
     const double* x0; const double* x0p; const double* nu0;
-    double* zout; double* u0out; int* status; int* iters; double* step;
+    double* zout; double* nuout; double* u0out; int* status; int* iters; double* step;
     int* need; int* handed;
     double* dump;                       // 4096 doubles nobody reads: where lanes without a valid target store (no branch around a store)
 };

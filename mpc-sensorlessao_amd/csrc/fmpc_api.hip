@@ -1035,7 +1035,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
     if (fa_ok) {
         FaParams& A = h->fa_P;
         memset(&A, 0, sizeof(A));
-        A.n = n; A.m = m; A.T = T; A.nb = h->nb; A.has_xf = h->has_xf; A.rows = AO.rows; A.tiles = AO.tiles;
+        A.n = n; A.m = m; A.T = T; A.nb = h->nb; A.has_xf = h->has_xf; A.rows = AO.rows; A.tiles = AO.tiles; A.nu_rows = AO.nu_rows; A.nu_tiles = AO.nu_tiles;
         A.img = h->fm_pool + oA; A.imgE = h->fm_pool + oAE; A.imgEp = h->fm_pool + oAEp; A.elin = h->fm_pool + oAl; A.eplin = h->fm_pool + oAlp; A.dump = h->fm_pool + oAd;
         A.dx0T = P.dx0T; A.e0 = O.e0; A.ep0 = O.ep0; A.normE = O.normE; A.norme = O.norme; A.normEp = O.normEp; A.normep = O.normep; A.rd2_0 = h->pn_rd2_0;
         h->fa_valid = 1;
@@ -1161,7 +1161,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             }
             // Without w, with a budget of 1 and no nu requested the whole step is ONE product on the matrix cores (affine form,
             // fmpc_kernel_affine.hip) + the exact path in flag mode for the problems whose decision is not clear-cut
-            if (dense_form && h->inv_valid && w == nullptr && max_iter == 1 && nu_out == nullptr && !h->fa_disabled && h->n == FP_N) {
+            if (dense_form && h->inv_valid && w == nullptr && max_iter == 1 && (nu_out == nullptr || !z_null) && !h->fa_disabled && h->n == FP_N) {
                 if (!h->fm_valid || h->fm_k != k) {
                     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
                     const int rcf = fmpc_build_first_move(h, k);
@@ -1179,11 +1179,11 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     }
                     FaParams A = h->fa_P;
                     A.batch = batch; A.step_ld = fmpc_step_ld(n_newton);
-                    A.x0 = x0; A.x0p = x0_pre; A.nu0 = nu0; A.zout = z_null ? nullptr : z_out; A.u0out = u0_out;
+                    A.x0 = x0; A.x0p = x0_pre; A.nu0 = nu0; A.zout = z_null ? nullptr : z_out; A.nuout = nu_out; A.u0out = u0_out;
                     A.status = status; A.iters = iters; A.step = step; A.need = h->fa_need; A.handed = h->pn_cnt;
                     if (fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
                     int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
-                    e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nullptr, status, iters, step,
+                    e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nu_out, status, iters, step,
                                          fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,
                                          h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need);
                     h->last_path = FMPC_PATH_PANEL; h->inv_last = 2;

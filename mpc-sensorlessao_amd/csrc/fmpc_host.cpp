@@ -576,4 +576,13 @@ void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out) {
         }
     }
     fmpc_host_mfma_a_images(Out.Kz.data(), Out.rows, Out.img);
+    // nu+ = nuc + J d as further rows (requested by callers that want the multipliers)
+    Out.nu_rows = In.nb * n; Out.nu_tiles = (Out.nu_rows + 15) / 16;
+    std::vector<double> Jn((size_t)Out.nu_rows * FA_KC, 0.0), imgn;
+    for (int r = 0; r < Out.nu_rows; ++r) {
+        for (int c = 0; c < nd; ++c) Jn[(size_t)r * FA_KC + c] = In.J[(size_t)r * ncJ + c];
+        Jn[(size_t)r * FA_KC + nd] = In.nuc[r];
+    }
+    fmpc_host_mfma_a_images(Jn.data(), Out.nu_rows, imgn);
+    Out.img.insert(Out.img.end(), imgn.begin(), imgn.end());
 }

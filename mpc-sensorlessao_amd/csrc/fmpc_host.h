@@ -117,8 +117,9 @@ struct FmpcAffineIn {
 };
 struct FmpcAffineOut {
     int rows, tiles;                    // T (n + m); 16-row tiles
+    int nu_rows, nu_tiles;              // nb n rows of nu+ = nuc + J d, as further tiles behind those of z
     std::vector<double> Kz;             // rows x FA_KC row-major (checks)
-    std::vector<double> img;            // matrix-core operand images: [tile][k-step][lane = 16 (k mod 4) + (row mod 16)]
+    std::vector<double> img;            // matrix-core operand images: [tile][k-step][lane = 16 (k mod 4) + (row mod 16)], z tiles then nu tiles
 };
 void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
 // operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)

@@ -231,15 +231,23 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
         __syncthreads();
     }
     // ================================================================ z = [D ; 1]' [Kz | zc]'
-    // Full rounds of tiles go round-robin to the group's wavefronts, every wavefront the same number.  The tiles that are left
-    // (z has 320 full tiles + one of 10 rows at (27, 144, 30): one) are dealt by COLUMN TILE, 14 matrix instructions apiece:
-    // a whole extra tile on one wavefront would hold up its SIMD for a tile's time, 10 % of the kernel.
-    const int tfull = (tiles / tstep) * tstep;
+    // Full rounds of tiles go round-robin to the group's wavefronts.  The workgroups that evaluated the decision forms (the
+    // last four of the group: 6 us, measured as the kernel's tail) leave out their tiles of the last round; those 16 tiles and
+    // the tiles beyond the full rounds (z has 320 full tiles + one of 10 rows at (27, 144, 30): one) are dealt by COLUMN TILE,
+    // 14 matrix instructions apiece, to all wavefronts of the group -- a whole extra tile on one wavefront holds up its SIMD for
+    // a tile's time, 10 % of the kernel.
+    const int rounds = tiles / tstep;
+    const bool forms_wg = P.wgs_per_group >= 8 && rounds >= 2 && slot >= P.wgs_per_group - FA_CT;
+    const int nskip = (P.wgs_per_group >= 8 && rounds >= 2) ? 4 * FA_CT : 0;  // tiles of the last round the forms workgroups leave out
+    const int skip0 = (rounds - 1) * tstep + (P.wgs_per_group - FA_CT) * 4;    // ... a contiguous range
+    const int tfull = (rounds - (forms_wg ? 1 : 0)) * tstep;                 // this wavefront's rounds end here
     double* dump = P.dump + ((blockIdx.x & 15) * FA_THREADS + tid);          // 16 x 256 doubles: nobody reads them
     {
         const int wg_w = slot * 4 + wv;                                          // wavefront of the group
-        for (int task = wg_w; task < (tiles - tfull) * FA_CT; task += tstep) {
-            const int lt = tfull + task / FA_CT, ct = task % FA_CT;
+        const int nleft = nskip + (tiles - rounds * tstep);
+        for (int task = wg_w; task < nleft * FA_CT; task += tstep) {
+            const int j = task / FA_CT, ct = task % FA_CT;
+            const int lt = j < nskip ? skip0 + j : rounds * tstep + (j - nskip);
             double Al[FA_KS], Dl[FA_KS];
             fa_load_a(Al, P.img, lt, lane);
 #pragma unroll
@@ -251,7 +259,8 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pp = (gi * FA_CT + ct) * 16 + 4 * r + g;
-                if (ZOUT && row < rows && pp < P.batch) P.zout[(size_t)pp * rows + row] = acc[r];
+                if (ZOUT && lt < P.tiles && row < rows && pp < P.batch) P.zout[(size_t)pp * rows + row] = acc[r];
+                if (ZOUT && lt >= P.tiles && row - 16 * P.tiles < P.nu_rows && pp < P.batch) P.nuout[(size_t)pp * P.nu_rows + (row - 16 * P.tiles)] = acc[r];
                 if (P.u0out != nullptr && row < m && pp < P.batch) P.u0out[(size_t)pp * m + row] = acc[r];
             }
         }
@@ -280,14 +289,18 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
         // stores follow the request for the next operand.)  Addresses: a uniform base per (column tile, register) + one per-lane offset.
         const int row = 16 * tile + c;
         if (ZOUT) {
-            const unsigned voz = (unsigned)(g * rows + row);
-            const bool rok = row < rows;
+            // (tiles beyond those of z are rows of nu+: another base and row count, the same 16 stores)
+            const bool isnu = tile >= P.tiles;
+            const int rloc = isnu ? row - 16 * P.tiles : row, rcnt = isnu ? P.nu_rows : rows;
+            double* obase = isnu ? P.nuout : P.zout;
+            const unsigned voz = (unsigned)(g * rcnt + rloc);
+            const bool rok = rloc < rcnt;
 #pragma unroll
             for (int ct = 0; ct < FA_CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pb = (gi * FA_CT + ct) * 16 + 4 * r;       // uniform
-                    double* zb = P.zout + (size_t)pb * rows + voz;
+                    double* zb = obase + (size_t)pb * rcnt + voz;
                     double* dst = (rok && pb + g < P.batch) ? zb : dump;
                     *dst = acc[ct][r];
                 }
@@ -322,7 +335,7 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
 hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream) {
     if (P.n != 27 || 2 * P.n + 2 > FA_KC || 7 * FA_THREADS < FA_CT * 16 * P.n) return hipErrorInvalidValue;
     const int ncol = (P.batch + 15) / 16, ngroups = (ncol + FA_CT - 1) / FA_CT;
-    P.tiles_used = P.zout ? P.tiles : (P.m + 15) / 16;
+    P.tiles_used = P.zout ? P.tiles + (P.nuout ? P.nu_tiles : 0) : (P.m + 15) / 16;
     // two workgroups of four wavefronts per CU are resident: that many workgroups share the groups of 64 problems (a workgroup
     // beyond the resident set would start when another ends)
     int wpg = (2 * num_cu) / ngroups;                            // workgroups per group

@@ -1,7 +1,7 @@
 """GPU tests of the affine form of the cold-start step without w (fmpc_kernel_affine.hip): z+ = zc + Kz [x0 ; x0_pre] as ONE
 product on the matrix cores + the step-length decision from two quadratic forms; problems whose decision is not clear-cut are
-redone by the exact path.  Taken by device-pointer solves with w = NULL, n_newton = 1 and no nu requested (the reference's
-replay call, README.md:548-556).  Checkers: the structured oracle (1e-9 on z), and the three-kernel form of the same step
+redone by the exact path.  Taken by solves from the cold start with w = NULL and n_newton = 1 (the reference's replay call,
+README.md:548-556); nu+, when requested, is further rows of the same product.  Checkers: the structured oracle (1e-9 on z), and the three-kernel form of the same step
 (dense dual solve + d_z + decision, FMPC_NO_AFFINE=1: 1e-11, identical status / iteration counts / step lengths)."""
 import os
 
@@ -13,7 +13,7 @@ from tests.util import canon_steps, handle_from_model, oracle_batch, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _solve_dev(pkg, h, data, want_z=True, want_u0=True):
+def _solve_dev(pkg, h, data, want_z=True, want_u0=True, want_nu=False):
     import torch
     dev = torch.device("cuda:0")
     t = {k: (None if v is None else torch.from_numpy(np.ascontiguousarray(v)).to(dev)) for k, v in data.items()}
@@ -22,8 +22,11 @@ def _solve_dev(pkg, h, data, want_z=True, want_u0=True):
     u0 = torch.full((B, h.m), float("nan"), dtype=torch.float64, device=dev) if want_u0 else None
     st = torch.full((B,), -99, dtype=torch.int32, device=dev); it = torch.full((B,), -99, dtype=torch.int32, device=dev)
     stp = torch.full((B, 1), float("nan"), dtype=torch.float64, device=dev)
-    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=z, status=st, iters=it, step=stp, u0_out=u0, want_z=want_z)
+    nu = torch.full((B, h.nu_len), float("nan"), dtype=torch.float64, device=dev) if want_nu else None
+    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=z, nu_out=nu, status=st, iters=it, step=stp, u0_out=u0, want_z=want_z)
     torch.cuda.synchronize()
+    if want_nu:
+        return z.cpu().numpy(), nu.cpu().numpy()
     return (None if z is None else z.cpu().numpy(), None if u0 is None else u0.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), stp.cpu().numpy())
 
 
@@ -72,6 +75,13 @@ def test_affine_form_matches_oracle_and_the_three_kernel_form(pkg, gpu, T, batch
     assert np.array_equal(ia[:nchk], ito) and np.array_equal(sa[:nchk], sto)
     assert np.array_equal(canon_steps(ta[:nchk, 0]), canon_steps([s[0] for s in steps]))
     assert max(rel_err(za[p], zo[p]) for p in range(nchk)) <= 1e-9
+    # with the multipliers requested: nu+ = nuc + J d as further rows of the same product; z does not change by a bit
+    zn, nun = _solve_dev(pkg, h, data, want_nu=True)
+    assert h.last_dual_form() == 2 and np.array_equal(zn, za) and np.all(np.isfinite(nun))
+    z3n, nu3 = _solve_dev(pkg, h3, data, want_nu=True)
+    assert max(rel_err(nun[p], nu3[p]) for p in range(batch)) <= 1e-11
+    _, nuo, *_ = oracle_batch(md, sub, 1, 1e-2)
+    assert max(rel_err(nun[p], nuo[p]) for p in range(nchk)) <= 1e-7
     # first moves only (z_out = NULL): the first m rows of the same product
     _, uo, so, io, _ = _solve_dev(pkg, h, data, want_z=False)
     assert h.last_dual_form() == 2
@@ -105,6 +115,9 @@ def test_affine_form_hands_unclear_problems_to_the_exact_path(pkg, gpu):
         assert np.array_equal(ia[pick], ito) and np.array_equal(sa[pick], sto)
         assert np.array_equal(canon_steps(ta[pick, 0]), canon_steps([s[0] for s in steps]))
         assert max(rel_err(za[p], zo[q]) for q, p in enumerate(pick)) <= 1e-9
+        zn, nun = _solve_dev(pkg, h, data, want_nu=True)
+        z3n, nu3 = _solve_dev(pkg, h3, data, want_nu=True)
+        assert np.array_equal(zn, za) and max(rel_err(nun[p], nu3[p]) for p in range(batch)) <= 1e-11
         if want_all:
             assert np.any(ta[:, 0] < 1.0), "no backtracking in the tight-box case"
         _, uo, _, _, _ = _solve_dev(pkg, h, data, want_z=False)

@@ -42,7 +42,7 @@ def test_dense_form_matches_oracle_and_sweeps(pkg, gpu, T, batch, xf, use_w, use
     h = handle_from_model(pkg, md)
     args = (data["x0"], data["x0_pre"], data["w"])
     zd, idn = h.solve(*args, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
-    assert h.last_dispatch()[0] == pkg.FMPC_PATH_PANEL and h.last_dual_form() == 1
+    assert h.last_dispatch()[0] == pkg.FMPC_PATH_PANEL and h.last_dual_form() >= 1
     h.set_dense_form(False)
     zs, isw = h.solve(*args, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
     assert h.last_dispatch()[0] == pkg.FMPC_PATH_PANEL and h.last_dual_form() == 0
@@ -68,7 +68,7 @@ def test_dense_form_is_independent_of_the_batch_it_runs_in(pkg, gpu):
     z_all = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2)
     for lo, hi in [(0, 1), (17, 18), (3, 40), (48, 64)]:
         z = h.solve(data["x0"][lo:hi], data["x0_pre"][lo:hi], data["w"][lo:hi], nu0=data["nu0"][lo:hi], n_newton=1, k=1e-2)
-        assert h.last_dual_form() == 1
+        assert h.last_dual_form() >= 1
         assert np.array_equal(z, z_all[lo:hi])
     h.close()
 
@@ -80,11 +80,11 @@ def test_dense_form_bound_and_barrier_weight_changes(pkg, gpu):
     h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2)
     assert h.last_dual_form() == 0                                    # 40 problems with w: beyond the bound, the sweeps
     h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2)
-    assert h.last_dual_form() == 1                                    # without w always
+    assert h.last_dual_form() >= 1                                    # without w always
     h.set_dense_form(True, max_batch_with_w=1024)
     for k in (1e-2, 1.0, 1e-4, 1e-2):                                 # J is rebuilt per barrier weight
         z, info = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=k, return_info=True)
-        assert h.last_dual_form() == 1
+        assert h.last_dual_form() >= 1
         zo, nuo, ito, sto, _ = oracle_batch(md, data, 1, k)
         assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
         for p in range(40):
@@ -98,7 +98,7 @@ def test_dense_form_with_a_newton_budget(pkg, gpu):
     md, data = _case(pkg, 30, 48, False, True, True, seed=31)
     h = handle_from_model(pkg, md)
     z, info = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=5, k=1e-2, return_info=True)
-    assert h.last_dual_form() == 1
+    assert h.last_dual_form() >= 1
     zo, nuo, ito, sto, _ = oracle_batch(md, data, 5, 1e-2)
     assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto)
     for p in range(48):
@@ -114,12 +114,16 @@ def test_dual_solve_fused_into_dz(pkg, gpu, T, batch, use_nu, var_order, m):
     HBM).  Against the default dense form (1e-11) and the oracle; nu_out comes from d_z in both."""
     import os
     md, data = _case(pkg, T, batch, False, False, use_nu, seed=41, var_order=var_order, m=m)
-    hu = handle_from_model(pkg, md)
-    os.environ["FMPC_FUSE_DZ"] = "1"
+    os.environ["FMPC_NO_AFFINE"] = "1"         # both handles on the three-kernel form (the affine form would take these solves)
     try:
-        hf = handle_from_model(pkg, md)
+        hu = handle_from_model(pkg, md)
+        os.environ["FMPC_FUSE_DZ"] = "1"
+        try:
+            hf = handle_from_model(pkg, md)
+        finally:
+            del os.environ["FMPC_FUSE_DZ"]
     finally:
-        del os.environ["FMPC_FUSE_DZ"]
+        del os.environ["FMPC_NO_AFFINE"]
     zf, inf_ = hf.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
     zu, inu = hu.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
     assert hf.last_dual_form() == 1 and hu.last_dual_form() == 1
@@ -143,7 +147,7 @@ def test_dense_form_at_panel_and_shape_boundaries(pkg, gpu, batch):
     md, data = _case(pkg, 30, batch, False, True, True, seed=batch)
     h = handle_from_model(pkg, md)
     zd, idn = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
-    assert h.last_dual_form() == 1
+    assert h.last_dual_form() >= 1
     h.set_dense_form(False)
     zs, isw = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=1, k=1e-2, return_info=True)
     assert np.array_equal(idn["iters"], isw["iters"]) and np.array_equal(idn["step"], isw["step"])
@@ -168,7 +172,7 @@ def test_budget_continuation_on_the_tiled_kernel_with_handed_over_problems(pkg, 
     h = handle_from_model(pkg, md)
     z, info = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=6, k=1e-2, return_info=True)
     path, handed = h.last_dispatch()
-    assert path == pkg.FMPC_PATH_PANEL and handed > 0 and h.last_dual_form() == 1
+    assert path == pkg.FMPC_PATH_PANEL and handed > 0 and h.last_dual_form() >= 1
     h.close()
     os.environ["FMPC_NO_SMALL_TILED"] = "1"
     try:
