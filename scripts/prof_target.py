@@ -7,6 +7,7 @@
   batch512        configs[2]: 512 problems, cold start
   dense_w512      512 problems with a disturbance w: the dense form of the dual solve with all T n columns of w
   closed512       closed loop, 512 realisations: fmpc_loop_step_device per step
+  walk64          closed loop, 64 realisations, a recorded stretch of 300 steps in one call (fmpc_first_move_run: one launch)
   budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
                   + compaction, continuation of the ~9 % that go on by the tiled kernel"""
 import importlib, os, sys
@@ -19,7 +20,7 @@ if target in ("general_tiled", "tiled_f32"):
 import numpy as np, torch
 pkg = importlib.import_module("mpc-sensorlessao_amd")
 dev = torch.device("cuda:0")
-n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512") else 2000)
+n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512") else (64 if target == "walk64" else 2000))
 model = pkg.synthetic.make_model(n, m, T)
 data = pkg.synthetic.make_replay_batch(model, r=0, steps=B)
 h = pkg.FastMPCHandle(model["A1"], model["A2"], model["B"], model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"],
@@ -41,8 +42,16 @@ if target == "closed512":
     for s_ in range(reps + 2):
         loop.step(at[s_])
     st, it = loop.status, loop.iters
+if target == "walk64":
+    nst = 300
+    a = np.stack([pkg.synthetic.make_realisation(model, r=r, steps=nst)[1:nst + 1] for r in range(8)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(np.tile(a, (1, 8, 1)))).to(dev)
+    for _ in range(reps):
+        loop = pkg.ClosedLoop(h, B, n_newton=1, k=1e-2, keep_z=False)
+        loop.run_recorded(at, want_x0=False)
+    st, it = loop.status, loop.iters
 wt = torch.from_numpy(0.01 * np.random.default_rng(3).standard_normal((B, T * n))).to(dev) if target == "dense_w512" else None
-for _ in range(0 if target == "closed512" else reps):
+for _ in range(0 if target in ("closed512", "walk64") else reps):
     h.solve_device(x0, x0p, wt, zi, nu0, 5 if target == "budget5" else 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
 torch.cuda.synchronize()
 assert int((st < 0).sum()) == 0
