@@ -319,6 +319,37 @@ int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled);
 int fmpc_last_dual_form(fmpc_handle h);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Phase-diversity estimator: replaces the "% Estimator" block of the reference's simulation loop (README.md:456-480)
+ *
+ *     for k = 1:numel(zd_list)
+ *         kW = zd_list(k).*squeeze(Zs(idx2,:,:));   P_defocus = pupil.*exp(1i*(scrn+kW));
+ *         I_defocus = fftshift(fft2(fftshift(P_defocus),res,res))*dx^2;   im = abs(I_defocus).^2;
+ *         v_im(:,:,k) = im(range_min:range_max,range_min:range_max)*AU;   Y_M = [Y_M; reshape(v_im(:,:,k),[],1)];
+ *     end
+ *     Y_M = Y_M + Y_M_noise;      ad_est = lsqminnorm((A_s'*A_s),((A_s)'*(Y_M-b_s)));
+ *
+ * for a batch of residual phase screens at once: the window of each PSF as a partial DFT on the fp64 matrix cores (the
+ * reference keeps 31 x 31 samples of a 512 x 512 FFT), ad_est = G (Y_M - b_s) with G = pinv(A_s'A_s) A_s' built once.
+ *
+ * fmpc_est_create   len: pixels per side (a multiple of 64; the reference: 512, mag = 1 so res = len).
+ *                   first, d: the window im(range_min:range_max, ...) as first = range_min - 1 (0-based), d = range_max -
+ *                   range_min + 1 <= 32.   ndiv <= 3 diversities;  D_re, D_im: ndiv arrays len x len (column-major, MATLAB
+ *                   order) = real / imaginary part of pupil.*exp(1i*zd_list(k)*squeeze(Zs(idx2,:,:))).   scale = dx^4*AU.
+ *                   A_s: p x nx column-major, b_s: p, p = ndiv d^2 (model_approx.mat of the reference, piston removed).
+ * fmpc_est_apply[_device]   scrn: batch arrays len x len column-major [rad]; noise: batch x p or NULL (Y_M_noise);
+ *                   ad_est: batch x nx;  Y_out: batch x p or NULL (Y_M, for Y_M_acc of the reference).
+ * fmpc_est_dims     any pointer may be NULL; rank = numerical rank of A_s'A_s found when G was built.
+ */
+typedef struct fmpc_est_s* fmpc_est;
+int fmpc_est_create(fmpc_est* out, int len, int first, int d, int ndiv, const double* D_re, const double* D_im,
+                    double scale, const double* A_s, const double* b_s, int p, int nx, int device);
+int fmpc_est_destroy(fmpc_est e);
+int fmpc_est_dims(fmpc_est e, int* len, int* d, int* ndiv, int* nx, int* p, int* rank);
+int fmpc_est_apply(fmpc_est e, int batch, const double* scrn, const double* noise, double* ad_est, double* Y_out);
+int fmpc_est_apply_device(fmpc_est e, int batch, const double* scrn, const double* noise, double* ad_est, double* Y_out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

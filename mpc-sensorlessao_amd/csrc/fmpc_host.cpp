@@ -586,3 +586,78 @@ void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out) {
     fmpc_host_mfma_a_images(Jn.data(), Out.nu_rows, imgn);
     Out.img.insert(Out.img.end(), imgn.begin(), imgn.end());
 }
+
+int fmpc_host_estimator_gain(const double* A_s, int p, int nx, std::vector<double>& G) {
+    typedef long double ld;
+    std::vector<ld> M((size_t)nx * nx, 0.0L), V((size_t)nx * nx, 0.0L);
+    for (int a = 0; a < nx; ++a)
+        for (int b = a; b < nx; ++b) {
+            ld s = 0.0L;
+            for (int i = 0; i < p; ++i) s += (ld)A_s[(size_t)a * p + i] * (ld)A_s[(size_t)b * p + i];
+            M[(size_t)a * nx + b] = s; M[(size_t)b * nx + a] = s;
+        }
+    for (int a = 0; a < nx; ++a) V[(size_t)a * nx + a] = 1.0L;
+    // cyclic Jacobi on the symmetric M: M <- J' M J, V <- V J
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        ld off = 0.0L, dia = 0.0L;
+        for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) { if (a != b) off += M[(size_t)a * nx + b] * M[(size_t)a * nx + b]; else dia += M[(size_t)a * nx + a] * M[(size_t)a * nx + a]; }
+        if (off <= 1e-60L * dia || off == 0.0L) break;
+        for (int a = 0; a < nx - 1; ++a)
+            for (int b = a + 1; b < nx; ++b) {
+                const ld apq = M[(size_t)a * nx + b];
+                if (apq == 0.0L) continue;
+                const ld theta = (M[(size_t)b * nx + b] - M[(size_t)a * nx + a]) / (2.0L * apq);
+                const ld t = (theta >= 0.0L ? 1.0L : -1.0L) / (fabsl(theta) + sqrtl(theta * theta + 1.0L));
+                const ld c = 1.0L / sqrtl(t * t + 1.0L), s = t * c;
+                for (int k = 0; k < nx; ++k) {                       // columns a, b
+                    const ld mka = M[(size_t)k * nx + a], mkb = M[(size_t)k * nx + b];
+                    M[(size_t)k * nx + a] = c * mka - s * mkb; M[(size_t)k * nx + b] = s * mka + c * mkb;
+                }
+                for (int k = 0; k < nx; ++k) {                       // rows a, b
+                    const ld mak = M[(size_t)a * nx + k], mbk = M[(size_t)b * nx + k];
+                    M[(size_t)a * nx + k] = c * mak - s * mbk; M[(size_t)b * nx + k] = s * mak + c * mbk;
+                }
+                for (int k = 0; k < nx; ++k) {
+                    const ld vka = V[(size_t)k * nx + a], vkb = V[(size_t)k * nx + b];
+                    V[(size_t)k * nx + a] = c * vka - s * vkb; V[(size_t)k * nx + b] = s * vka + c * vkb;
+                }
+            }
+    }
+    ld lmax = 0.0L;
+    for (int a = 0; a < nx; ++a) lmax = fmaxl(lmax, fabsl(M[(size_t)a * nx + a]));
+    const ld tol = (ld)nx * 2.220446049250313e-16L * lmax;
+    int rank = 0;
+    std::vector<ld> inv(nx, 0.0L);
+    for (int a = 0; a < nx; ++a) if (M[(size_t)a * nx + a] > tol) { inv[a] = 1.0L / M[(size_t)a * nx + a]; ++rank; }
+    // pinv = V diag(inv) V' ;  G = pinv A_s'
+    std::vector<ld> Pm((size_t)nx * nx, 0.0L);
+    for (int a = 0; a < nx; ++a)
+        for (int b = 0; b < nx; ++b) {
+            ld s = 0.0L;
+            for (int k = 0; k < nx; ++k) s += V[(size_t)a * nx + k] * inv[k] * V[(size_t)b * nx + k];
+            Pm[(size_t)a * nx + b] = s;
+        }
+    G.assign((size_t)nx * p, 0.0);
+    for (int a = 0; a < nx; ++a)
+        for (int i = 0; i < p; ++i) {
+            ld s = 0.0L;
+            for (int b = 0; b < nx; ++b) s += Pm[(size_t)a * nx + b] * (ld)A_s[(size_t)b * p + i];
+            G[(size_t)a * p + i] = (double)s;
+        }
+    return rank;
+}
+
+void fmpc_host_estimator_dft_images(int len, int d, int first, std::vector<double>& img) {
+    typedef long double ld;
+    const ld two_pi = 6.283185307179586476925286766559L;
+    img.assign((size_t)(len / 4) * 2 * 2 * 64, 0.0);
+    for (int y = 0; y < len; ++y)
+        for (int j = 0; j < d && j < 32; ++j) {
+            // the exponent reduced mod len in integers: the argument of cos / sin stays in [0, 2 pi)
+            const long long e = ((long long)(first + j - len / 2) * (long long)(y - len / 2)) % len;
+            const ld ang = -two_pi * (ld)((e + len) % len) / (ld)len;
+            const size_t base = (((size_t)(y / 4) * 2 + (j / 16)) * 2) * 64 + (size_t)(y % 4) * 16 + (j % 16);
+            img[base] = (double)cosl(ang);
+            img[base + 64] = (double)sinl(ang);
+        }
+}

@@ -124,3 +124,12 @@ struct FmpcAffineOut {
 void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
 // operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img);
+
+// ---- estimator (README.md:456-480): ad_est = lsqminnorm(A_s'*A_s, A_s'*(Y_M - b_s)) = G (Y_M - b_s), G = pinv(A_s' A_s) A_s'
+// A_s: p x nx COLUMN-major (MATLAB).  G: nx x p row-major.  Eigenvalues of A_s'A_s below nx * eps * max are treated as zero
+// (minimum-norm solution, as lsqminnorm).  Returns the numerical rank.
+int fmpc_host_estimator_gain(const double* A_s, int p, int nx, std::vector<double>& G);
+// DFT factors of the d-point window starting at frequency index first (0-based, of the fftshift-ed len-point transform):
+// F[y][j] = exp(-2 pi i (first + j - len/2) (y - len/2) / len), as matrix-core operand images [len/4][2 tiles][re, im][64 lanes]
+// (lane = 16 (y mod 4) + (j mod 16); columns j >= d are zero).
+void fmpc_host_estimator_dft_images(int len, int d, int first, std::vector<double>& img);

@@ -82,3 +82,66 @@ def make_test_problem(n=8, m=5, T=10, seed=0, umax=2.0, xf=False, var_order=2, b
     data = dict(x0=rng.random((batch, n)), x0_pre=rng.random((batch, n)),
                 w=rng.random((batch, T * n)), nu0=rng.random((batch, nb * n)))
     return model, data
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Synthetic optics for the estimator (README.md:456-480): the reference loads its Zernike modes (Zs.mat) and its linearised
+# image model (model_approx.mat: A_s, b_s) from files it does not ship.  These stand-ins follow the README's pixel arrays
+# (README.md:236-250, 366-396): OSA/ANSI-indexed, Noll-normalised Zernike modes on the len x len grid x = (-N:2:N)/N, the
+# pin-hole pupil, and y = b_s + A_s alpha linearised at alpha = 0 from the same image formation (README.md:406).
+def _zernike_radial(nr, ma, rho):
+    import math
+    R = np.zeros_like(rho)
+    for s_ in range((nr - ma) // 2 + 1):
+        c_ = (-1) ** s_ * math.factorial(nr - s_) / (math.factorial(s_) * math.factorial((nr + ma) // 2 - s_) * math.factorial((nr - ma) // 2 - s_))
+        R += c_ * rho ** (nr - 2 * s_)
+    return R
+
+
+def zernike_modes(length, n_modes=28):
+    """(n_modes, len, len): OSA/ANSI index j = 0 (piston), 1, 2 (tilts), 3, 4 (defocus: the reference's idx2 = 5, 1-based), ...;
+    unit RMS over the disk, zero outside it."""
+    N = length - 1
+    x = np.arange(-N, N + 1, 2) / N
+    X, Y = np.meshgrid(x, x)
+    rho, th = np.hypot(X, Y), np.arctan2(Y, X)
+    inside = rho <= np.max(np.abs(x))
+    Z = np.zeros((n_modes, length, length))
+    j = 0
+    nr = 0
+    while j < n_modes:
+        for mz in range(-nr, nr + 1, 2):
+            if j >= n_modes:
+                break
+            R = _zernike_radial(nr, abs(mz), rho)
+            norm = np.sqrt((2 if mz else 1) * (nr + 1))
+            Z[j] = norm * R * (np.sin(-mz * th) if mz < 0 else np.cos(mz * th)) * inside
+            j += 1
+        nr += 1
+    return Z
+
+
+def estimator_optics(length=512, dx=6.5e-6, n_modes=28, zd_dist=3.0, AU=1e12):
+    """Everything the estimator is built from: pupil, diversity mode W (defocus), zd_list, the window, and the linearised model
+    A_s (p x (n_modes - 1)), b_s (p) at zero aberration (piston removed, README.md:331)."""
+    Z = zernike_modes(length, n_modes)
+    df = 1.0 / (length * dx)
+    fx = np.arange(-length // 2, length // 2) * df
+    FX, FY = np.meshgrid(fx, -fx)
+    pupil = (np.sqrt(FX ** 2 + FY ** 2) <= (length / 2 - 1) * df).astype(np.float64)
+    W = Z[4]
+    zd_list = np.array([-zd_dist, 0.0, zd_dist])
+    xaxis = np.arange(-length // 2, length // 2) * dx
+    rmin = int(np.nonzero(np.abs(xaxis + 1.0e-4) < 3e-6)[0][0]); rmax = int(np.nonzero(np.abs(xaxis - 1.0e-4) < 3e-6)[0][-1])
+    d = rmax - rmin + 1
+    nx = n_modes - 1
+    b_s = np.zeros(len(zd_list) * d * d); A_s = np.zeros((len(zd_list) * d * d, nx))
+    ft = lambda P_: np.fft.fftshift(np.fft.fft2(np.fft.fftshift(P_))) * dx ** 2
+    for k_, zd in enumerate(zd_list):
+        P0 = pupil * np.exp(1j * zd * W)
+        I0 = ft(P0)[rmin:rmax + 1, rmin:rmax + 1]
+        b_s[k_ * d * d:(k_ + 1) * d * d] = (np.abs(I0) ** 2 * AU).reshape(-1, order="F")
+        for j in range(nx):                       # d|I|^2 / d alpha_j = 2 Re(conj(I) FT(i Z_j P0))
+            dI = ft(1j * Z[j + 1] * P0)[rmin:rmax + 1, rmin:rmax + 1]
+            A_s[k_ * d * d:(k_ + 1) * d * d, j] = (2.0 * np.real(np.conj(I0) * dI) * AU).reshape(-1, order="F")
+    return dict(len=length, dx=dx, AU=AU, Z=Z, pupil=pupil, W=W, zd_list=zd_list, range_min=rmin, range_max=rmax, d=d, A_s=A_s, b_s=b_s, nx=nx)

@@ -212,6 +212,37 @@ int main(int argc, char** argv) {
         }
     }
 
+    // ---- estimator builders: G = pinv(A'A) A' (full rank: G A = I; a repeated column: the minimum-norm solution treats both alike),
+    //      DFT factor images (unit modulus inside the window, zero padding, the centre sample is 1)
+    {
+        const int pe = 60, nxe = 7;
+        std::vector<double> A((size_t)pe * nxe), G;
+        for (auto& v : A) v = N01(rng);
+        if (fmpc_host_estimator_gain(A.data(), pe, nxe, G) != nxe || G.size() != (size_t)nxe * pe) return fail("estimator gain: rank / size");
+        for (int a = 0; a < nxe; ++a)
+            for (int b = 0; b < nxe; ++b) {
+                ld s = 0.0L;
+                for (int i = 0; i < pe; ++i) s += (ld)G[(size_t)a * pe + i] * (ld)A[(size_t)b * pe + i];
+                if (fabsl(s - (a == b ? 1.0L : 0.0L)) > 1e-12L) return fail("estimator gain: G A != I");
+            }
+        for (int i = 0; i < pe; ++i) A[(size_t)6 * pe + i] = A[(size_t)5 * pe + i];           // columns 5 and 6 equal: rank 6
+        if (fmpc_host_estimator_gain(A.data(), pe, nxe, G) != nxe - 1) return fail("estimator gain: rank of a deficient model");
+        for (int i = 0; i < pe; ++i) if (fabs(G[(size_t)5 * pe + i] - G[(size_t)6 * pe + i]) > 1e-12) return fail("estimator gain: minimum norm");
+        std::vector<double> img;
+        const int L = 128, dw = 31, first = 49;
+        fmpc_host_estimator_dft_images(L, dw, first, img);
+        if (img.size() != (size_t)(L / 4) * 256) return fail("dft images: size");
+        for (int y = 0; y < L; ++y)
+            for (int j = 0; j < 32; ++j) {
+                const size_t base = (((size_t)(y / 4) * 2 + (j / 16)) * 2) * 64 + (size_t)(y % 4) * 16 + (j % 16);
+                const double re = img[base], im = img[base + 64];
+                if (j >= dw) { if (re != 0.0 || im != 0.0) return fail("dft images: padding"); continue; }
+                if (fabs(re * re + im * im - 1.0) > 1e-14) return fail("dft images: modulus");
+                const double ang = -2.0 * M_PI * (double)(first + j - L / 2) * (double)(y - L / 2) / L;
+                if (fabs(re - cos(ang)) > 1e-12 || fabs(im - sin(ang)) > 1e-12) return fail("dft images: value");
+            }
+    }
+
     // ---- the model cache of the one-shot entry: capacity 4, least recently used goes first
     {
         int destroyed = 0, last = -1;

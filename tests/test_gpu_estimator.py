@@ -1,0 +1,84 @@
+"""GPU tests of the phase-diversity estimator (fmpc_kernel_estimator.hip, fmpc_est_*; README.md:456-480): the PSF windows as
+partial DFTs on the matrix cores + ad_est = G (Y_M - b_s), against the numpy restatement of the reference's FFT-based code
+(oracle/estimator_ref.py) on synthetic optics (the reference's Zs.mat / model_approx.mat / SNR_10.mat are not shipped).
+Tolerances: 1e-10 relative on Y_M (fp64 both ways; a 512-point sum against an FFT), 1e-8 on ad_est."""
+import numpy as np
+import pytest
+
+from oracle import estimator_ref as er
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _estimator(pkg, op):
+    return pkg.PhaseDiversityEstimator(op["pupil"], op["W"], op["zd_list"], op["dx"], op["range_min"] + 1, op["range_max"] + 1,
+                                       op["A_s"], op["b_s"], AU=op["AU"])
+
+
+def _screens(op, batch, seed, strength=0.3, rough=0.05):
+    """Residual screens: a few Zernike modes + pixel noise (the estimator must not rely on the screen being in the span of Z)."""
+    rng = np.random.default_rng(seed)
+    al = strength * rng.standard_normal((batch, op["nx"])) / np.sqrt(op["nx"])
+    scr = np.tensordot(al, op["Z"][1:], axes=1) + rough * rng.standard_normal((batch, op["len"], op["len"]))
+    return al, scr
+
+
+@pytest.mark.parametrize("length,batch,with_noise", [(128, 5, True), (256, 3, False), (64, 2, True)])
+def test_estimator_matches_the_fft_restatement(pkg, gpu, length, batch, with_noise):
+    import torch
+    op = pkg.synthetic.estimator_optics(length)
+    est = _estimator(pkg, op)
+    assert est.rank == op["nx"] and est.d == op["d"] and est.p == 3 * op["d"] ** 2
+    _, scr = _screens(op, batch, seed=length)
+    rng = np.random.default_rng(1)
+    noise = 1e-3 * np.abs(op["b_s"]).max() * rng.standard_normal((batch, est.p)) if with_noise else None
+    dev = torch.device("cuda:0")
+    ad, Y = est.apply_device(torch.from_numpy(scr).to(dev), None if noise is None else torch.from_numpy(noise).to(dev), want_Y=True)
+    torch.cuda.synchronize()
+    ad, Y = ad.cpu().numpy(), Y.cpu().numpy()
+    for b in range(batch):
+        ad_o, Y_o = er.estimator_step(scr[b], er.pupil_mask(length, op["dx"]), op["W"], op["zd_list"], op["dx"], op["A_s"], op["b_s"],
+                                      None if noise is None else noise[b], AU=op["AU"])
+        assert rel_err(Y[b], Y_o) <= 1e-10, (b, rel_err(Y[b], Y_o))
+        assert rel_err(ad[b], ad_o) <= 1e-8, (b, rel_err(ad[b], ad_o))
+    # host-pointer entry: same numbers
+    ad_h, Y_h = est.apply(scr, noise, want_Y=True)
+    assert np.array_equal(ad_h, ad) and np.array_equal(Y_h, Y)
+    est.close()
+
+
+def test_estimator_at_the_reference_size_and_recovers_small_aberrations(pkg, gpu):
+    """len = 512, window 31 x 31, three diversities (README.md:237, 378-380, 396): against the FFT restatement, and the linear
+    model does what it is for -- a small aberration in the span of the modes comes back to first order."""
+    import torch
+    op = pkg.synthetic.estimator_optics(512)
+    assert op["d"] == 31 and (op["range_min"], op["range_max"]) == er.window_range(512, op["dx"])
+    est = _estimator(pkg, op)
+    rng = np.random.default_rng(7)
+    al = 0.02 * rng.standard_normal((4, op["nx"]))
+    scr = np.tensordot(al, op["Z"][1:], axes=1)
+    ad = est.apply_device(torch.from_numpy(scr).to(torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    ad = ad.cpu().numpy()
+    for b in range(2):
+        ad_o, _ = er.estimator_step(scr[b], op["pupil"], op["W"], op["zd_list"], op["dx"], op["A_s"], op["b_s"], AU=op["AU"])
+        assert rel_err(ad[b], ad_o) <= 1e-8
+    assert max(rel_err(ad[b], al[b]) for b in range(4)) <= 0.1          # second-order terms of the image model
+    # a result does not depend on the batch it was computed in
+    ad1 = est.apply_device(torch.from_numpy(scr[2:3]).to(torch.device("cuda:0"))).cpu().numpy()
+    assert np.array_equal(ad1[0], ad[2])
+    est.close()
+
+
+def test_estimator_argument_checks(pkg, gpu):
+    import ctypes as C
+    lib = pkg.load()
+    h = C.c_void_p()
+    z = np.zeros(64 * 64 * 3)
+    p_ = z.ctypes.data_as(C.c_void_p)
+    assert lib.fmpc_est_create(C.byref(h), 100, 0, 31, 3, p_, p_, 1.0, p_, p_, 3 * 31 * 31, 27, 0) == pkg.FMPC_E_DIM      # len % 64
+    assert lib.fmpc_est_create(C.byref(h), 64, 40, 31, 3, p_, p_, 1.0, p_, p_, 3 * 31 * 31, 27, 0) == pkg.FMPC_E_DIM       # window outside
+    assert lib.fmpc_est_create(C.byref(h), 64, 0, 31, 3, p_, p_, 1.0, p_, p_, 100, 27, 0) == pkg.FMPC_E_DIM                # p != ndiv d^2
+    assert lib.fmpc_est_create(C.byref(h), 64, 0, 31, 3, None, p_, 1.0, p_, p_, 3 * 31 * 31, 27, 0) == pkg.FMPC_E_NULL
+    assert lib.fmpc_est_apply_device(None, 1, p_, None, p_, None, None) == pkg.FMPC_E_NULL
