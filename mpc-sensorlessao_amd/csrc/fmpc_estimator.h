@@ -13,6 +13,7 @@ struct FeParams {
     const double* Fimg;                 // DFT factors of the window as operand images (fmpc_host_estimator_dft_images)
     const double* G; const double* bs;  // nx x p row-major, p
     double* part;                       // workspace [batch][ndiv][len / 16][2][32][32]
+    double* shares;                     // [batch][ndiv][nx] shares of ad_est per diversity
     double* ad_est; double* Yout;       // [batch][nx], [batch][p] or NULL
 };
 

@@ -11,7 +11,10 @@
 // full FFT, but as dense 16 x 16 x 4 products and without a len^2 complex intermediate in memory).  With P = E .* D_k,
 // E = exp(1i*scrn) (one sincos per pixel, shared by the diversities) and D_k = pupil .* exp(1i*zd_k*W) constant per handle.
 //
-// fmpc_est_psf: one workgroup per (16 rows of the screen, realisation).  Wavefront w takes the columns [w len/4, (w+1) len/4):
+// fmpc_est_psf<NW>: one workgroup of NW wavefronts per (16 rows of the screen, realisation): 4 wavefronts for batches that fill
+//   the chip (two workgroups per CU), 8 for a few screens (16 would leave 128 registers per lane: spills; a lone 512 x 512 screen is 32 workgroups: the sequential loop of the
+//   reference estimates ONE screen per timestep, and its latency is what counts there).  Wavefront w takes the columns
+//   [w len/NW, (w+1) len/NW):
 //   per k-step (4 columns) a lane computes its pixel of E, the three P_k = E D_k, and issues 8 matrix instructions per
 //   diversity for T_k (16 x 32 complex) += P_k (16 x 4) F (4 x 32); the four partial T_k meet in LDS, and the workgroup
 //   applies the other factor at once: O_k (32 x 32 complex) = F_blk' T_k (16 more instructions per wavefront), a PARTIAL sum
@@ -27,12 +30,13 @@
 
 typedef double d4e __attribute__((ext_vector_type(4)));
 #define FE_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-#define FE_THREADS 256
+#define FE_TSTRIDE (2 * 16 * 33)         // doubles of one wavefront's partial T in LDS: (re, im) x 16 rows x 32 columns (+1 pad)
 
-__global__ void __launch_bounds__(FE_THREADS, 2) fmpc_est_psf(FeParams P) {
-    __shared__ double sT[4][2][16][33];                       // per wavefront: partial T (re, im), 16 rows x 32 columns
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParams P) {      // (second argument: workgroups per CU here = 2 wavefronts per SIMD either way)
+    extern __shared__ double sTd[];                           // [NW][2][16][33]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int len = P.len, nq = len / 16;                     // k-steps per wavefront
+    const int len = P.len, nq = len / (4 * NW);               // k-steps per wavefront
     const int blk = blockIdx.x, r = blockIdx.y;
     const int y0 = 16 * blk;
     const size_t npx = (size_t)len * len;
@@ -44,24 +48,38 @@ __global__ void __launch_bounds__(FE_THREADS, 2) fmpc_est_psf(FeParams P) {
         for (int t = 0; t < 2; ++t) { Tr[k][t] = (d4e){0, 0, 0, 0}; Ti[k][t] = (d4e){0, 0, 0, 0}; }
     // ---- T_k += P_k F over this wavefront's columns.  Lane (g, c): pixel (row y0 + c, column 4 Q + g) of the A operand,
     //      entry (k-row 4 Q + g, window column 16 t + c) of the B operand.
+    //      Everything a k-step reads is requested one k-step ahead (11 loads per lane): a lone screen has nothing else to
+    //      hide the memory latency behind.
+    const int Q0 = wv * nq;
+    double ph_n, dr_n[FE_MAXDIV], di_n[FE_MAXDIV], f_n[4];
+    {
+        const size_t px = (size_t)(4 * Q0 + g) * len + (y0 + c);
+        ph_n = scrn[px];
+#pragma unroll
+        for (int k = 0; k < FE_MAXDIV; ++k) { const size_t o = (size_t)(k < P.ndiv ? k : 0) * npx + px; dr_n[k] = P.Dre[o]; di_n[k] = P.Dim[o]; }
+        const double* fp = P.Fimg + (size_t)Q0 * 256 + lane;
+        f_n[0] = fp[0]; f_n[1] = fp[64]; f_n[2] = fp[128]; f_n[3] = fp[192];
+    }
     for (int q = 0; q < nq; ++q) {
-        const int Q = wv * nq + q;
-        const size_t px = (size_t)(4 * Q + g) * len + (y0 + c);
-        const double ph = scrn[px];
+        const double ph = ph_n, fr0 = f_n[0], fi0 = f_n[1], fr1 = f_n[2], fi1 = f_n[3];
         double dr[FE_MAXDIV], di[FE_MAXDIV];
 #pragma unroll
-        for (int k = 0; k < FE_MAXDIV; ++k) {
-            const size_t o = (size_t)(k < P.ndiv ? k : 0) * npx + px;
-            dr[k] = P.Dre[o]; di[k] = P.Dim[o];
+        for (int k = 0; k < FE_MAXDIV; ++k) { dr[k] = dr_n[k]; di[k] = di_n[k]; }
+        {
+            const int Qn = Q0 + (q + 1 < nq ? q + 1 : q);
+            const size_t px = (size_t)(4 * Qn + g) * len + (y0 + c);
+            ph_n = scrn[px];
+#pragma unroll
+            for (int k = 0; k < FE_MAXDIV; ++k) { const size_t o = (size_t)(k < P.ndiv ? k : 0) * npx + px; dr_n[k] = P.Dre[o]; di_n[k] = P.Dim[o]; }
+            const double* fp = P.Fimg + (size_t)Qn * 256 + lane;
+            f_n[0] = fp[0]; f_n[1] = fp[64]; f_n[2] = fp[128]; f_n[3] = fp[192];
         }
-        const double* fp = P.Fimg + (size_t)Q * 256 + lane;
-        const double fr0 = fp[0], fi0 = fp[64], fr1 = fp[128], fi1 = fp[192];
-        double sn, cs;
-        sincos(ph, &sn, &cs);
+        double sn, co;
+        sincos(ph, &sn, &co);
 #pragma unroll
         for (int k = 0; k < FE_MAXDIV; ++k) {
             if (k < P.ndiv) {                                    // (uniform)
-                const double pr = cs * dr[k] - sn * di[k], pi = cs * di[k] + sn * dr[k], npi = -pi;
+                const double pr = co * dr[k] - sn * di[k], pi = co * di[k] + sn * dr[k], npi = -pi;
                 Tr[k][0] = FE_MFMA(pr, fr0, Tr[k][0]); Tr[k][0] = FE_MFMA(npi, fi0, Tr[k][0]);
                 Ti[k][0] = FE_MFMA(pr, fi0, Ti[k][0]); Ti[k][0] = FE_MFMA(pi, fr0, Ti[k][0]);
                 Tr[k][1] = FE_MFMA(pr, fr1, Tr[k][1]); Tr[k][1] = FE_MFMA(npi, fi1, Tr[k][1]);
@@ -69,8 +87,8 @@ __global__ void __launch_bounds__(FE_THREADS, 2) fmpc_est_psf(FeParams P) {
             }
         }
     }
-    // ---- per diversity: the four partial T meet in LDS; O = F_blk' T, wavefront w the tile (w / 2, w % 2) of the window
-    const int tu = wv >> 1, tv = wv & 1;
+    // ---- per diversity: the NW partial T meet in LDS; O = F_blk' T, wavefront w < 4 the tile (w / 2, w % 2) of the window
+    const int tu = (wv >> 1) & 1, tv = wv & 1;
     double far[4], fai[4];                                   // A operand of the second product: F[y0 + 4 q2 + g][16 tu + c]
 #pragma unroll
     for (int q2 = 0; q2 < 4; ++q2) {
@@ -86,19 +104,25 @@ __global__ void __launch_bounds__(FE_THREADS, 2) fmpc_est_psf(FeParams P) {
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {          // register rr <-> row 4 rr + g, column 16 t + c
-                        sT[wv][0][4 * rr + g][16 * t + c] = Tr[kk][t][rr];
-                        sT[wv][1][4 * rr + g][16 * t + c] = Ti[kk][t][rr];
+                        sTd[wv * FE_TSTRIDE + (4 * rr + g) * 33 + 16 * t + c] = Tr[kk][t][rr];
+                        sTd[wv * FE_TSTRIDE + 528 + (4 * rr + g) * 33 + 16 * t + c] = Ti[kk][t][rr];
                     }
             }
         }
         __syncthreads();
+        if (wv >= 4) continue;                               // (uniform per wavefront; the barriers above are reached by all)
         d4e Or = {0, 0, 0, 0}, Oi = {0, 0, 0, 0};
 #pragma unroll
         for (int q2 = 0; q2 < 4; ++q2) {
-            // B operand: T[4 q2 + g][16 tv + c], summed over the four wavefronts in a fixed order
-            const int row = 4 * q2 + g, col = 16 * tv + c;
-            const double tr = (sT[0][0][row][col] + sT[1][0][row][col]) + (sT[2][0][row][col] + sT[3][0][row][col]);
-            const double ti = (sT[0][1][row][col] + sT[1][1][row][col]) + (sT[2][1][row][col] + sT[3][1][row][col]);
+            // B operand: T[4 q2 + g][16 tv + c], summed over the wavefronts in a fixed order (groups of four)
+            const int o = (4 * q2 + g) * 33 + 16 * tv + c;
+            double tr = 0.0, ti = 0.0;
+#pragma unroll
+            for (int w4 = 0; w4 < NW; w4 += 4) {
+                const double* b4 = sTd + w4 * FE_TSTRIDE + o;
+                tr += (b4[0] + b4[FE_TSTRIDE]) + (b4[2 * FE_TSTRIDE] + b4[3 * FE_TSTRIDE]);
+                ti += (b4[528] + b4[FE_TSTRIDE + 528]) + (b4[2 * FE_TSTRIDE + 528] + b4[3 * FE_TSTRIDE + 528]);
+            }
             const double nfai = -fai[q2];
             Or = FE_MFMA(far[q2], tr, Or); Or = FE_MFMA(nfai, ti, Or);
             Oi = FE_MFMA(far[q2], ti, Oi); Oi = FE_MFMA(fai[q2], tr, Oi);
@@ -114,38 +138,101 @@ __global__ void __launch_bounds__(FE_THREADS, 2) fmpc_est_psf(FeParams P) {
 }
 
 __global__ void __launch_bounds__(1024) fmpc_est_finish(FeParams P) {
-    extern __shared__ double sY[];                           // p = ndiv d^2 measurements minus b_s
+    extern __shared__ double sY[];                           // d^2 measurements of this diversity minus b_s, then nx x 16 partial sums
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = blockIdx.x, d = P.d, nblk = P.len / 16, p = P.ndiv * d * d;
-    const int u = tid & 31, v = tid >> 5;                    // window row (y frequency), column (x frequency)
-    for (int k = 0; k < P.ndiv; ++k) {
-        if (u < d && v < d) {
-            const double* src = P.part + (((size_t)r * P.ndiv + k) * nblk * 2) * 1024 + u * 32 + v;
-            double orr = 0.0, oi = 0.0;
-            for (int b = 0; b < nblk; ++b) { orr += src[(size_t)b * 2048]; oi += src[(size_t)b * 2048 + 1024]; }
-            const int idx = k * d * d + v * d + u;           // reshape(v_im(:,:,k), [], 1): column-major
-            double y = (orr * orr + oi * oi) * P.scale;
-            if (P.noise) y += P.noise[(size_t)r * p + idx];
-            if (P.Yout) P.Yout[(size_t)r * p + idx] = y;
-            sY[idx] = y - P.bs[idx];
+    const int r = blockIdx.x, k = blockIdx.y, d = P.d, nblk = P.len / 16, dd = d * d, p = P.ndiv * dd;
+    double* sRed = sY + ((dd + 1) & ~1);
+    const int v = tid & 31, u = tid >> 5;                    // window column (x frequency: consecutive lanes read consecutive doubles
+                                                             // of a partial window -- the other way round a wavefront touched 64 cache
+                                                             // lines per load and the kernel took 104 us for one screen), row (y frequency)
+    // One workgroup per (screen, diversity), which leaves its share of ad_est (fmpc_est_combine adds the shares).  Every load sits in a chain of dependent steps (a lone screen: the reference's loop): loads are
+    // issued in batches of 16 (partial windows) and 9 (rows of G) so that a batch costs one memory round trip, not one each.
+    if (u < d && v < d) {
+        const double* src = P.part + (((size_t)r * P.ndiv + k) * nblk * 2) * 1024 + u * 32 + v;
+        double orr = 0.0, oi = 0.0;                        // fixed order (nblk is a multiple of 4)
+        int b = 0;
+        for (; b + 8 <= nblk; b += 8) {
+            double re[8], im[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { re[j] = src[(size_t)(b + j) * 2048]; im[j] = src[(size_t)(b + j) * 2048 + 1024]; }
+            orr += ((re[0] + re[1]) + (re[2] + re[3])) + ((re[4] + re[5]) + (re[6] + re[7]));
+            oi += ((im[0] + im[1]) + (im[2] + im[3])) + ((im[4] + im[5]) + (im[6] + im[7]));
+        }
+        for (; b < nblk; b += 4) {
+            double re[4], im[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { re[j] = src[(size_t)(b + j) * 2048]; im[j] = src[(size_t)(b + j) * 2048 + 1024]; }
+            orr += (re[0] + re[1]) + (re[2] + re[3]);
+            oi += (im[0] + im[1]) + (im[2] + im[3]);
+        }
+        const int il = v * d + u, idx = k * dd + il;       // reshape(v_im(:,:,k), [], 1): column-major
+        double y = (orr * orr + oi * oi) * P.scale;
+        if (P.noise) y += P.noise[(size_t)r * p + idx];
+        if (P.Yout) P.Yout[(size_t)r * p + idx] = y;
+        sY[il] = y - P.bs[idx];
+    }
+    __syncthreads();
+    // this diversity's share of ad_est = G (Y - b_s): every thread a strided share of every row (9 rows at a time: their loads in
+    // one batch), wavefront sums, then a fixed-order sum of the 16 wavefronts
+    constexpr int FE_ROWB = 9;
+    for (int j0 = 0; j0 < P.nx; j0 += FE_ROWB) {
+        double acc[FE_ROWB];
+#pragma unroll
+        for (int jj = 0; jj < FE_ROWB; ++jj) acc[jj] = 0.0;
+        for (int i = tid; i < dd; i += 1024) {
+            const double yv = sY[i];
+            double gv[FE_ROWB];
+#pragma unroll
+            for (int jj = 0; jj < FE_ROWB; ++jj) gv[jj] = P.G[(size_t)(j0 + jj < P.nx ? j0 + jj : j0) * p + k * dd + i];
+#pragma unroll
+            for (int jj = 0; jj < FE_ROWB; ++jj) acc[jj] = fma(gv[jj], yv, acc[jj]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < FE_ROWB; ++jj) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc[jj] += __shfl_xor(acc[jj], o, 64);
+            if (lane == 0 && j0 + jj < P.nx) sRed[(j0 + jj) * 16 + wv] = acc[jj];
         }
     }
     __syncthreads();
-    // ad_est = G (Y - b_s): row j by wavefront j mod 16, fixed-order sums
-    for (int j = wv; j < P.nx; j += 16) {
-        const double* gj = P.G + (size_t)j * p;
-        double acc = 0.0;
-        for (int i = lane; i < p; i += 64) acc = fma(gj[i], sY[i], acc);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) P.ad_est[(size_t)r * P.nx + j] = acc;
+    double* share = P.shares + ((size_t)r * P.ndiv + k) * P.nx;
+    if (tid < P.nx) {
+        const double* q = sRed + tid * 16;
+        share[tid] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                     (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
     }
+}
+
+// ad_est = sum over the diversities of their shares, in a fixed order.  (A launch of its own: the last-arriving workgroup of
+// fmpc_est_finish doing it needs device-scope release fences, which write back an L2 full of partial windows: 35 % slower at
+// 256 screens, measured.)
+__global__ void __launch_bounds__(256) fmpc_est_combine(FeParams P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.batch * P.nx) return;
+    const int r = i / P.nx, j = i - r * P.nx;
+    const double* sh = P.shares + (size_t)r * P.ndiv * P.nx + j;
+    double a = 0.0;
+    for (int kk = 0; kk < P.ndiv; ++kk) a += sh[(size_t)kk * P.nx];
+    P.ad_est[i] = a;
 }
 
 hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
     if (P.len % 64 != 0 || P.len < 64 || P.d < 1 || P.d > 32 || P.ndiv < 1 || P.ndiv > FE_MAXDIV) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fmpc_est_psf, dim3(P.len / 16, P.batch), dim3(FE_THREADS), 0, stream, P);
-    const size_t lds = (size_t)P.ndiv * P.d * P.d * sizeof(double);
-    hipLaunchKernelGGL(fmpc_est_finish, dim3(P.batch), dim3(1024), lds, stream, P);
+    // few screens: 8 wavefronts per workgroup so that a lone screen is 256 wavefronts, not 128
+    const bool wide = (size_t)P.batch * (P.len / 16) < 512 && P.len % 128 == 0;
+    if (wide) {
+        static bool prepared = false;
+        const size_t lds8 = (size_t)8 * FE_TSTRIDE * sizeof(double);
+        if (!prepared) {
+            if (hipFuncSetAttribute((const void*)fmpc_est_psf<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess) return hipErrorInvalidValue;
+            prepared = true;
+        }
+        hipLaunchKernelGGL(fmpc_est_psf<8>, dim3(P.len / 16, P.batch), dim3(512), lds8, stream, P);
+    } else {
+        hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.len / 16, P.batch), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
+    }
+    const size_t lds = ((((size_t)P.d * P.d + 1) & ~(size_t)1) + (size_t)P.nx * 16) * sizeof(double);
+    hipLaunchKernelGGL(fmpc_est_finish, dim3(P.batch, P.ndiv), dim3(1024), lds, stream, P);
+    hipLaunchKernelGGL(fmpc_est_combine, dim3((P.batch * P.nx + 255) / 256), dim3(256), 0, stream, P);
     return hipGetLastError();
 }

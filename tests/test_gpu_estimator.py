@@ -65,9 +65,13 @@ def test_estimator_at_the_reference_size_and_recovers_small_aberrations(pkg, gpu
         ad_o, _ = er.estimator_step(scr[b], op["pupil"], op["W"], op["zd_list"], op["dx"], op["A_s"], op["b_s"], AU=op["AU"])
         assert rel_err(ad[b], ad_o) <= 1e-8
     assert max(rel_err(ad[b], al[b]) for b in range(4)) <= 0.1          # second-order terms of the image model
-    # a result does not depend on the batch it was computed in
-    ad1 = est.apply_device(torch.from_numpy(scr[2:3]).to(torch.device("cuda:0"))).cpu().numpy()
-    assert np.array_equal(ad1[0], ad[2])
+    # a result does not depend on its position in the batch (the launch shape -- 4 or 8 wavefronts per 16 rows -- depends on the
+    # batch SIZE: another summation order, the same numbers to rounding)
+    ad1 = est.apply_device(torch.from_numpy(scr[2:4]).to(torch.device("cuda:0"))).cpu().numpy()
+    assert np.array_equal(ad1[0], ad[2]) and np.array_equal(ad1[1], ad[3])
+    big = np.concatenate([scr, scr, scr, scr, scr])                                  # 20 screens: the 4-wavefront shape
+    adb = est.apply_device(torch.from_numpy(big).to(torch.device("cuda:0"))).cpu().numpy()
+    assert np.array_equal(adb[:4], adb[16:]) and max(rel_err(adb[b], ad[b]) for b in range(4)) <= 1e-11
     est.close()
 
 
