@@ -342,6 +342,12 @@ int fmpc_last_dual_form(fmpc_handle h);
  * fmpc_est_dims     any pointer may be NULL; rank = numerical rank of A_s'A_s found when G was built.
  */
 typedef struct fmpc_est_s* fmpc_est;
+/* The screen the estimator looks at (README.md:453 with :590-601): phase_res = phase_valid(:,:,k) + phase_cor, phase_cor =
+ * sum_j ad_cor(j).*Zs(j+1,:,:), ad_cor = B*u_prev, for a batch of screens: out[b] = phase[b] + sum_j (B u_prev[b])_j Z[j].
+ * npx = len^2 pixels per screen (any order, the same for phase, Z and out); Z: n maps (piston removed); u_prev: batch x m, NULL at
+ * the first step (out = phase, README.md:447).  B is the handle's. */
+int fmpc_phase_residual_device(fmpc_handle h, int batch, long long npx, const double* phase, const double* u_prev,
+                               const double* Z, double* out, void* stream);
 int fmpc_est_create(fmpc_est* out, int len, int first, int d, int ndiv, const double* D_re, const double* D_im,
                     double scale, const double* A_s, const double* b_s, int p, int nx, int device);
 int fmpc_est_destroy(fmpc_est e);

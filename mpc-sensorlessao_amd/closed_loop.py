@@ -118,3 +118,54 @@ class ClosedLoop:
             u = self.step(a[s], None if nu0 is None else nu0[s])
             U0[s].copy_(u); X0[s].copy_(self.x0)
         return U0, X0
+
+
+class AOLoop:
+    """The reference's simulation loop WITH its estimator on the device (README.md:444-626) for `batch` realisations at once:
+    residual screen = phase_valid[k] + sum_j (B u[k-1])_j Z_j (`fmpc_phase_residual_device`), the phase-diversity estimator
+    (`PhaseDiversityEstimator`: three PSF windows, ad_est = G (Y_M - b_s)), x0 = ad_est, x0_pre = the previous ad_est,
+    b_ref from the last two first moves (`fmpc_loop_inputs_device`), the fastMPC solve, u[k] = U(1:nu).
+    Z: (n, len, len) mode maps indexed [j, row, column] (piston removed).  Screens are handed over indexed [b, row, column]."""
+
+    def __init__(self, handle, estimator, Z, batch, n_newton=1, k=1e-2):
+        import ctypes as C
+        import numpy as np
+        import torch
+        self.h, self.est, self.batch, self.n_newton, self.k = handle, estimator, int(batch), int(n_newton), float(k)
+        dev = torch.device("cuda", handle.device)
+        f64 = dict(dtype=torch.float64, device=dev)
+        n, m, T = handle.n, handle.m, handle.T
+        assert Z.shape[0] == n and Z.shape[1] == estimator.len
+        self.Z = torch.from_numpy(np.ascontiguousarray(np.swapaxes(np.asarray(Z, dtype=np.float64), -1, -2))).to(dev)   # column-major planes
+        self.npx = estimator.len ** 2
+        self.scrn = torch.empty((batch, estimator.len, estimator.len), **f64)
+        self.x0 = torch.zeros((batch, n), **f64); self.x0_pre = torch.zeros((batch, n), **f64)
+        self.w = torch.zeros((batch, T * n), **f64)
+        self._scr_x = torch.zeros((batch, n), **f64); self._scr_xp = torch.zeros((batch, n), **f64); self._zero_a = torch.zeros((batch, n), **f64)
+        self.u = [torch.zeros((batch, m), **f64) for _ in range(3)]
+        self.status = torch.zeros(batch, dtype=torch.int32, device=dev); self.iters = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.steps_done = 0
+        self._C, self._torch, self._dev = C, torch, dev
+
+    def step(self, phase_k, noise=None):
+        """phase_k: (batch, len, len) float64 HIP tensor indexed [b, row, column] (phase_valid(:,:,k) of every realisation).
+        Returns (u[k] (batch, m), ad_est (batch, n)); both views valid until two further steps / the next step."""
+        torch, C = self._torch, self._C
+        s = self.steps_done
+        u_new, u1, u2 = self.u[s % 3], self.u[(s - 1) % 3], self.u[(s - 2) % 3]
+        ph = phase_k.transpose(-1, -2).contiguous()                                   # column-major planes, as the mode maps
+        vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+        rc = self.h._lib.fmpc_phase_residual_device(self.h._h, self.batch, self.npx, vp(ph), vp(u1) if s >= 1 else None, vp(self.Z), vp(self.scrn), stream)
+        if rc != 0:
+            from ._lib import FastMPCError
+            raise FastMPCError(rc, "fmpc_phase_residual_device")
+        ad_est = self.est.apply_device(self.scrn, noise, colmajor=True)
+        self.x0_pre.copy_(self.x0) if s >= 1 else self.x0_pre.zero_()
+        self.x0.copy_(ad_est)
+        # b_ref = -M1 B u[k-1] - M2 B u[k-2] (README.md:490-497): the loop-input kernel's w; its x0 / x0_pre go to scratch
+        self.h.loop_inputs_device(self._zero_a, None, u1 if s >= 1 else None, u2 if s >= 2 else None, self._scr_x, self._scr_xp, self.w)
+        self.h.solve_device(self.x0, self.x0_pre, self.w, None, None, self.n_newton, self.k, z_out=None, status=self.status, iters=self.iters,
+                            u0_out=u_new, want_z=False)
+        self.steps_done = s + 1
+        return u_new, self.x0

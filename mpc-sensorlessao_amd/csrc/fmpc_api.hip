@@ -1751,6 +1751,20 @@ extern "C" int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a
                                    x0, x0_pre, w, (hipStream_t)stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
+hipError_t fmpc_launch_phase_residual(int batch, size_t npx, int n, int m, const double* Bt, const double* phase, const double* u,
+                                      const double* Z, double* out, hipStream_t stream);
+// Residual phase screens of a timestep: README.md:453, 590-601 (see include/fastmpc.h).
+extern "C" int fmpc_phase_residual_device(fmpc_handle h, int batch, long long npx, const double* phase, const double* u_prev,
+                                          const double* Z, double* out, void* stream) {
+    if (!h || !phase || !out || (u_prev && !Z)) return FMPC_E_NULL;
+    if (batch < 0 || npx < 0) return FMPC_E_DIM;
+    if (batch == 0 || npx == 0) return FMPC_OK;
+    if (h->n > 32) return FMPC_E_UNSUPPORTED;
+    if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
+    return fmpc_launch_phase_residual(batch, (size_t)npx, h->n, h->m, h->dev.Bt, phase, u_prev, Z, out, (hipStream_t)stream) == hipSuccess
+               ? FMPC_OK : FMPC_E_HIP;
+}
+
 extern "C" int fmpc_unpack(fmpc_handle h, int batch, const double* z, double* U, double* X, double* u0) {
     if (!h || !z) return FMPC_E_NULL;
     if (batch < 0) return FMPC_E_DIM;

@@ -236,3 +236,51 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
     hipLaunchKernelGGL(fmpc_est_combine, dim3((P.batch * P.nx + 255) / 256), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Residual phase screen of a timestep (README.md:453 with :590-601):
+//     ad_cor = B*u_prev ;  phase_cor = sum_j ad_cor(j) .* Zs(j+1,:,:) ;  phase_res = phase_valid(:,:,k) + phase_cor
+// for a batch of screens: out[b][px] = phase[b][px] + sum_j (B u[b])_j Z[j][px].  A workgroup takes 256 pixels and walks over
+// the batch in groups of FE_PB screens, so that the n mode maps (n x npx doubles: 57 MB at n = 27, len = 512) are read once per
+// group, not once per screen.  u == NULL: out = phase (the first step of the loop, README.md:447).
+#define FE_PB 8
+__global__ void __launch_bounds__(256) fmpc_phase_residual(int batch, size_t npx, int n, int m, const double* Bt, const double* phase,
+                                                           const double* u, const double* Z, double* out) {
+    __shared__ double sc[FE_PB][32];                          // ad_cor of the group's screens (n <= 32)
+    const int tid = threadIdx.x;
+    const size_t px = (size_t)blockIdx.x * 256 + tid;
+    for (int b0 = 0; b0 < batch; b0 += FE_PB) {
+        __syncthreads();
+        if (tid < FE_PB * 32) {
+            const int bb = tid >> 5, j = tid & 31, b = b0 + bb;
+            double a = 0.0;
+            if (u && b < batch && j < n) {
+                const double* ub = u + (size_t)b * m;
+                for (int cidx = 0; cidx < m; ++cidx) a = fma(Bt[(size_t)cidx * n + j], ub[cidx], a);      // Bt[c*n + r] = B[r][c]
+            }
+            sc[bb][j] = a;
+        }
+        __syncthreads();
+        if (px < npx) {
+            double acc[FE_PB];
+#pragma unroll
+            for (int bb = 0; bb < FE_PB; ++bb) acc[bb] = b0 + bb < batch ? phase[(size_t)(b0 + bb) * npx + px] : 0.0;
+            if (u) {
+                for (int j = 0; j < n; ++j) {
+                    const double z = Z[(size_t)j * npx + px];
+#pragma unroll
+                    for (int bb = 0; bb < FE_PB; ++bb) acc[bb] = fma(sc[bb][j], z, acc[bb]);
+                }
+            }
+#pragma unroll
+            for (int bb = 0; bb < FE_PB; ++bb) if (b0 + bb < batch) out[(size_t)(b0 + bb) * npx + px] = acc[bb];
+        }
+    }
+}
+
+hipError_t fmpc_launch_phase_residual(int batch, size_t npx, int n, int m, const double* Bt, const double* phase, const double* u,
+                                      const double* Z, double* out, hipStream_t stream) {
+    if (n > 32 || n < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fmpc_phase_residual, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, batch, npx, n, m, Bt, phase, u, Z, out);
+    return hipGetLastError();
+}

@@ -86,3 +86,62 @@ def test_estimator_argument_checks(pkg, gpu):
     assert lib.fmpc_est_create(C.byref(h), 64, 0, 31, 3, p_, p_, 1.0, p_, p_, 100, 27, 0) == pkg.FMPC_E_DIM                # p != ndiv d^2
     assert lib.fmpc_est_create(C.byref(h), 64, 0, 31, 3, None, p_, 1.0, p_, p_, 3 * 31 * 31, 27, 0) == pkg.FMPC_E_NULL
     assert lib.fmpc_est_apply_device(None, 1, p_, None, p_, None, None) == pkg.FMPC_E_NULL
+
+
+def test_phase_residual_kernel_against_numpy(pkg, gpu):
+    """README.md:453, 590-601: out = phase + sum_j (B u)_j Z_j; u = NULL: out = phase.  11 screens (two groups of eight)."""
+    import ctypes as C
+    import torch
+    from tests.util import handle_from_model
+    md = pkg.synthetic.make_model(27, 144, 10)
+    h = handle_from_model(pkg, md)
+    rng = np.random.default_rng(2)
+    batch, npx = 11, 64 * 64 + 37                                                     # not a multiple of the workgroup's 256 pixels
+    phase = rng.standard_normal((batch, npx)); u = rng.standard_normal((batch, 144)); Z = rng.standard_normal((27, npx))
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tp, tu, tz = t(phase), t(u), t(Z)
+    out = torch.empty_like(tp)
+    vp = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    assert h._lib.fmpc_phase_residual_device(h._h, batch, npx, vp(tp), vp(tu), vp(tz), vp(out), None) == 0
+    torch.cuda.synchronize()
+    ref = phase + (u @ md["B"].T) @ Z
+    assert rel_err(out.cpu().numpy(), ref) <= 1e-13
+    assert h._lib.fmpc_phase_residual_device(h._h, batch, npx, vp(tp), None, None, vp(out), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), phase)
+    h.close()
+
+
+def test_simulation_loop_with_the_estimator_against_the_numpy_loop(pkg, gpu):
+    """README.md:444-626 for two realisations over six steps at len = 128: residual screen, estimator, fastMPC, correction.
+    Turbulence screens in and beyond the span of the modes; the deformable mirror's B scaled so that the loop's correction
+    stays in the estimator's linear range.  Against oracle/ao_loop_ref.py: 1e-7 on the estimates and the first moves after
+    six fed-back steps."""
+    import torch
+    from oracle.ao_loop_ref import ao_loop
+    from tests.util import handle_from_model
+    length, steps, R = 128, 6, 2
+    op = pkg.synthetic.estimator_optics(length)
+    md = pkg.synthetic.make_model(27, 144, 10)
+    rng = np.random.default_rng(4)
+    a = np.stack([0.03 * pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)   # (steps, R, n)
+    phase = np.tensordot(a, op["Z"][1:], axes=1) + 0.01 * rng.standard_normal((steps, R, length, length))
+    h = handle_from_model(pkg, md)
+    est = _estimator(pkg, op)
+    loop = pkg.AOLoop(h, est, op["Z"][1:], R, n_newton=1, k=1e-2)
+    dev = torch.device("cuda:0")
+    U, X = [], []
+    for s_ in range(steps):
+        u, x0 = loop.step(torch.from_numpy(np.ascontiguousarray(phase[s_])).to(dev))
+        U.append(u.clone()); X.append(x0.clone())
+    torch.cuda.synchronize()
+    assert int(loop.status.abs().sum()) == 0
+    U = torch.stack(U).cpu().numpy(); X = torch.stack(X).cpu().numpy()
+    for r in range(R):
+        ref = ao_loop(md, op, phase[:, r], 1, 1e-2)
+        assert rel_err(X[:, r], ref["ad_est"]) <= 1e-7, rel_err(X[:, r], ref["ad_est"])
+        assert rel_err(U[:, r], ref["u0"]) <= 1e-7, rel_err(U[:, r], ref["u0"])
+    # the loop does what it is for: the residual it estimates is smaller than the uncorrected aberration
+    assert np.linalg.norm(X[-1]) < np.linalg.norm(a[-1])
+    est.close(); h.close()
