@@ -533,6 +533,43 @@ def _main(real_out):
                                          "simulation knows its turbulence coefficients in advance, README.md:51-93), i.e. one launch in which the workgroup of a "
                                          "realisation walks through the steps with its rows of the first-move form in registers, stopping where a step "
                                          "is not clear-cut (the exact path redoes that step)", **cl)
+        # ------------------------------------------------------------------ estimator (README.md:456-480) and the loop with it
+        try:
+            op_ = pkg.synthetic.estimator_optics(512)
+            est_ = pkg.PhaseDiversityEstimator(op_["pupil"], op_["W"], op_["zd_list"], op_["dx"], op_["range_min"] + 1, op_["range_max"] + 1,
+                                               op_["A_s"], op_["b_s"])
+            fl_est = 3 * (8 * 512 * 512 * 32 + 8 * 32 * 512 * 32)        # executed: 8 real flops per complex multiply-add, both products, 32 of 31 columns
+            es = {"what": "phase-diversity estimator at the reference's size (len 512, 31 x 31 window, three diversities; synthetic optics: "
+                          "Zs.mat / model_approx.mat are not shipped): PSF windows as partial DFTs on the fp64 matrix cores + ad_est = G (Y_M - b_s)",
+                  "executed_flops_per_screen": fl_est}
+            rng_ = np.random.default_rng(5)
+            for Be in (1, 256):
+                scr_ = to_dev(0.3 * rng_.standard_normal((Be, 512, 512)))
+                ee, se, _ = timed(lambda: est_.apply_device(scr_, colmajor=True), 10, 3)
+                es["screens_%d" % Be] = {"value": Be * se / ee, "unit": "screens/s", "us_per_call": ee / se * 1e6,
+                                         "executed_tflops": fl_est * Be * se / ee / 1e12, "frac_of_fp64_peak": fl_est * Be * se / ee / 1e12 / FP64_PEAK_TFLOPS}
+                del scr_
+            # the reference's loop, one realisation: residual screen + estimator + loop inputs + fastMPC per timestep
+            a_np = pkg.synthetic.make_realisation(model, r=3, steps=40)[1:41]
+            ph_ = to_dev(np.tensordot(0.03 * a_np, op_["Z"][1:], axes=1)[:, None])            # (steps, 1, 512, 512)
+            ao_ = pkg.AOLoop(h, est_, op_["Z"][1:], 1, n_newton=args.n_newton, k=K_BAR)
+            for s_ in range(5):
+                ao_.step(ph_[s_])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for s_ in range(5, 40):
+                ao_.step(ph_[s_])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            assert int(ao_.status.abs().sum()) == 0
+            es["loop_with_estimator_1_realisation"] = {"what": "README.md:444-626 per timestep on the device: residual screen (57 MB of mode maps), three PSF "
+                                                                "windows, ad_est, b_ref, fastMPC step, first moves", "ms_per_loop_step": dt / 35 * 1e3,
+                                                       "value": 35 / dt, "unit": "loop steps/s"}
+            extra["estimator"] = es
+            est_.close()
+            del ph_, ao_
+        except Exception as ex_:                                                               # never lose the bench line over an extra
+            extra["estimator"] = {"error": repr(ex_)}
         # ------------------------------------------------------------------ configs[0] on the device: VAR(1), T = 10, ramp rows
         T0 = 10
         m0 = pkg.synthetic.make_model(n, m, T0, var_order=1)
