@@ -8,6 +8,7 @@
   dense_w512      512 problems with a disturbance w: the dense form of the dual solve with all T n columns of w
   closed512       closed loop, 512 realisations: fmpc_loop_step_device per step
   walk64          closed loop, 64 realisations, a recorded stretch of 300 steps in one call (fmpc_first_move_run: one launch)
+  estimator256    phase-diversity estimator, 256 screens of 512 x 512 per call (fmpc_est_psf<4>, fmpc_est_finish, fmpc_est_combine)
   budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
                   + compaction, continuation of the ~9 % that go on by the tiled kernel"""
 import importlib, os, sys
@@ -20,6 +21,16 @@ if target in ("general_tiled", "tiled_f32"):
 import numpy as np, torch
 pkg = importlib.import_module("mpc-sensorlessao_amd")
 dev = torch.device("cuda:0")
+if target == "estimator256":
+    op = pkg.synthetic.estimator_optics(512)
+    est = pkg.PhaseDiversityEstimator(op["pupil"], op["W"], op["zd_list"], op["dx"], op["range_min"] + 1, op["range_max"] + 1, op["A_s"], op["b_s"])
+    scr = torch.from_numpy(0.3 * np.random.default_rng(0).standard_normal((256, 512, 512))).to(dev)
+    for _ in range(reps):
+        ad = est.apply_device(scr, colmajor=True)
+    torch.cuda.synchronize()
+    print(target, "ad_est norm", float(ad.norm()))
+    est.close()
+    sys.exit(0)
 n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512") else (64 if target == "walk64" else 2000))
 model = pkg.synthetic.make_model(n, m, T)
 data = pkg.synthetic.make_replay_batch(model, r=0, steps=B)
