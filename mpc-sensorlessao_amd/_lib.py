@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FMPC_LIB") or os.path.join(_HERE, "lib", "libfastmpc.so")
@@ -91,6 +92,15 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C mpc-sensorlessao_amd/csrc`). "
             "This package has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  Whichever runtime is loaded FIRST serves the
+    # process: with this library first (it resolves /opt/rocm's), a later `import torch` brings a second runtime and the
+    # library's hipGetDeviceCount then finds no device.  Let torch, when installed, go first; plain C / ctypes clients
+    # without torch are unaffected.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
