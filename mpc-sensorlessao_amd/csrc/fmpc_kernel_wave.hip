@@ -71,6 +71,11 @@ struct FwCfg {
     static constexpr int RC = N;                  // tile column that carries the rhs / y_i
     static constexpr int LD = 29;                 // LDS tile leading dimension (odd); col 28 = dump
     static constexpr int LDG = (N + 2) & ~1;      // HBM factor tile leading dimension (even)
+    // Factor stream of a stage (per-problem factor): L as its lower triangle packed by columns -- column j = L[j..N-1][j] at
+    // LOFF(j), N (N + 1) / 2 doubles instead of a N x LDG tile (the upper half was never read: 0.38 GB of 3.2 GB per 2048-problem
+    // launch, written and read back) -- followed by the U1 tile.  The exported shared factor keeps full tiles.
+    static constexpr int LPACK = (N * (N + 1) / 2 + 1) & ~1;
+    __host__ __device__ static constexpr int LOFF(int j) { return j * N - j * (j - 1) / 2; }
     static constexpr int TILE = 32 * LD;
     static constexpr int PER_WAVE = 2 * TILE;                 // tA, tB
     static constexpr int IMG_D = 3 * 4 * 64;                  // subtiles (0,0),(0,1),(1,1)
@@ -213,7 +218,7 @@ struct FwView {
         b = wsp + L.b; nu = wsp + L.nu; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
-        fstride = 2 * N * FwCfg<N>::LDG;
+        fstride = FwCfg<N>::LPACK + N * FwCfg<N>::LDG;      // L packed by columns (lower triangle), then the U1 tile
         if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; fstride = 6 * N * FwCfg<N>::LDG; }   // the factor IS the product
     }
 };
@@ -1310,16 +1315,25 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             if (cl < N && (!hi || ex)) {
                 // U1 row-major for the backward sweep.  U2 = L^-1 Y_{i,i+2} is not streamed (the backward sweep applies
                 // L^-1 to the constant block times d_nu_{i+2} instead); only the exported shared factor carries it
-                double* gdst = f + (hi ? 2 : 1) * N * LDG + cl;
+                double* gdst = f + (ex ? (hi ? 2 : 1) * N * LDG : C::LPACK) + cl;
 #pragma unroll
                 for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];
             }
             if (lane < N) {
-                // column j of L contiguous in r.  Shared (exported) tiles carry exact zeros on and above
-                // the diagonal so that the shared sweeps need no per-step masking; otherwise that part is unused.
-                double* gl = f + lane;
+                if (ex) {
+                    // column j of L contiguous in r.  Shared (exported) tiles carry exact zeros on and above
+                    // the diagonal so that the shared sweeps need no per-step masking
+                    double* gl = f + lane;
 #pragma unroll
-                for (int j = 0; j < N; ++j) gl[j * LDG] = (ex && j >= lane) ? 0.0 : row[j];
+                    for (int j = 0; j < N; ++j) gl[j * LDG] = (j >= lane) ? 0.0 : row[j];
+                } else {
+                    // packed lower triangle: lane r writes L[r][j] to LOFF(j) + r - j = (LOFF(j) - j) + r -- one per-lane base and a
+                    // constant per column.  No predicate: a lane above the diagonal (r < j) writes into the tail of an EARLIER
+                    // column, which is written afterwards (j descending; a wavefront's stores to one address keep their order)
+                    double* gl = f + lane;
+#pragma unroll
+                    for (int j = N - 1; j >= 0; --j) gl[C::LOFF(j) - j] = row[j];
+                }
                 W.rsg[i * 32 + lane] = myrs;
             }
             if (ex) {
@@ -1394,6 +1408,9 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     const int lr = lane < N ? lane : N - 1;
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
     const double* facp = W.fac;
+    const bool ex = P->mode == FW_MODE_EXPORT;                 // the exported shared factor keeps full tiles (FwCfg::LPACK)
+    const int u1o = (ex ? N * LDG : C::LPACK) + lc;
+    const int lo = ex ? lc : lr;
     const double* rsp = W.rsg;
     const double* imgs = P->V.img + C::IMG_D + C::IMG_1;       // [block][row j][col c] copies of the constant blocks
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
@@ -1402,14 +1419,14 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     int cur2 = -1;                    // block whose rows are in y2
     {
         const int i = W.nb - 1;
-        const double* f = facp + (size_t)i * W.fstride + lc;
+        const double* f = facp + (size_t)i * W.fstride;
 #pragma unroll
-        for (int j = 0; j < N; ++j) { g1[j] = f[(N + j) * LDG]; gl[j] = f[j * LDG]; }
+        for (int j = 0; j < N; ++j) { g1[j] = f[u1o + j * LDG]; gl[j] = f[(ex ? j * LDG : C::LOFF(j) - j) + lo]; }
         yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
     }
     for (int i = W.nb - 1; i >= 0; --i) {
         const int ip = i > 0 ? i - 1 : 0;                      // stage to prefetch (harmless re-read at i = 0)
-        const double* fp = facp + (size_t)ip * W.fstride + lc;
+        const double* fp = facp + (size_t)ip * W.fstride;
         double v = yv_n;
         const double rsv = rs_n;
         const int b2 = P->V.i2[i];
@@ -1424,7 +1441,7 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         for (int j = 0; j < N; ++j) tA[j * LD + lc] = g1[j];
         fw_wave_fence();
 #pragma unroll
-        for (int j = 0; j < N; ++j) g1[j] = fp[(N + j) * LDG];
+        for (int j = 0; j < N; ++j) g1[j] = fp[u1o + j * LDG];
         yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
         double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
         {
@@ -1453,7 +1470,7 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         for (int j = 0; j < N; ++j) tB[j * LD + lc] = gl[j];
         fw_wave_fence();
 #pragma unroll
-        for (int j = 0; j < N; ++j) gl[j] = fp[j * LDG];
+        for (int j = 0; j < N; ++j) gl[j] = fp[(ex ? j * LDG : C::LOFF(j) - j) + lo];      // (lanes above the diagonal read the tail of an earlier column: unused)
         double res = 0.0;
         {
             const fw_clds_t cl = tB + lr * LD;
