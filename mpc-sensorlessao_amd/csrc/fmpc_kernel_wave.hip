@@ -1654,15 +1654,26 @@ FW_FN void fw_phase_zcopy(FwKP Pin, int p) {
 //   mid : factorisation + forward sweep, backward sweep             returns "Y not PD"
 //   post: d_z with the new iterate for t = 1, line-search dots, nu += t d_nu (the caller passes t back in a second call
 //         only in the rare case t != 1: fw_phase_zfix)
+// One non-inlined function per Newton ITERATION (fw_iteration) instead of one per phase group: a function that uses all 256
+// registers saves and restores the ~112 callee-saved ones on every call (57 KB of scratch per call and problem, HBM traffic at
+// 2048 resident problems): 2.84 -> 2.62 GB per launch, same time (-DFW_THREE_CALLS: the three-call variant, for A/B runs).
+#ifndef FW_THREE_CALLS
+#define FW_ONE_CALL
+#endif
+#ifdef FW_ONE_CALL
+#define FW_PH FW_IN
+#else
+#define FW_PH FW_FN
+#endif
 template <int N>
-FW_FN void fw_phase_pre(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
+FW_PH void fw_phase_pre(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
     do_init = __builtin_amdgcn_readfirstlane(do_init);
     if (do_init >= 0) fw_phase_init<N>(Pin, p, do_init);
     fw_phase_CT<N, 0>(Pin, p, lds_g, red_g, first);
     fw_phase_C2<N>(Pin, p, lds_g, red_g + 1, first);
 }
 template <int N>
-FW_FN int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
+FW_PH int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
     const int npd = fw_phase_factor<N>(Pin, p, lds_g, first);
     const FwKP P = fw_uniform(Pin);
     if (P->mode == FW_MODE_EXPORT && (threadIdx.x & 63) == 0) *P->sh_ok = npd ? 0 : 1;
@@ -1673,7 +1684,7 @@ FW_FN int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
 template <int N> FW_FN void fw_phase_zfix(FwKP Pin, int p, double t);
 // out: red[0] = accepted step length t, red[1] = 1 if the search collapsed (FMPC_W_LINESEARCH)
 template <int N>
-FW_FN void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int first, double rho2) {
+FW_PH void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int first, double rho2) {
     fw_phase_CT<N, 1>(Pin, p, lds_g, red_g, first);
     const fw_lds_t red = (fw_lds_t)red_g;
     fw_wave_fence();
@@ -1695,6 +1706,27 @@ FW_FN void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int firs
     if ((threadIdx.x & 63) == 0) { red[0] = t; red[1] = collapsed; }
     fw_wave_fence();
 }
+#ifdef FW_ONE_CALL
+// One Newton iteration as ONE non-inlined function (one save / restore of the callee-saved registers per iteration instead of
+// three).  Returns 0 = stepped (red[0] = t, red[1] = collapsed), 1 = converged before the step, 2 / 3 = Phi / Schur complement
+// not positive definite.
+template <int N>
+FW_FN int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
+    const FwKP P = fw_uniform(Pin);
+    fw_phase_pre<N>(Pin, p, lds_g, red_g, first, do_init);
+    const fw_lds_t red = (fw_lds_t)red_g;
+    fw_wave_fence();
+    const double rd2 = red[0], rp2 = red[1];
+    const bool bad = red[2] != 0.0;
+    fw_wave_fence();
+    const double rho2 = rd2 + rp2;
+    if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) return 1;       // inf_newton_solver.m:19-22
+    if (bad) return 2;
+    if (fw_phase_mid<N>(Pin, p, lds_g, first)) return 3;
+    fw_phase_post<N>(Pin, p, lds_g, red_g, first, rho2);
+    return 0;
+}
+#endif
 // the start point / b / nu of a problem outside the merged functions (cold-start path)
 template <int N>
 FW_FN void fw_phase_init_fn(FwKP Pin, int p, int write_z) { fw_phase_init<N>(Pin, p, write_z); }
@@ -1895,6 +1927,13 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         int do_init = (!cold_mode && active) ? (P->zinit ? 0 : 1) : -1;       // an explicit start point is read where it lies (FwView::zs)
         for (int it = it0; it < max_iter && !done; ++it) {
             const int first = (P->zinit != nullptr && nsteps == 0) ? 1 : 0;     // z_out not written yet: read z_init
+#ifdef FW_ONE_CALL
+            const int code = fw_iteration<N>(P, p, lds, red, first, do_init);
+            do_init = -1;
+            if (code == 1) break;
+            if (code == 2) { st = FMPC_E_NOT_PD_PHI; break; }
+            if (code == 3) { st = FMPC_E_NOT_PD_SCHUR; break; }
+#else
             fw_phase_pre<N>(P, p, lds, red, first, do_init);               // [start,] r_d, r_p, right-hand side
             do_init = -1;
             fw_wave_fence();
@@ -1910,6 +1949,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FW_KTICK(4);
             fw_phase_post<N>(P, p, lds, red, first, rho2);  // d_z and z + d_z, line search, nu += t d_nu
+#endif
             fw_wave_fence();
             const double t = red[0];
             if (red[1] != 0.0) st = FMPC_W_LINESEARCH;
