@@ -1710,8 +1710,13 @@ FW_PH void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int firs
 // One Newton iteration as ONE non-inlined function (one save / restore of the callee-saved registers per iteration instead of
 // three).  Returns 0 = stepped (red[0] = t, red[1] = collapsed), 1 = converged before the step, 2 / 3 = Phi / Schur complement
 // not positive definite.
+#ifdef FW_INLINE_ITER                             // A/B switch: the iteration inlined into the kernel spills 1148 bytes per lane: 8 % slower
+#define FW_ITER FW_IN
+#else
+#define FW_ITER FW_FN
+#endif
 template <int N>
-FW_FN int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
+FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
     const FwKP P = fw_uniform(Pin);
     fw_phase_pre<N>(Pin, p, lds_g, red_g, first, do_init);
     const fw_lds_t red = (fw_lds_t)red_g;
