@@ -261,6 +261,376 @@ __device__ __noinline__ int ft_dense_r(double* sL, const double* R2P, int MP, co
     return bad;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// P3 of the kernel below (factor + forward sweep) as a function of its own, with a register allocation of its own.  It takes
+// nothing but the kernel's parameter block: every pointer and size is rebuilt from it (scalar arithmetic), the LDS map from
+// the same layout function, the tile ownership from the wavefront number.  Returns true when a pivot was not positive.
+typedef const FtParams __attribute__((address_space(4))) * FtKP;
+__device__ __forceinline__ FtKP ft_params() { return (FtKP)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ FtKP ft_uniform(FtKP P) {             // a function argument arrives in VGPRs: make it scalar again
+    const unsigned long long a = (unsigned long long)P;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (FtKP)(((unsigned long long)hi << 32) | lo);
+}
+template <typename R, int NB, int NW, int NL, bool DR>
+__device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
+    typedef FtT<R> TT;
+    typedef typename TT::v4 v4;
+    constexpr int NS = NB * (NB + 1) / 2, NQ = NB * NB;
+    constexpr int SS = (NS + NW - 1) / NW, MS = (NQ + NW - 1) / NW;
+    constexpr int STAGE_TILES = 3 * NB * NB, REC_TILES = 3 * NB;
+    constexpr bool TS = !(sizeof(R) == 8 && NW == 2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FtKP P = ft_uniform(Pin);
+    const int n = P->M.n, m = P->M.m, T = P->M.T, nb = P->M.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int mb = P->V.mb, cn = P->V.cn, nl = P->V.nl;
+    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb, DR ? ft_pr_doubles(n, m) : 0);
+    R* sSLOT = (R*)(smem + LL.slot);
+    R* sLT = (R*)(smem + LL.lt);
+    R* sWT = (R*)(smem + LL.wt);
+    R* sYSH = (R*)(smem + LL.ysh);
+    int* sflag = (int*)(smem + LL.flag);
+    const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R), DR ? 1 : 0);
+    double* wsp = P->ws + (size_t)blockIdx.x * P->ws_stride;
+    double* yv = wsp + L.y;
+    R* fac = (R*)(wsp + L.fac);
+    R* gws = (R*)(wsp + L.gt);
+    const R* yimg = (const R*)P->V.yimg;
+    const int* Vi1 = P->V.i1; const int* Vi2 = P->V.i2;
+    const int firstS = wv, firstM1 = ((wv - NS) % NW + NW) % NW, firstM2 = ((wv - NS - NQ) % NW + 2 * NW) % NW;
+    int sI[SS], sJ[SS];
+#pragma unroll
+    for (int sl = 0; sl < SS; ++sl) {
+        int t = firstS + sl * NW, I = 0;
+        if (t < NS) { while (t >= NB - I) { t -= NB - I; ++I; } sI[sl] = I; sJ[sl] = I + t; }
+        else { sI[sl] = -1; sJ[sl] = -1; }
+    }
+    FT_T0();
+    bool fail = false;
+    int ub = 1, uc = 2;                                     // !TS: roles of the slots 1 and 2
+    // Loads queue behind the stores a wave has issued (vmcnt is in order), so everything stage i + 1 needs from
+    // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
+    // before that stage's factor tiles are stored.
+    v4 nS[SS], fS[SS], nM1[MS];                          // S0 tiles of stage i + 1 (loaded, updated in phase A) and i + 2 (in flight)
+    auto requestS = [&](int i, v4 (&dst)[SS]) {
+#pragma unroll
+        for (int sl = 0; sl < SS; ++sl)
+            if (sI[sl] >= 0) {
+                const R* gt = gws + ((size_t)i * NS + firstS + sl * NW) * FT_TILE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[sl][r] = gt[TT::row(g, r) * 16 + c];
+            }
+    };
+    auto requestM = [&](int i) {
+        const R* Y1 = yimg + (size_t)Vi1[i] * NQ * FT_TILE;
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) {
+            const int q1 = firstM1 + sl * NW;
+            if (q1 < NQ) {
+                const R* yt = Y1 + (size_t)q1 * FT_TILE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nM1[sl][r] = yt[TT::row(g, r) * 16 + c];
+            }
+        }
+    };
+    v4 cS[SS];                                             // S tiles of the current stage (S0_i - U2_{i-2}' U2_{i-2})
+    if (TS) { requestS(0, cS); requestS(nb > 1 ? 1 : 0, nS); }
+    else requestS(0, nS);                                  // (!TS: no third set, nS is the current stage's at the top of a stage)
+    requestM(0);
+    for (int i = 0; i < nb; ++i) {
+        R* UA = sSLOT;
+        R* UB = sSLOT + (size_t)(TS ? 1 : ub) * NQ * FT_TILE;
+        R* UC = sSLOT + (size_t)(TS ? 1 : uc) * NQ * FT_TILE;
+        R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
+        const R* Y2 = yimg + (size_t)Vi2[i] * NQ * FT_TILE;
+        // ---------------- phase A: all tiles of the stage, independent
+        v4 aS[SS], aM1[MS];
+#pragma unroll
+        for (int sl = 0; sl < SS; ++sl) aS[sl] = TS ? cS[sl] : nS[sl];
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
+#pragma unroll
+        for (int sl = 0; sl < SS; ++sl) {
+            const int I = sI[sl], J = sJ[sl];
+            if (I >= 0) {
+#pragma unroll 1
+                for (int j = 0; j < NB; ++j) {
+                    ft_xtz_sub<R>(aS[sl], UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
+                    if (TS) ft_xtz_sub<R>(nS[sl], UB + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);   // for S_{i+1}
+                    else ft_xtz_sub<R>(aS[sl], UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
+                }
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) {
+            const int q1 = firstM1 + sl * NW;
+            if (q1 < NQ) {
+                const int I = q1 / NB, J = q1 - I * NB;
+#pragma unroll 1
+                for (int j = 0; j < NB; ++j)
+                    ft_xtz_sub<R>(aM1[sl], UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
+            }
+        }
+        ft_lds_barrier();                                      // Ua, Ub are dead from here: their slots take U1_i, U2_i
+        FT_TICK(3);
+        R* U1N = UA; R* U2N = TS ? UB : UC;
+        if (!TS && i + 1 < nb) requestS(i + 1, nS);
+        if (i + 1 < nb) requestM(i + 1);
+        if (TS) requestS(i + 2 < nb ? i + 2 : nb - 1, fS);     // (harmless re-read at the end of the horizon)
+        v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) {
+            const int q2 = firstM2 + sl * NW;
+            if (q2 < NQ) {
+                const R* yt = Y2 + (size_t)q2 * FT_TILE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aM2[sl][r] = yt[TT::row(g, r) * 16 + c];
+            }
+        }
+        // ---------------- phase B: the 16-row blocks of the stage, in order
+        for (int kb = 0; kb < NB; ++kb) {
+            int cnt = n - 16 * kb; cnt = cnt > 16 ? 16 : (cnt < 0 ? 0 : cnt);
+            // (1) products with the rows of this stage already done
+#pragma unroll
+            for (int sl = 0; sl < SS; ++sl)
+                if (sI[sl] == kb)
+                    for (int j = 0; j < kb; ++j)
+                        ft_xtz_sub<R>(aS[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
+                                      sLT + (size_t)ft_lt_index(NB, j, sJ[sl]) * FT_TILE, lane);
+#pragma unroll
+            for (int sl = 0; sl < MS; ++sl) {
+                const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
+                if (q1 < NQ && q1 / NB == kb)
+                    for (int j = 0; j < kb; ++j)
+                        ft_xtz_sub<R>(aM1[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
+                                      U1N + (size_t)(j * NB + q1 % NB) * FT_TILE, lane);
+                if (q2 < NQ && q2 / NB == kb) {
+                    for (int j = 0; j < kb; ++j)
+                        ft_xtz_sub<R>(aM2[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
+                                      U2N + (size_t)(j * NB + q2 % NB) * FT_TILE, lane);
+                }
+            }
+            // (2) the rhs column of this row block, still unscaled: shared with the owners of M1(kb,cn), M2(kb,cn);
+            //     the owner of the diagonal tile factors it
+#pragma unroll
+            for (int sl = 0; sl < SS; ++sl) {
+                if (sI[sl] == kb && sJ[sl] == cn && c == nl) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sYSH[TT::row(g, r)] = aS[sl][r];
+                }
+                if (sI[sl] == kb && sJ[sl] == kb) {
+                    v4 Ro, Wo;
+                    __builtin_amdgcn_s_setprio(3);             // a chain of dependent steps: issue ahead of the SIMD's other wave
+                    bool ok;
+                    if (kb < NB - 1) ok = ft_potrf16_ct<R, 16>(aS[sl], c, g, Ro, Wo);        // (all blocks but the last are full)
+                    else if (NL >= 0) ok = ft_potrf16_ct<R, (NL >= 0 ? NL : 0)>(aS[sl], c, g, Ro, Wo);
+                    else ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (!ok && lane == 0) sflag[0] = 1;
+                    R* ri = facs + (size_t)(kb * REC_TILES) * FT_TILE;   // R(kb,kb)^-1 = W' for the backward sweep
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sWT[c * FT_WLD + TT::row(g, r)] = Wo[r];
+                        ri[c * 16 + TT::row(g, r)] = Wo[r];
+                    }
+                    if (kb == cn && c == nl) {                 // y of this row block is the rhs column of the factored tile
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * kb + TT::row(g, r);
+                            if (row < n) yv[i * n + row] = (double)Ro[r];
+                        }
+                    }
+                    aS[sl] = Ro;
+                }
+            }
+            ft_lds_barrier();
+            FT_TICK(4);
+            // (3) scale the tiles of the row: Rwide(kb, .) = W P(kb, .)
+            R wop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wop[r] = sWT[TT::row(g, r) * FT_WLD + c];
+#pragma unroll
+            for (int sl = 0; sl < SS; ++sl) {
+                if (sI[sl] == kb && sJ[sl] > kb) {
+                    v4 o = {0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], aS[sl][r], o);
+                    R* dl = sLT + (size_t)ft_lt_index(NB, kb, sJ[sl]) * FT_TILE;
+                    R* dg = facs + (size_t)(kb * REC_TILES + sJ[sl]) * FT_TILE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                    if (sJ[sl] == cn && c == nl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * kb + TT::row(g, r);
+                            if (row < n) yv[i * n + row] = (double)o[r];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < MS; ++sl) {
+                const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
+                if (q1 < NQ && q1 / NB == kb) {
+                    const int J = q1 % NB;
+                    v4 pv = aM1[sl];
+                    if (J == cn && c == nl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = sYSH[TT::row(g, r)];
+                    }
+                    v4 o = {0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
+                    R* dl = U1N + (size_t)q1 * FT_TILE;
+                    R* dg = facs + (size_t)(kb * REC_TILES + NB + J) * FT_TILE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                }
+                if (q2 < NQ && q2 / NB == kb) {
+                    const int J = q2 % NB;
+                    v4 pv = aM2[sl];
+                    if (J == cn && c == nl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = sYSH[TT::row(g, r)];
+                    }
+                    v4 o = {0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
+                    R* dl = U2N + (size_t)q2 * FT_TILE;
+                    R* dg = facs + (size_t)(kb * REC_TILES + 2 * NB + J) * FT_TILE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                }
+            }
+            ft_lds_barrier();
+            FT_TICK(5);
+            if (sflag[0]) { fail = true; break; }              // uniform: read after the barrier
+        }
+        if (fail) break;
+        // next stage: its S tiles are the updated set, the set in flight becomes the next one
+#pragma unroll
+        for (int sl = 0; sl < SS; ++sl) { if (TS) { cS[sl] = nS[sl]; nS[sl] = fS[sl]; } }
+        if (!TS) { const int t = ub; ub = uc; uc = t; }        // Ub <- U2_i (slot uc), Uc <- old Ub
+    }
+    return fail;
+}
+
+// The S pre-pass of the kernel below (S0_i = Y_ii const + B W_i B' of every block row) as a function of its own: see ft_phase_factor.
+// Workgroup-collective (barriers inside): every thread of the workgroup calls it.
+template <typename R, int NB, int NW, bool DR>
+__device__ __noinline__ void ft_phase_spre(FtKP Pin) {
+    typedef FtT<R> TT;
+    typedef typename TT::v4 v4;
+    constexpr int NT = NW * 64;
+    constexpr int NS = NB * (NB + 1) / 2, NQ = NB * NB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FtKP P = ft_uniform(Pin);
+    const int n = P->M.n, m = P->M.m, T = P->M.T, nb = P->M.nb;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int mb = P->V.mb, cn = P->V.cn, nl = P->V.nl;
+    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb, DR ? ft_pr_doubles(n, m) : 0);
+    R* sBT = (R*)(smem + LL.bt);
+    R* sWL = (R*)(smem + LL.wl);
+    const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R), DR ? 1 : 0);
+    double* wsp = P->ws + (size_t)blockIdx.x * P->ws_stride;
+    double* ztw = wsp + L.zt;
+    const int ZLD = n + 1;
+    double* winv = wsp + L.winv;
+    double* yv = wsp + L.y;
+    R* gws = (R*)(wsp + L.gt);
+    const R* yimg = (const R*)P->V.yimg;
+    const int* ViD = P->V.iD;
+    {
+        const R* src = (const R*)P->V.btimg;
+        for (int q = tid; q < mb * NB * FT_TILE; q += NT) sBT[q] = src[q];
+    }
+    {
+        // One block row (all its NS upper-triangular tiles) per wave and chunk: the B' tiles and Phi^-1 read from LDS
+        // feed NS products (one LDS read per MFMA instead of three; the LDS port is what bounds this phase).
+        constexpr int WPT = (NW * 16 * 16 + NT - 1) / NT;      // Phi^-1 entries per thread and chunk (mb <= 16)
+        R wreg[WPT];
+        auto wload = [&](int i0) {
+#pragma unroll
+            for (int e = 0; e < WPT; ++e) {
+                const int q = tid + e * NT;
+                const int ii = q / (mb * 16), k = q - ii * (mb * 16);
+                const bool ok = q < NW * mb * 16 && i0 + ii < T && k < m;
+                const R v = (R)winv[ok ? (size_t)(i0 + ii) * m + k : 0];
+                wreg[e] = ok ? v : (R)0;
+            }
+        };
+        wload(0);
+        for (int i0 = 0; i0 < nb; i0 += NW) {
+            __syncthreads();                                   // (the previous chunk's products are done with sWL)
+#pragma unroll
+            for (int e = 0; e < WPT; ++e) {
+                const int q = tid + e * NT;
+                if (q < NW * mb * 16) sWL[q] = wreg[e];
+            }
+            __syncthreads();
+            const int i = i0 + wv;
+            if (i0 + NW < nb) wload(i0 + NW);
+            if (i < nb) {                                      // uniform per wave
+                v4 a[NS];
+                const R* yd = yimg + (size_t)ViD[i] * NQ * FT_TILE;
+#pragma unroll
+                for (int t = 0, I = 0, J = 0; t < NS; ++t) {  // every load of the block row first ...
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[t][r] = yd[(size_t)(I * NB + J) * FT_TILE + TT::row(g, r) * 16 + c];
+                    if (J == cn) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * I + TT::row(g, r);
+                            const R yr = (R)yv[i * n + (row < n ? row : n - 1)];
+                            a[t][r] = c == nl ? (row < n ? yr : (R)0) : a[t][r];
+                        }
+                    }
+                    if (++J == NB) { ++I; J = I; }
+                }
+                if (i < T) {
+                    const R* wl = sWL + wv * mb * 16;
+#pragma unroll 3
+                    for (int kb = 0; kb < mb; ++kb) {
+                        R x[NB][4], zw[NB][4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const R wk = wl[16 * kb + 4 * r + g];
+                            const int qz = 16 * kb + 4 * r + g < m ? 16 * kb + 4 * r + g : m - 1;   // dense R: row of Z_i = Rt_i^-1 B'
+#pragma unroll
+                            for (int J = 0; J < NB; ++J) {
+                                x[J][r] = sBT[(size_t)(kb * NB + J) * FT_TILE + 64 * r + lane];
+                                if (DR) {
+                                    const int cz = 16 * J + c;
+                                    const double zv = ztw[((size_t)i * m + qz) * ZLD + (cz < n ? cz : n - 1)];
+                                    zw[J][r] = cz < n ? (R)zv : (R)0;                 // (column n of a tile row is the rhs)
+                                } else {
+                                    zw[J][r] = x[J][r] * wk;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0, I = 0, J = 0; t < NS; ++t) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a[t] = TT::mfma(x[I][r], zw[J][r], a[t]);
+                            if (++J == NB) { ++I; J = I; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {                 // ... the stores last
+                    R* dst = gws + ((size_t)i * NS + t) * FT_TILE;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[TT::row(g, r) * 16 + c] = a[t][r];
+                }
+            }
+        }
+    }
+}
+
 // NL: live rows of the last 16-row block of a stage, n - 16 (NB - 1), when known at compile time (the AO sizes), else -1
 template <typename R, int NB, int NW, int NL, bool DR = false>
 __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
@@ -562,91 +932,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // ================= S pre-pass: the initial diagonal blocks S0_i = Y_ii const + B W_i B' (upper-triangular tiles,
             // rhs_i in column n) of EVERY block row, all independent, ahead of the serial factorisation.  The B' tiles are
             // in LDS only for this (the factor phase reuses the space); Phi^-1 of FT_GCH stages at a time in LDS.
-            {
-                const R* src = (const R*)V.btimg;
-                for (int q = tid; q < mb * NB * FT_TILE; q += NT) sBT[q] = src[q];
-            }
-            {
-                // One block row (all its NS upper-triangular tiles) per wave and chunk: the B' tiles and Phi^-1 read from LDS
-                // feed NS products (one LDS read per MFMA instead of three; the LDS port is what bounds this phase).
-                constexpr int WPT = (NW * 16 * 16 + NT - 1) / NT;      // Phi^-1 entries per thread and chunk (mb <= 16)
-                R wreg[WPT];
-                auto wload = [&](int i0) {
-#pragma unroll
-                    for (int e = 0; e < WPT; ++e) {
-                        const int q = tid + e * NT;
-                        const int ii = q / (mb * 16), k = q - ii * (mb * 16);
-                        const bool ok = q < NW * mb * 16 && i0 + ii < T && k < m;
-                        const R v = (R)winv[ok ? (size_t)(i0 + ii) * m + k : 0];
-                        wreg[e] = ok ? v : (R)0;
-                    }
-                };
-                wload(0);
-                for (int i0 = 0; i0 < nb; i0 += NW) {
-                    __syncthreads();                                   // (the previous chunk's products are done with sWL)
-#pragma unroll
-                    for (int e = 0; e < WPT; ++e) {
-                        const int q = tid + e * NT;
-                        if (q < NW * mb * 16) sWL[q] = wreg[e];
-                    }
-                    __syncthreads();
-                    const int i = i0 + wv;
-                    if (i0 + NW < nb) wload(i0 + NW);
-                    if (i < nb) {                                      // uniform per wave
-                        v4 a[NS];
-                        const R* yd = yimg + (size_t)V.iD[i] * NQ * FT_TILE;
-#pragma unroll
-                        for (int t = 0, I = 0, J = 0; t < NS; ++t) {  // every load of the block row first ...
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) a[t][r] = yd[(size_t)(I * NB + J) * FT_TILE + TT::row(g, r) * 16 + c];
-                            if (J == cn) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = 16 * I + TT::row(g, r);
-                                    const R yr = (R)yv[i * n + (row < n ? row : n - 1)];
-                                    a[t][r] = c == nl ? (row < n ? yr : (R)0) : a[t][r];
-                                }
-                            }
-                            if (++J == NB) { ++I; J = I; }
-                        }
-                        if (i < T) {
-                            const R* wl = sWL + wv * mb * 16;
-#pragma unroll 3
-                            for (int kb = 0; kb < mb; ++kb) {
-                                R x[NB][4], zw[NB][4];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const R wk = wl[16 * kb + 4 * r + g];
-                                    const int qz = 16 * kb + 4 * r + g < m ? 16 * kb + 4 * r + g : m - 1;   // dense R: row of Z_i = Rt_i^-1 B'
-#pragma unroll
-                                    for (int J = 0; J < NB; ++J) {
-                                        x[J][r] = sBT[(size_t)(kb * NB + J) * FT_TILE + 64 * r + lane];
-                                        if (DR) {
-                                            const int cz = 16 * J + c;
-                                            const double zv = ztw[((size_t)i * m + qz) * ZLD + (cz < n ? cz : n - 1)];
-                                            zw[J][r] = cz < n ? (R)zv : (R)0;                 // (column n of a tile row is the rhs)
-                                        } else {
-                                            zw[J][r] = x[J][r] * wk;
-                                        }
-                                    }
-                                }
-#pragma unroll
-                                for (int t = 0, I = 0, J = 0; t < NS; ++t) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) a[t] = TT::mfma(x[I][r], zw[J][r], a[t]);
-                                    if (++J == NB) { ++I; J = I; }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int t = 0; t < NS; ++t) {                 // ... the stores last
-                            R* dst = gws + ((size_t)i * NS + t) * FT_TILE;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dst[TT::row(g, r) * 16 + c] = a[t][r];
-                        }
-                    }
-                }
-            }
+            ft_phase_spre<R, NB, NW, DR>(ft_params());                 // (not inlined: see ft_phase_factor)
             __syncthreads();
             // zero the three U slots: stages 0 and 1 then need no special cases
             constexpr bool TS = !(sizeof(R) == 8 && NW == 2);       // two U slots (ft_u_slots): see below
@@ -662,212 +948,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // no rotation, and a third of the factor phase's LDS is gone (95 -> 70 KB at n = 65: two workgroups per CU).
             // !TS (fp64 with 2 wavefronts, short of registers for the extra tile set): three slots, Uc = U2_{i-2} kept in LDS
             // and subtracted in the stage itself.
-            int ub = 1, uc = 2;                                     // !TS: roles of the slots 1 and 2
-            bool fail = false;
-            // Loads queue behind the stores a wave has issued (vmcnt is in order), so everything stage i + 1 needs from
-            // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
-            // before that stage's factor tiles are stored.
-            v4 nS[SS], fS[SS], nM1[MS];                          // S0 tiles of stage i + 1 (loaded, updated in phase A) and i + 2 (in flight)
-            auto requestS = [&](int i, v4 (&dst)[SS]) {
-#pragma unroll
-                for (int sl = 0; sl < SS; ++sl)
-                    if (sI[sl] >= 0) {
-                        const R* gt = gws + ((size_t)i * NS + firstS + sl * NW) * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[sl][r] = gt[TT::row(g, r) * 16 + c];
-                    }
-            };
-            auto requestM = [&](int i) {
-                const R* Y1 = yimg + (size_t)V.i1[i] * NQ * FT_TILE;
-#pragma unroll
-                for (int sl = 0; sl < MS; ++sl) {
-                    const int q1 = firstM1 + sl * NW;
-                    if (q1 < NQ) {
-                        const R* yt = Y1 + (size_t)q1 * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) nM1[sl][r] = yt[TT::row(g, r) * 16 + c];
-                    }
-                }
-            };
-            v4 cS[SS];                                             // S tiles of the current stage (S0_i - U2_{i-2}' U2_{i-2})
-            if (TS) { requestS(0, cS); requestS(nb > 1 ? 1 : 0, nS); }
-            else requestS(0, nS);                                  // (!TS: no third set, nS is the current stage's at the top of a stage)
-            requestM(0);
-            for (int i = 0; i < nb; ++i) {
-                R* UA = sSLOT;
-                R* UB = sSLOT + (size_t)(TS ? 1 : ub) * NQ * FT_TILE;
-                R* UC = sSLOT + (size_t)(TS ? 1 : uc) * NQ * FT_TILE;
-                R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
-                const R* Y2 = yimg + (size_t)V.i2[i] * NQ * FT_TILE;
-                // ---------------- phase A: all tiles of the stage, independent
-                v4 aS[SS], aM1[MS];
-#pragma unroll
-                for (int sl = 0; sl < SS; ++sl) aS[sl] = TS ? cS[sl] : nS[sl];
-#pragma unroll
-                for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
-#pragma unroll
-                for (int sl = 0; sl < SS; ++sl) {
-                    const int I = sI[sl], J = sJ[sl];
-                    if (I >= 0) {
-#pragma unroll 1
-                        for (int j = 0; j < NB; ++j) {
-                            ft_xtz_sub<R>(aS[sl], UA + (size_t)(j * NB + I) * FT_TILE, UA + (size_t)(j * NB + J) * FT_TILE, lane);
-                            if (TS) ft_xtz_sub<R>(nS[sl], UB + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);   // for S_{i+1}
-                            else ft_xtz_sub<R>(aS[sl], UC + (size_t)(j * NB + I) * FT_TILE, UC + (size_t)(j * NB + J) * FT_TILE, lane);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int sl = 0; sl < MS; ++sl) {
-                    const int q1 = firstM1 + sl * NW;
-                    if (q1 < NQ) {
-                        const int I = q1 / NB, J = q1 - I * NB;
-#pragma unroll 1
-                        for (int j = 0; j < NB; ++j)
-                            ft_xtz_sub<R>(aM1[sl], UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
-                    }
-                }
-                ft_lds_barrier();                                      // Ua, Ub are dead from here: their slots take U1_i, U2_i
-                FT_TICK(3);
-                R* U1N = UA; R* U2N = TS ? UB : UC;
-                if (!TS && i + 1 < nb) requestS(i + 1, nS);
-                if (i + 1 < nb) requestM(i + 1);
-                if (TS) requestS(i + 2 < nb ? i + 2 : nb - 1, fS);     // (harmless re-read at the end of the horizon)
-                v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
-#pragma unroll
-                for (int sl = 0; sl < MS; ++sl) {
-                    const int q2 = firstM2 + sl * NW;
-                    if (q2 < NQ) {
-                        const R* yt = Y2 + (size_t)q2 * FT_TILE;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) aM2[sl][r] = yt[TT::row(g, r) * 16 + c];
-                    }
-                }
-                // ---------------- phase B: the 16-row blocks of the stage, in order
-                for (int kb = 0; kb < NB; ++kb) {
-                    int cnt = n - 16 * kb; cnt = cnt > 16 ? 16 : (cnt < 0 ? 0 : cnt);
-                    // (1) products with the rows of this stage already done
-#pragma unroll
-                    for (int sl = 0; sl < SS; ++sl)
-                        if (sI[sl] == kb)
-                            for (int j = 0; j < kb; ++j)
-                                ft_xtz_sub<R>(aS[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
-                                              sLT + (size_t)ft_lt_index(NB, j, sJ[sl]) * FT_TILE, lane);
-#pragma unroll
-                    for (int sl = 0; sl < MS; ++sl) {
-                        const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
-                        if (q1 < NQ && q1 / NB == kb)
-                            for (int j = 0; j < kb; ++j)
-                                ft_xtz_sub<R>(aM1[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
-                                              U1N + (size_t)(j * NB + q1 % NB) * FT_TILE, lane);
-                        if (q2 < NQ && q2 / NB == kb) {
-                            for (int j = 0; j < kb; ++j)
-                                ft_xtz_sub<R>(aM2[sl], sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE,
-                                              U2N + (size_t)(j * NB + q2 % NB) * FT_TILE, lane);
-                        }
-                    }
-                    // (2) the rhs column of this row block, still unscaled: shared with the owners of M1(kb,cn), M2(kb,cn);
-                    //     the owner of the diagonal tile factors it
-#pragma unroll
-                    for (int sl = 0; sl < SS; ++sl) {
-                        if (sI[sl] == kb && sJ[sl] == cn && c == nl) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) sYSH[TT::row(g, r)] = aS[sl][r];
-                        }
-                        if (sI[sl] == kb && sJ[sl] == kb) {
-                            v4 Ro, Wo;
-                            __builtin_amdgcn_s_setprio(3);             // a chain of dependent steps: issue ahead of the SIMD's other wave
-                            bool ok;
-                            if (kb < NB - 1) ok = ft_potrf16_ct<R, 16>(aS[sl], c, g, Ro, Wo);        // (all blocks but the last are full)
-                            else if (NL >= 0) ok = ft_potrf16_ct<R, (NL >= 0 ? NL : 0)>(aS[sl], c, g, Ro, Wo);
-                            else ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
-                            __builtin_amdgcn_s_setprio(0);
-                            if (!ok && lane == 0) sflag[0] = 1;
-                            R* ri = facs + (size_t)(kb * REC_TILES) * FT_TILE;   // R(kb,kb)^-1 = W' for the backward sweep
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                sWT[c * FT_WLD + TT::row(g, r)] = Wo[r];
-                                ri[c * 16 + TT::row(g, r)] = Wo[r];
-                            }
-                            if (kb == cn && c == nl) {                 // y of this row block is the rhs column of the factored tile
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = 16 * kb + TT::row(g, r);
-                                    if (row < n) yv[i * n + row] = (double)Ro[r];
-                                }
-                            }
-                            aS[sl] = Ro;
-                        }
-                    }
-                    ft_lds_barrier();
-                    FT_TICK(4);
-                    // (3) scale the tiles of the row: Rwide(kb, .) = W P(kb, .)
-                    R wop[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) wop[r] = sWT[TT::row(g, r) * FT_WLD + c];
-#pragma unroll
-                    for (int sl = 0; sl < SS; ++sl) {
-                        if (sI[sl] == kb && sJ[sl] > kb) {
-                            v4 o = {0, 0, 0, 0};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], aS[sl][r], o);
-                            R* dl = sLT + (size_t)ft_lt_index(NB, kb, sJ[sl]) * FT_TILE;
-                            R* dg = facs + (size_t)(kb * REC_TILES + sJ[sl]) * FT_TILE;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
-                            if (sJ[sl] == cn && c == nl) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int row = 16 * kb + TT::row(g, r);
-                                    if (row < n) yv[i * n + row] = (double)o[r];
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int sl = 0; sl < MS; ++sl) {
-                        const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
-                        if (q1 < NQ && q1 / NB == kb) {
-                            const int J = q1 % NB;
-                            v4 pv = aM1[sl];
-                            if (J == cn && c == nl) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) pv[r] = sYSH[TT::row(g, r)];
-                            }
-                            v4 o = {0, 0, 0, 0};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
-                            R* dl = U1N + (size_t)q1 * FT_TILE;
-                            R* dg = facs + (size_t)(kb * REC_TILES + NB + J) * FT_TILE;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
-                        }
-                        if (q2 < NQ && q2 / NB == kb) {
-                            const int J = q2 % NB;
-                            v4 pv = aM2[sl];
-                            if (J == cn && c == nl) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) pv[r] = sYSH[TT::row(g, r)];
-                            }
-                            v4 o = {0, 0, 0, 0};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
-                            R* dl = U2N + (size_t)q2 * FT_TILE;
-                            R* dg = facs + (size_t)(kb * REC_TILES + 2 * NB + J) * FT_TILE;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
-                        }
-                    }
-                    ft_lds_barrier();
-                    FT_TICK(5);
-                    if (sflag[0]) { fail = true; break; }              // uniform: read after the barrier
-                }
-                if (fail) break;
-                // next stage: its S tiles are the updated set, the set in flight becomes the next one
-#pragma unroll
-                for (int sl = 0; sl < SS; ++sl) { if (TS) { cS[sl] = nS[sl]; nS[sl] = fS[sl]; } }
-                if (!TS) { const int t = ub; ub = uc; uc = t; }        // Ub <- U2_i (slot uc), Uc <- old Ub
-            }
+            // (a function of its own, not inlined: inside the kernel body the factor phase's ~150 registers of tiles compete with
+            // everything else that is live there -- the n = 65 instance spilled 928 bytes per lane, ~300 scratch accesses per stage)
+            const bool fail = ft_phase_factor<R, NB, NW, NL, DR>(ft_params());
             if (fail) { st = FMPC_E_NOT_PD_SCHUR; break; }
             __syncthreads();                                           // the factor stream and y are in HBM (same workgroup reads them)
             FT_TICK(6);
