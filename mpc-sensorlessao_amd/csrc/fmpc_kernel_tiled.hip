@@ -631,6 +631,285 @@ __device__ __noinline__ void ft_phase_spre(FtKP Pin) {
     }
 }
 
+// Everything a phase function needs, rebuilt from the kernel's parameter block (scalar arithmetic; unused names cost nothing)
+#define FT_VIEW(R, NB, NW, DR)                                                                                                      \
+    constexpr int NT = NW * 64, NP = 16 * NB;                                                                                       \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                                            \
+    const FtKP P = ft_uniform(Pin);                                                                                                 \
+    [[maybe_unused]] const int n = P->M.n, m = P->M.m, T = P->M.T, nb = P->M.nb;                                                     \
+    [[maybe_unused]] const int s = n + m, Nz = T * s, nbn = nb * n;                                                                 \
+    [[maybe_unused]] const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);                   \
+    [[maybe_unused]] const int c = lane & 15, g = lane >> 4;                                                                        \
+    [[maybe_unused]] const bool var2 = P->M.var2 != 0;                                                                              \
+    [[maybe_unused]] const int mb = P->V.mb;                                                                                        \
+    const FtLds LL = ft_lds_layout(NB, mb, NW, (int)sizeof(R), nb, DR ? ft_pr_doubles(n, m) : 0);                                   \
+    [[maybe_unused]] double* red = (double*)(smem + LL.red);                                                                        \
+    [[maybe_unused]] double* sNU = (double*)(smem + LL.slot);                                                                       \
+    [[maybe_unused]] constexpr int LDN = 16 * NB + 1;                                                                               \
+    [[maybe_unused]] const int TA = (nb + 15) / 16, NUROWS = 16 * TA + 2, MP = 16 * mb;                                             \
+    const FtWs L = ft_ws_layout(n, m, T, nb, NB, (int)sizeof(R), DR ? 1 : 0);                                                       \
+    double* wsp = P->ws + (size_t)blockIdx.x * P->ws_stride;                                                                        \
+    [[maybe_unused]] double* ztw = wsp + L.zt;                                                                                      \
+    [[maybe_unused]] const int ZLD = n + 1;                                                                                         \
+    [[maybe_unused]] double* b = wsp + L.b;                                                                                         \
+    [[maybe_unused]] double* nu = wsp + L.nu;                                                                                       \
+    [[maybe_unused]] double* hess = wsp + L.hess;                                                                                   \
+    [[maybe_unused]] double* winv = wsp + L.winv;                                                                                   \
+    [[maybe_unused]] double* rdu = wsp + L.rdu;                                                                                     \
+    [[maybe_unused]] double* rdx = wsp + L.rdx;                                                                                     \
+    [[maybe_unused]] double* phx = wsp + L.phx;                                                                                     \
+    [[maybe_unused]] double* rp = wsp + L.rp;                                                                                       \
+    [[maybe_unused]] double* yv = wsp + L.y
+
+struct FtResid { double rp2, rho2, bad; };
+struct FtStep { double t; int collapsed; };
+
+// P1 of the kernel below (residuals of problem p, their norms) as a function of its own: see ft_phase_factor.  Workgroup-collective.
+template <typename R, int NB, int NW, bool DR>
+__device__ __noinline__ FtResid ft_phase_resid(FtKP Pin, int p) {
+    FT_VIEW(R, NB, NW, DR);
+    p = __builtin_amdgcn_readfirstlane(p);
+    double* zp = P->zout + (size_t)p * Nz;
+    double acc_d = 0.0, acc_p = 0.0;
+    int bad = 0;
+    for (int idx = tid; idx < NUROWS * LDN; idx += NT) {       // nu as [stage][state] in LDS, zero padded
+        const int j = idx / LDN, r = idx - j * LDN;
+        sNU[idx] = (j < nb && r < n) ? nu[j * n + r] : 0.0;
+    }
+    __syncthreads();
+    {
+        const int nC = NB * TA, nB_ = NB * TA, nA = mb * TA;   // items: r_p tiles, r_d[x] tiles, r_d[u] tiles (heaviest first)
+        for (int item = wv; item < nC + nB_ + nA; item += NW) {
+            ft_d4 acc = {0, 0, 0, 0};
+            if (item < nC) {
+                // ---- r_p,i = x_{i+1} - b_i - B u_i - A1 x_i - A2 x_{i-1}      (terminal row: x_T - xf)
+                const int Jr = item / TA, A = item - Jr * TA;
+                const int i = 16 * A + c, r = 16 * Jr + c;      // as A-operand lane: stage i; as B-operand lane: state r
+                const bool rok = r < n;
+                // Z comes from zero-padded images and X needs no zeros where Z has them, so every load is
+                // unconditional (a conditional load is a branch with a wait behind it); stage 0 / 1 terms that
+                // do not exist are switched off by a factor
+                const double* zi0 = zp + (size_t)(i < T ? i : T - 1) * s;
+                const double* zi1 = zp + (size_t)((i >= 1 && i < T) ? i - 1 : 0) * s + m;
+                const double* zi2 = zp + (size_t)((i >= 2 && i < T) ? i - 2 : 0) * s + m;
+                const double f1 = (i >= 1 && i < T) ? 1.0 : 0.0, f2 = (i >= 2 && i < T) ? 1.0 : 0.0;
+                ft_vec_gemm<12>(acc, MP, g,
+                            [&](int k) { return zi0[k < m ? k : m - 1]; },
+                            [&](int k) { return P->V.BtP[(size_t)k * NP + r]; });
+                ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                            [&](int k) { return zi1[k < n ? k : n - 1] * f1; },
+                            [&](int k) { return P->V.A1tP[k * NP + r]; });
+                if (var2)
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return zi2[k < n ? k : n - 1] * f2; },
+                                [&](int k) { return P->V.A2tP[k * NP + r]; });
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int io = 16 * A + g + 4 * rr;
+                    if (io < nb && rok) {
+                        const double v = (io < T ? zp[io * s + m + r] - acc[rr] : zp[(T - 1) * s + m + r]) - b[io * n + r];
+                        rp[io * n + r] = v;
+                        acc_p += v * v;
+                    }
+                }
+            } else if (item < nC + nB_) {
+                // ---- r_d on x_j (j = jj + 1): 2Q x + q + nu_{j-1} - A1' nu_j - A2' nu_{j+1}  (+ nu_T with xf)
+                const int it2 = item - nC, Jr = it2 / TA, A = it2 - Jr * TA;
+                const int jj = 16 * A + c, r = 16 * Jr + c;
+                const bool rok = r < n;
+                const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
+                ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                            [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
+                            [&](int k) { return P->V.A1P[k * NP + r]; });
+                if (var2)
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                                [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
+                                [&](int k) { return P->V.A2P[k * NP + r]; });
+                ft_d4 accq = {0, 0, 0, 0};                       // dense state weights: 2Q_j x_j as a product (Qf at the last stage)
+                if (P->V.denseQ) {
+                    const double* xj = zp + (size_t)(jj < T ? jj : T - 1) * s + m;
+                    const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
+                                [&](int k) { return xj[k < n ? k : n - 1] * fq; },
+                                [&](int k) { return P->V.Q2P[k * NP + r]; });
+                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
+                                [&](int k) { return xj[k < n ? k : n - 1] * fqf; },
+                                [&](int k) { return P->V.Qf2P[k * NP + r]; });
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int jo = 16 * A + g + 4 * rr;
+                    if (jo < T && rok) {
+                        const bool last = jo + 1 == T;
+                        const double q2 = last ? P->M.Qf2[r] : P->M.Q2[r];
+                        const double qx = P->V.denseQ ? accq[rr] : q2 * zp[jo * s + m + r];
+                        double v = qx + (last ? P->M.qfl[r] : P->M.ql[r]) + sNU[jo * LDN + r] - acc[rr];
+                        if (last && P->M.has_xf) v += sNU[T * LDN + r];
+                        rdx[jo * n + r] = v;
+                        phx[jo * n + r] = v * ft_rcp(q2);              // Phi^-1 r_d on x_j (dense weights: redone below)
+                        acc_d += v * v;
+                    }
+                }
+            } else {
+                // ---- r_d on u_j: 2R u + r + k P'd - B' nu_j ; barrier Hessian and Phi^-1 on the way
+                const int it3 = item - nC - nB_, J = it3 / TA, A = it3 - J * TA;
+                const int j = 16 * A + c, q = 16 * J + c;
+                const bool qok = q < m;
+                ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                            [&](int k) { return sNU[j * LDN + k]; },
+                            [&](int k) { return P->V.BmP[(size_t)k * MP + q]; });
+                ft_d4 accr = {0, 0, 0, 0};
+                if (DR) {                                           // dense R: (2R u_j)[q], one more stage-batched product
+                    const double* uj = zp + (size_t)(j < T ? j : T - 1) * s;
+                    ft_vec_gemm<12>(accr, MP, g,
+                                [&](int k) { return uj[k < m ? k : m - 1]; },
+                                [&](int k) { return P->V.R2P[(size_t)k * MP + q]; });
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int jo = 16 * A + g + 4 * rr;
+                    if (jo < T && qok) {
+                        const double u = zp[jo * s + q];
+                        const double dp = ft_rcp(P->M.umax[q] - u), dm = ft_rcp(u - P->M.umin[q]);
+                        const double hs = P->kbar * (dp * dp + dm * dm);
+                        const double rt = P->M.R2[q] + hs;
+                        if (!DR && (!(rt > 0.0) || isinf(rt))) bad = 1;     // (dense R: the factorisation below finds a bad pivot)
+                        if (DR && !(hs >= 0.0 && !isinf(hs))) bad = 1;
+                        const double rd = (DR ? accr[rr] : P->M.R2[q] * u) + P->M.rl[q] + P->kbar * (dp - dm) - acc[rr];
+                        hess[jo * m + q] = hs;
+                        winv[jo * m + q] = ft_rcp(rt);
+                        rdu[jo * m + q] = rd;
+                        acc_d += rd * rd;
+                    }
+                }
+            }
+        }
+    }
+    FtResid out;
+    out.rp2 = ft_block_sum<NW>(acc_p, red);
+    out.rho2 = ft_block_sum<NW>(acc_d, red) + out.rp2;
+    out.bad = ft_block_sum<NW>((double)bad, red);
+    return out;
+}
+
+// P5 of the kernel below (d_z, line search, update of z and nu of problem p) as a function of its own.  Workgroup-collective.
+template <typename R, int NB, int NW, bool DR>
+__device__ __noinline__ FtStep ft_phase_update(FtKP Pin, int p, double rho2) {
+    FT_VIEW(R, NB, NW, DR);
+    p = __builtin_amdgcn_readfirstlane(p);
+    double* zp = P->zout + (size_t)p * Nz;
+    double be = 0.0, e2 = 0.0;
+    for (int item = wv; item < NB * TA + (DR ? 0 : mb * TA); item += NW) {   // (d_nu is in the staging area: written by P4)
+        ft_d4 acc = {0, 0, 0, 0};
+        if (item < NB * TA) {
+            // ---- d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1' d_nu_j + A2' d_nu_{j+1}  [- d_nu_T])
+            const int Jr = item / TA, A = item - Jr * TA;
+            const int jj = 16 * A + c, r = 16 * Jr + c;
+            const bool rok = r < n;
+            const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
+            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                        [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
+                        [&](int k) { return P->V.A1P[k * NP + r]; });
+            if (var2)
+                ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                            [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
+                            [&](int k) { return P->V.A2P[k * NP + r]; });
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int jo = 16 * A + g + 4 * rr;
+                if (jo < T && rok) {
+                    const bool last = jo + 1 == T;
+                    double v = -rdx[jo * n + r] - sNU[jo * LDN + r] + acc[rr];
+                    if (last && P->M.has_xf) v -= sNU[T * LDN + r];
+                    if (P->V.denseQ) phx[jo * n + r] = v;                                  // dense weights: d_x = (2Q_j)^-1 v below
+                    else rdx[jo * n + r] = v * ft_rcp(last ? P->M.Qf2[r] : P->M.Q2[r]);       // reuse as d_x
+                }
+            }
+        } else {
+            // ---- d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) ; e = k P'DP d_z for the line search
+            const int it3 = item - NB * TA, J = it3 / TA, A = it3 - J * TA;
+            const int j = 16 * A + c, q = 16 * J + c;
+            const bool qok = q < m;
+            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                        [&](int k) { return sNU[j * LDN + k]; },
+                        [&](int k) { return P->V.BmP[(size_t)k * MP + q]; });
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int jo = 16 * A + g + 4 * rr;
+                if (jo < T && qok) {
+                    const int idx = jo * m + q;
+                    const double rd = rdu[idx];
+                    const double du = (acc[rr] - rd) * winv[idx];
+                    const double e = hess[idx] * du;
+                    be += rd * e;
+                    e2 += e * e;
+                    rdu[idx] = du;                              // reuse as d_u
+                }
+            }
+        }
+    }
+    if (DR) {
+        // ---- dense R: d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) = Z_j d_nu_j - t_j
+        for (int idx = tid; idx < T * m; idx += NT) {
+            const int j = idx / m;
+            const double* zr = ztw + (size_t)idx * ZLD;
+            double du = -zr[n];
+            for (int r = 0; r < n; ++r) du = fma(zr[r], sNU[j * LDN + r], du);
+            const double rd = rdu[idx];
+            const double e = hess[idx] * du;
+            be += rd * e;
+            e2 += e * e;
+            rdu[idx] = du;                                      // reuse as d_u
+        }
+    }
+    if (P->V.denseQ) {
+        __syncthreads();
+        for (int item = wv; item < NB * TA; item += NW) {
+            const int Jr = item / TA, A = item - Jr * TA;
+            const int jj = 16 * A + c, r = 16 * Jr + c;
+            const double* vj = phx + (size_t)(jj < T ? jj : T - 1) * n;
+            const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
+            ft_d4 acc = {0, 0, 0, 0};
+            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                        [&](int k) { return vj[k < n ? k : n - 1] * fq; },
+                        [&](int k) { return P->V.XP[k * NP + r]; });
+            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
+                        [&](int k) { return vj[k < n ? k : n - 1] * fqf; },
+                        [&](int k) { return P->V.XfP[k * NP + r]; });
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int jo = 16 * A + g + 4 * rr;
+                if (jo < T && r < n) rdx[jo * n + r] = acc[rr];                       // d_x
+            }
+        }
+    }
+    const double beta_e = ft_block_sum<NW>(be, red);
+    const double eps2 = ft_block_sum<NW>(e2, red);
+    // closed form of backtracking_inf_newton.m:2-11 with the frozen barrier gradient:
+    // ||r(t)||^2 - ((1-al t) rho)^2 = t * gq(t)
+    double t = 1.0;
+    int collapsed = 0;
+    {
+        const double al = 1e-4;
+        int halv = 0;
+        while (true) {
+            const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2 - 2.0 * (1.0 - t) * beta_e + t * eps2;
+            if (gq <= 0.0) break;
+            t *= 0.5;
+            if (++halv >= FT_MAX_HALVINGS) { t = 0.0; collapsed = 1; break; }
+        }
+    }
+#pragma unroll 8
+    for (int idx = tid; idx < Nz; idx += NT) {
+        const int j = idx / s, e = idx - j * s;
+        const double dv = e < m ? rdu[j * m + e] : rdx[j * n + (e < m ? 0 : e - m)];
+        zp[idx] += t * dv;
+    }
+    for (int idx = tid; idx < nbn; idx += NT) { const int j = idx / n; nu[idx] += t * sNU[j * LDN + idx - j * n]; }
+    FtStep out; out.t = t; out.collapsed = collapsed;
+    return out;
+}
+
 // NL: live rows of the last 16-row block of a stage, n - 16 (NB - 1), when known at compile time (the AO sizes), else -1
 template <typename R, int NB, int NW, int NL, bool DR = false>
 __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
@@ -742,124 +1021,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // ================= P1: residuals.  Every product is a GEMM with the horizon stages as one dimension
             // (out[stage][entry] = sum_k X[k][stage] Z[k][entry]) on the fp64 matrix cores; Z (B, A1, A2 and transposes)
             // is read from L2 with 128-byte rows, the epilogues read and write along the entries of a stage.
-            double acc_d = 0.0, acc_p = 0.0;
-            int bad = 0;
-            for (int idx = tid; idx < NUROWS * LDN; idx += NT) {       // nu as [stage][state] in LDS, zero padded
-                const int j = idx / LDN, r = idx - j * LDN;
-                sNU[idx] = (j < nb && r < n) ? nu[j * n + r] : 0.0;
-            }
-            __syncthreads();
-            {
-                const int nC = NB * TA, nB_ = NB * TA, nA = mb * TA;   // items: r_p tiles, r_d[x] tiles, r_d[u] tiles (heaviest first)
-                for (int item = wv; item < nC + nB_ + nA; item += NW) {
-                    ft_d4 acc = {0, 0, 0, 0};
-                    if (item < nC) {
-                        // ---- r_p,i = x_{i+1} - b_i - B u_i - A1 x_i - A2 x_{i-1}      (terminal row: x_T - xf)
-                        const int Jr = item / TA, A = item - Jr * TA;
-                        const int i = 16 * A + c, r = 16 * Jr + c;      // as A-operand lane: stage i; as B-operand lane: state r
-                        const bool rok = r < n;
-                        // Z comes from zero-padded images and X needs no zeros where Z has them, so every load is
-                        // unconditional (a conditional load is a branch with a wait behind it); stage 0 / 1 terms that
-                        // do not exist are switched off by a factor
-                        const double* zi0 = zp + (size_t)(i < T ? i : T - 1) * s;
-                        const double* zi1 = zp + (size_t)((i >= 1 && i < T) ? i - 1 : 0) * s + m;
-                        const double* zi2 = zp + (size_t)((i >= 2 && i < T) ? i - 2 : 0) * s + m;
-                        const double f1 = (i >= 1 && i < T) ? 1.0 : 0.0, f2 = (i >= 2 && i < T) ? 1.0 : 0.0;
-                        ft_vec_gemm<12>(acc, MP, g,
-                                    [&](int k) { return zi0[k < m ? k : m - 1]; },
-                                    [&](int k) { return V.BtP[(size_t)k * NP + r]; });
-                        ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                    [&](int k) { return zi1[k < n ? k : n - 1] * f1; },
-                                    [&](int k) { return V.A1tP[k * NP + r]; });
-                        if (var2)
-                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                        [&](int k) { return zi2[k < n ? k : n - 1] * f2; },
-                                        [&](int k) { return V.A2tP[k * NP + r]; });
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int io = 16 * A + g + 4 * rr;
-                            if (io < nb && rok) {
-                                const double v = (io < T ? zp[io * s + m + r] - acc[rr] : zp[(T - 1) * s + m + r]) - b[io * n + r];
-                                rp[io * n + r] = v;
-                                acc_p += v * v;
-                            }
-                        }
-                    } else if (item < nC + nB_) {
-                        // ---- r_d on x_j (j = jj + 1): 2Q x + q + nu_{j-1} - A1' nu_j - A2' nu_{j+1}  (+ nu_T with xf)
-                        const int it2 = item - nC, Jr = it2 / TA, A = it2 - Jr * TA;
-                        const int jj = 16 * A + c, r = 16 * Jr + c;
-                        const bool rok = r < n;
-                        const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
-                        ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                    [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
-                                    [&](int k) { return V.A1P[k * NP + r]; });
-                        if (var2)
-                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                        [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
-                                        [&](int k) { return V.A2P[k * NP + r]; });
-                        ft_d4 accq = {0, 0, 0, 0};                       // dense state weights: 2Q_j x_j as a product (Qf at the last stage)
-                        if (V.denseQ) {
-                            const double* xj = zp + (size_t)(jj < T ? jj : T - 1) * s + m;
-                            const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
-                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
-                                        [&](int k) { return xj[k < n ? k : n - 1] * fq; },
-                                        [&](int k) { return V.Q2P[k * NP + r]; });
-                            ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(accq, NP, g,
-                                        [&](int k) { return xj[k < n ? k : n - 1] * fqf; },
-                                        [&](int k) { return V.Qf2P[k * NP + r]; });
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int jo = 16 * A + g + 4 * rr;
-                            if (jo < T && rok) {
-                                const bool last = jo + 1 == T;
-                                const double q2 = last ? M.Qf2[r] : M.Q2[r];
-                                const double qx = V.denseQ ? accq[rr] : q2 * zp[jo * s + m + r];
-                                double v = qx + (last ? M.qfl[r] : M.ql[r]) + sNU[jo * LDN + r] - acc[rr];
-                                if (last && M.has_xf) v += sNU[T * LDN + r];
-                                rdx[jo * n + r] = v;
-                                phx[jo * n + r] = v * ft_rcp(q2);              // Phi^-1 r_d on x_j (dense weights: redone below)
-                                acc_d += v * v;
-                            }
-                        }
-                    } else {
-                        // ---- r_d on u_j: 2R u + r + k P'd - B' nu_j ; barrier Hessian and Phi^-1 on the way
-                        const int it3 = item - nC - nB_, J = it3 / TA, A = it3 - J * TA;
-                        const int j = 16 * A + c, q = 16 * J + c;
-                        const bool qok = q < m;
-                        ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                    [&](int k) { return sNU[j * LDN + k]; },
-                                    [&](int k) { return V.BmP[(size_t)k * MP + q]; });
-                        ft_d4 accr = {0, 0, 0, 0};
-                        if (DR) {                                           // dense R: (2R u_j)[q], one more stage-batched product
-                            const double* uj = zp + (size_t)(j < T ? j : T - 1) * s;
-                            ft_vec_gemm<12>(accr, MP, g,
-                                        [&](int k) { return uj[k < m ? k : m - 1]; },
-                                        [&](int k) { return V.R2P[(size_t)k * MP + q]; });
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int jo = 16 * A + g + 4 * rr;
-                            if (jo < T && qok) {
-                                const double u = zp[jo * s + q];
-                                const double dp = ft_rcp(M.umax[q] - u), dm = ft_rcp(u - M.umin[q]);
-                                const double hs = P.kbar * (dp * dp + dm * dm);
-                                const double rt = M.R2[q] + hs;
-                                if (!DR && (!(rt > 0.0) || isinf(rt))) bad = 1;     // (dense R: the factorisation below finds a bad pivot)
-                                if (DR && !(hs >= 0.0 && !isinf(hs))) bad = 1;
-                                const double rd = (DR ? accr[rr] : M.R2[q] * u) + M.rl[q] + P.kbar * (dp - dm) - acc[rr];
-                                hess[jo * m + q] = hs;
-                                winv[jo * m + q] = ft_rcp(rt);
-                                rdu[jo * m + q] = rd;
-                                acc_d += rd * rd;
-                            }
-                        }
-                    }
-                }
-            }
-            const double rp2 = ft_block_sum<NW>(acc_p, red);
-            const double rho2 = ft_block_sum<NW>(acc_d, red) + rp2;
-            const double badsum = ft_block_sum<NW>((double)bad, red);
+            const FtResid rs_ = ft_phase_resid<R, NB, NW, DR>(ft_params(), p);      // (not inlined: see ft_phase_factor)
+            const double rp2 = rs_.rp2, rho2 = rs_.rho2, badsum = rs_.bad;
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
             if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
@@ -964,113 +1127,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             FT_TICK(7);
 
             // ================= P5: d_z, line-search scalars, update (the same stage-batched GEMMs with d_nu)
-            double be = 0.0, e2 = 0.0;
-            for (int item = wv; item < NB * TA + (DR ? 0 : mb * TA); item += NW) {   // (d_nu is in the staging area: written by P4)
-                ft_d4 acc = {0, 0, 0, 0};
-                if (item < NB * TA) {
-                    // ---- d_x_j = (2Q_j)^-1 (-r_d[x_j] - d_nu_{j-1} + A1' d_nu_j + A2' d_nu_{j+1}  [- d_nu_T])
-                    const int Jr = item / TA, A = item - Jr * TA;
-                    const int jj = 16 * A + c, r = 16 * Jr + c;
-                    const bool rok = r < n;
-                    const double f1 = jj + 1 < T ? 1.0 : 0.0, f2 = jj + 2 < T ? 1.0 : 0.0;
-                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                [&](int k) { return sNU[(jj + 1) * LDN + k] * f1; },
-                                [&](int k) { return V.A1P[k * NP + r]; });
-                    if (var2)
-                        ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                    [&](int k) { return sNU[(jj + 2) * LDN + k] * f2; },
-                                    [&](int k) { return V.A2P[k * NP + r]; });
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int jo = 16 * A + g + 4 * rr;
-                        if (jo < T && rok) {
-                            const bool last = jo + 1 == T;
-                            double v = -rdx[jo * n + r] - sNU[jo * LDN + r] + acc[rr];
-                            if (last && M.has_xf) v -= sNU[T * LDN + r];
-                            if (V.denseQ) phx[jo * n + r] = v;                                  // dense weights: d_x = (2Q_j)^-1 v below
-                            else rdx[jo * n + r] = v * ft_rcp(last ? M.Qf2[r] : M.Q2[r]);       // reuse as d_x
-                        }
-                    }
-                } else {
-                    // ---- d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) ; e = k P'DP d_z for the line search
-                    const int it3 = item - NB * TA, J = it3 / TA, A = it3 - J * TA;
-                    const int j = 16 * A + c, q = 16 * J + c;
-                    const bool qok = q < m;
-                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                [&](int k) { return sNU[j * LDN + k]; },
-                                [&](int k) { return V.BmP[(size_t)k * MP + q]; });
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int jo = 16 * A + g + 4 * rr;
-                        if (jo < T && qok) {
-                            const int idx = jo * m + q;
-                            const double rd = rdu[idx];
-                            const double du = (acc[rr] - rd) * winv[idx];
-                            const double e = hess[idx] * du;
-                            be += rd * e;
-                            e2 += e * e;
-                            rdu[idx] = du;                              // reuse as d_u
-                        }
-                    }
-                }
-            }
-            if (DR) {
-                // ---- dense R: d_u_j = Rt_j^-1 (B' d_nu_j - r_d[u_j]) = Z_j d_nu_j - t_j
-                for (int idx = tid; idx < T * m; idx += NT) {
-                    const int j = idx / m;
-                    const double* zr = ztw + (size_t)idx * ZLD;
-                    double du = -zr[n];
-                    for (int r = 0; r < n; ++r) du = fma(zr[r], sNU[j * LDN + r], du);
-                    const double rd = rdu[idx];
-                    const double e = hess[idx] * du;
-                    be += rd * e;
-                    e2 += e * e;
-                    rdu[idx] = du;                                      // reuse as d_u
-                }
-            }
-            if (V.denseQ) {
-                __syncthreads();
-                for (int item = wv; item < NB * TA; item += NW) {
-                    const int Jr = item / TA, A = item - Jr * TA;
-                    const int jj = 16 * A + c, r = 16 * Jr + c;
-                    const double* vj = phx + (size_t)(jj < T ? jj : T - 1) * n;
-                    const double fq = jj + 1 < T ? 1.0 : 0.0, fqf = jj + 1 == T ? 1.0 : 0.0;
-                    ft_d4 acc = {0, 0, 0, 0};
-                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                [&](int k) { return vj[k < n ? k : n - 1] * fq; },
-                                [&](int k) { return V.XP[k * NP + r]; });
-                    ft_vec_gemm<(NP / 4 < 12 ? NP / 4 : 10)>(acc, NP, g,
-                                [&](int k) { return vj[k < n ? k : n - 1] * fqf; },
-                                [&](int k) { return V.XfP[k * NP + r]; });
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int jo = 16 * A + g + 4 * rr;
-                        if (jo < T && r < n) rdx[jo * n + r] = acc[rr];                       // d_x
-                    }
-                }
-            }
-            const double beta_e = ft_block_sum<NW>(be, red);
-            const double eps2 = ft_block_sum<NW>(e2, red);
-            // closed form of backtracking_inf_newton.m:2-11 with the frozen barrier gradient:
-            // ||r(t)||^2 - ((1-al t) rho)^2 = t * gq(t)
-            double t = 1.0;
+            double t;
             {
-                const double al = 1e-4;
-                int halv = 0;
-                while (true) {
-                    const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2 - 2.0 * (1.0 - t) * beta_e + t * eps2;
-                    if (gq <= 0.0) break;
-                    t *= 0.5;
-                    if (++halv >= FT_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
-                }
+                const FtStep sp_ = ft_phase_update<R, NB, NW, DR>(ft_params(), p, rho2);   // (not inlined: see ft_phase_factor)
+                t = sp_.t;
+                if (sp_.collapsed) st = FMPC_W_LINESEARCH;
             }
-#pragma unroll 8
-            for (int idx = tid; idx < Nz; idx += NT) {
-                const int j = idx / s, e = idx - j * s;
-                const double dv = e < m ? rdu[j * m + e] : rdx[j * n + (e < m ? 0 : e - m)];
-                zp[idx] += t * dv;
-            }
-            for (int idx = tid; idx < nbn; idx += NT) { const int j = idx / n; nu[idx] += t * sNU[j * LDN + idx - j * n]; }
             if (P.step && tid == 0 && it < P.step_ld) P.step[(size_t)p * P.step_ld + it] = t;
             ++nsteps;
             __syncthreads();
