@@ -30,3 +30,11 @@ for want_z in (True, False):
     print("   medians: staged %.1f, D read %.1f, A there %.1f, first tile computed+stores issued %.1f, next A there %.1f, end %.1f" % (md_(k[:, 1]), md_(k[:, 4]), md_(k[:, 5]), md_(k[:, 6]), md_(k[:, 2]), md_(k[:, 3])))
     print("   %d product workgroups: start %.1f..%.1f (median %.1f), staged +%.1f (median), first tile +%.1f (median after staged), end %.1f..%.1f (median %.1f)"
           % (len(k), k[:, 0].min(), k[:, 0].max(), np.median(k[:, 0]), np.median(k[:, 1] - k[:, 0]), np.median(k[:, 2] - k[:, 1]), k[:, 3].min(), k[:, 3].max(), np.median(k[:, 3])))
+    if want_z:
+        wpg = 16
+        byslot = [float(np.median(k[np.arange(len(k)) % wpg == sl, 3])) for sl in range(wpg)]
+        print("   median end by workgroup slot in its group:", " ".join("%.1f" % v for v in byslot))
+        bygrp = [float(np.median(k[(np.arange(len(k)) // wpg) == gq, 3])) for gq in range(len(k) // wpg)]
+        print("   median end by group:", " ".join("%.1f" % v for v in bygrp))
+        st = k[:, 0]
+        print("   start by slot:", " ".join("%.1f" % float(np.median(st[np.arange(len(k)) % wpg == sl])) for sl in range(wpg)))
