@@ -139,7 +139,8 @@ class AOLoop:
         self.Z = torch.from_numpy(np.ascontiguousarray(np.swapaxes(np.asarray(Z, dtype=np.float64), -1, -2))).to(dev)   # column-major planes
         self.npx = estimator.len ** 2
         self.scrn = torch.empty((batch, estimator.len, estimator.len), **f64)
-        self.x0 = torch.zeros((batch, n), **f64); self.x0_pre = torch.zeros((batch, n), **f64)
+        self._xb = [torch.zeros((batch, n), **f64) for _ in range(2)]          # ad_est of this and of the previous step, in turn
+        self.x0, self.x0_pre = self._xb[0], self._xb[1]
         self.w = torch.zeros((batch, T * n), **f64)
         self._scr_x = torch.zeros((batch, n), **f64); self._scr_xp = torch.zeros((batch, n), **f64); self._zero_a = torch.zeros((batch, n), **f64)
         self.u = [torch.zeros((batch, m), **f64) for _ in range(3)]
@@ -160,9 +161,11 @@ class AOLoop:
         if rc != 0:
             from ._lib import FastMPCError
             raise FastMPCError(rc, "fmpc_phase_residual_device")
-        ad_est = self.est.apply_device(self.scrn, noise, colmajor=True)
-        self.x0_pre.copy_(self.x0) if s >= 1 else self.x0_pre.zero_()
-        self.x0.copy_(ad_est)
+        # x0 = ad_est, x0_pre = the previous ad_est (README.md:482-488): two buffers in turn, the estimator writes into this step's
+        self.x0, self.x0_pre = self._xb[s % 2], self._xb[(s + 1) % 2]
+        if s == 0:
+            self.x0_pre.zero_()
+        self.est.apply_device(self.scrn, noise, colmajor=True, out=self.x0)
         # b_ref = -M1 B u[k-1] - M2 B u[k-2] (README.md:490-497): the loop-input kernel's w; its x0 / x0_pre go to scratch
         self.h.loop_inputs_device(self._zero_a, None, u1 if s >= 1 else None, u2 if s >= 2 else None, self._scr_x, self._scr_xp, self.w)
         self.h.solve_device(self.x0, self.x0_pre, self.w, None, None, self.n_newton, self.k, z_out=None, status=self.status, iters=self.iters,

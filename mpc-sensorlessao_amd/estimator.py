@@ -57,15 +57,17 @@ class PhaseDiversityEstimator:
         except Exception:
             pass
 
-    def apply_device(self, scrn, noise=None, want_Y=False, colmajor=False):
+    def apply_device(self, scrn, noise=None, want_Y=False, colmajor=False, out=None):
         """scrn: (batch, len, len) float64 HIP tensor indexed [b, row, column] (colmajor=True: already [b, column, row], no copy).
-        Returns ad_est (batch, nx) [, Y_M (batch, p)] on torch's current stream."""
+        Returns ad_est (batch, nx) [, Y_M (batch, p)] on torch's current stream; out: a (batch, nx) tensor to write ad_est into."""
         import torch
         if not colmajor:
             scrn = scrn.transpose(-1, -2).contiguous()
         assert scrn.is_cuda and scrn.dtype == torch.float64 and scrn.is_contiguous() and tuple(scrn.shape[1:]) == (self.len, self.len)
         batch = scrn.shape[0]
-        ad = torch.empty((batch, self.nx), dtype=torch.float64, device=scrn.device)
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and tuple(out.shape) == (batch, self.nx)
+        ad = out if out is not None else torch.empty((batch, self.nx), dtype=torch.float64, device=scrn.device)
         Y = torch.empty((batch, self.p), dtype=torch.float64, device=scrn.device) if want_Y else None
         if noise is not None:
             assert noise.is_cuda and noise.dtype == torch.float64 and noise.is_contiguous() and tuple(noise.shape) == (batch, self.p)
