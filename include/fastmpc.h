@@ -309,7 +309,11 @@ int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
  *                        step from the cold start is z+ = zc + Kz [x0; x0_pre], one product per batch on the matrix cores
  *                        (Kz built once per (handle, k) with J; the step-length decision from two quadratic forms of the
  *                        data, problems that are not clear-cut redone by the exact path: tests/test_gpu_affine.py).
- *                        FMPC_NO_AFFINE=1 or fmpc_set_dense_form(h, 0, ..) switch it off. */
+ *                        FMPC_NO_AFFINE=1 or fmpc_set_dense_form(h, 0, ..) switch it off.
+ *                        3 = the first-move form as a product: fmpc_loop_step_device with first moves only (z_out = nu_out =
+ *                        NULL, n_newton == 1) and more than 64 realisations: u0 = u0c + K0 [x0; x0_pre; B u1; B u2] and the
+ *                        same two-form decision, one product per batch (tests/test_gpu_closed_loop.py; FMPC_NO_LOOP_U0=1
+ *                        switches it off). */
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)

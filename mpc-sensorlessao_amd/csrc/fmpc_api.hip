@@ -15,6 +15,7 @@
 #include "fmpc_host.h"
 #include "fmpc_first.h"
 #include "fmpc_affine.h"
+#include "fmpc_loopu0.h"
 #include "fmpc_tiled.h"
 
 // kernels / launchers (fmpc_kernel_generic.hip)
@@ -82,6 +83,7 @@ struct fmpc_handle_s {
     int* fm_walk_i; size_t fm_walk_cap;   // start / stop step per realisation of a walk
     // affine form of the cold-start step without w (fmpc_kernel_affine.hip), built with the first-move form
     FaParams fa_P; int fa_valid, fa_disabled; int* fa_need; size_t fa_need_cap;
+    FlParams fl_P; int fl_valid, fl_disabled;       // first-move form as a product: closed-loop steps of > 64 realisations (fmpc_kernel_loopu0.hip)
     FwModel wave;
     double* wave_pool_d;
     int* wave_pool_i;
@@ -301,8 +303,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
-    h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0;
+    h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0; h->fl_valid = 0;
     { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
+    { const char* na = getenv("FMPC_NO_LOOP_U0"); h->fl_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -1022,6 +1025,32 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         oA = push(AO.img); oAE = push(imgE); oAEp = push(imgEp); oAl = push(el); oAlp = push(epl);
         oAd = push(std::vector<double>(4096, 0.0));
     }
+    // the first-move form as a product over many realisations: [K0 | u0c], E, Ep as matrix-core images over d (4 n entries, then 1)
+    h->fl_valid = 0;
+    size_t oLU = 0, oLE = 0, oLEp = 0, oLl = 0, oLlp = 0;
+    const bool fl_ok = !h->fl_disabled && 4 * n + 1 <= 4 * FL_KS;
+    if (fl_ok) {
+        const int nc = 4 * n, kc = 4 * FL_KS;
+        std::vector<double> U((size_t)m * kc, 0.0), E112((size_t)kc * kc, 0.0), Ep112((size_t)kc * kc, 0.0), el(kc, 0.0), epl(kc, 0.0), iU, iE, iEp;
+        for (int j = 0; j < m; ++j) {
+            for (int c = 0; c < nc; ++c) U[(size_t)j * kc + c] = O.K0t[(size_t)c * m + j];
+            U[(size_t)j * kc + nc] = O.u0c[j];
+        }
+        // forms: block-upper triangle of the symmetric E (16-blocks above the diagonal doubled, those below dropped), the linear
+        // term in the column of the constant (d[4 n] = 1; its own row stays zero)
+        for (int r = 0; r < nc; ++r) {
+            for (int c = 0; c < nc; ++c) {
+                const double wgt = c / 16 > r / 16 ? 2.0 : (c / 16 == r / 16 ? 1.0 : 0.0);
+                E112[(size_t)r * kc + c] = wgt * O.E[(size_t)r * nc + c]; Ep112[(size_t)r * kc + c] = wgt * O.Ep[(size_t)r * nc + c];
+            }
+            el[r] = 2.0 * O.e[r]; epl[r] = -2.0 * O.ep[r];
+            E112[(size_t)r * kc + nc] = el[r]; Ep112[(size_t)r * kc + nc] = epl[r];
+        }
+        fmpc_host_mfma_images(U.data(), m, kc, FL_KS, iU);
+        fmpc_host_mfma_images(E112.data(), kc, kc, FL_KS, iE);
+        fmpc_host_mfma_images(Ep112.data(), kc, kc, FL_KS, iEp);
+        oLU = push(iU); oLE = push(iE); oLEp = push(iEp); oLl = push(el); oLlp = push(epl);
+    }
     if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
     if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
     if (hipMemcpy(h->fm_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
@@ -1039,6 +1068,14 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         A.img = h->fm_pool + oA; A.imgE = h->fm_pool + oAE; A.imgEp = h->fm_pool + oAEp; A.elin = h->fm_pool + oAl; A.eplin = h->fm_pool + oAlp; A.dump = h->fm_pool + oAd;
         A.dx0T = P.dx0T; A.e0 = O.e0; A.ep0 = O.ep0; A.normE = O.normE; A.norme = O.norme; A.normEp = O.normEp; A.normep = O.normep; A.rd2_0 = h->pn_rd2_0;
         h->fa_valid = 1;
+    }
+    if (fl_ok) {
+        FlParams& L = h->fl_P;
+        memset(&L, 0, sizeof(L));
+        L.n = n; L.m = m; L.T = T; L.nb = h->nb; L.has_xf = h->has_xf; L.var2 = In.var2;
+        L.imgU = h->fm_pool + oLU; L.imgE = h->fm_pool + oLE; L.imgEp = h->fm_pool + oLEp; L.elin = h->fm_pool + oLl; L.eplin = h->fm_pool + oLlp;
+        L.dx0T = P.dx0T; L.e0 = O.e0; L.ep0 = O.ep0; L.normE = O.normE; L.norme = O.norme; L.normEp = O.normEp; L.normep = O.normep; L.rd2_0 = h->pn_rd2_0;
+        h->fl_valid = 1;
     }
     return FMPC_OK;
 }
@@ -1328,8 +1365,8 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
 // realisation was not clear-cut.  FMPC_E_UNSUPPORTED: the caller takes the four-launch path.  Caller holds h->mu.
 #define FMPC_FIRST_MOVE_MAX_BATCH 64
 #define FMPC_WALK_MAX_BATCH 4096          // realisations of a one-launch walk (fmpc_loop_run_walk): one workgroup each
-static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_t stream, size_t* stride_out) {
-    if (h->fm_disabled || !h->use_wave || !h->sh_enabled || !h->pn_enabled || !h->inv_enabled || h->n != FP_N || batch > FMPC_FIRST_MOVE_MAX_BATCH)
+static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_t stream, size_t* stride_out, int max_batch = FMPC_FIRST_MOVE_MAX_BATCH) {
+    if (h->fm_disabled || !h->use_wave || !h->sh_enabled || !h->pn_enabled || !h->inv_enabled || h->n != FP_N || batch > max_batch)
         return FMPC_E_UNSUPPORTED;
     size_t stride = 0;
     int rc = fmpc_ensure_wave_ws(h, &stride);
@@ -1359,8 +1396,9 @@ static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_
     }
     if ((size_t)batch > h->fm_need_cap) {
         if (h->fm_need) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_need); h->fm_need = nullptr; h->fm_need_cap = 0; }
-        if (hipMalloc((void**)&h->fm_need, FMPC_FIRST_MOVE_MAX_BATCH * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
-        h->fm_need_cap = FMPC_FIRST_MOVE_MAX_BATCH;
+        const size_t cap = batch > FMPC_FIRST_MOVE_MAX_BATCH ? (size_t)batch : (size_t)FMPC_FIRST_MOVE_MAX_BATCH;
+        if (hipMalloc((void**)&h->fm_need, cap * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+        h->fm_need_cap = cap;
     }
     *stride_out = stride;
     return FMPC_OK;
@@ -1389,6 +1427,41 @@ static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, con
     return FMPC_OK;
 }
 
+// Closed-loop step of MANY realisations with first moves only: the loop-input kernel, the first-move form as a product over the
+// batch (fmpc_kernel_loopu0.hip), the exact path in flag mode -- three launches, none of them over the T stages.
+#define FMPC_LOOP_U0_MAX_BATCH 65536
+static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
+                             double* x0, double* x0_pre, double* w, const double* nu0, double k,
+                             int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+    if (h->fl_disabled) return FMPC_E_UNSUPPORTED;
+    size_t stride = 0;
+    int rc = fmpc_first_move_ensure(h, batch, k, stream, &stride, FMPC_LOOP_U0_MAX_BATCH);
+    if (rc != FMPC_OK) return rc;
+    if (!h->fl_valid) return FMPC_E_UNSUPPORTED;
+    if ((size_t)batch > h->lp_cap) {
+        (void)hipDeviceSynchronize();
+        if (h->lp_v) (void)hipFree(h->lp_v);
+        h->lp_v = nullptr; h->lp_cap = 0;
+        if (hipMalloc((void**)&h->lp_v, (size_t)batch * 2 * h->n * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+        h->lp_cap = batch;
+    }
+    if (fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_k, x0_last, u1, u2,
+                                x0, x0_pre, w, stream, h->lp_v) != hipSuccess) return FMPC_E_HIP;
+    FlParams L = h->fl_P;
+    L.batch = batch; L.step_ld = fmpc_step_ld(1);
+    L.x0 = x0; L.x0_pre = x0_pre; L.v = h->lp_v; L.nu0 = nu0;
+    L.u0out = u0_out; L.status = status; L.iters = iters; L.step = step; L.need = h->fm_need; L.handed = h->pn_cnt;
+    if (fmpc_launch_loop_u0(L, stream) != hipSuccess) return FMPC_E_HIP;
+    const int wpw = fmpc_wave_waves_per_wg();
+    int grid = (batch + wpw - 1) / wpw;
+    if (grid > 64) grid = 64;                      // flagged realisations are few: the list is walked by a small grid (as after the affine kernel)
+    if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
+                         fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                         nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;
+    h->last_path = FMPC_PATH_PANEL; h->inv_last = 3;
+    return FMPC_OK;
+}
+
 // One closed-loop step: fmpc_loop_inputs_device + fmpc_solve_u0_device under one lock, with the knowledge that
 // w = -M1 (B u1) - M2 (B u2) has only 2 n degrees of freedom.
 extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
@@ -1407,6 +1480,8 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
     if (lr && !z_out && !nu_out && n_newton == 1) {
         // first moves only, a few realisations: one launch instead of four (falls through when the form does not apply)
         rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream);
+        if (rc == FMPC_E_UNSUPPORTED && batch > FMPC_FIRST_MOVE_MAX_BATCH)
+            rc = fmpc_loop_u0_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream);
         if (rc != FMPC_E_UNSUPPORTED) { fmpc_guard_end(h, (hipStream_t)stream); return rc; }
         rc = FMPC_OK;
     }

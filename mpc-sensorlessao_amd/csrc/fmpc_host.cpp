@@ -519,6 +519,18 @@ void fmpc_host_build_first_move(const FmpcFirstIn& In, FmpcFirstOut& Out) {
     Out.normE = fro(E); Out.norme = fro(e); Out.normEp = fro(Ep); Out.normep = fro(ep);
 }
 
+void fmpc_host_mfma_images(const double* M, int rows, int cols, int ks, std::vector<double>& img) {
+    const int tiles = (rows + 15) / 16;
+    img.assign((size_t)tiles * ks * 64, 0.0);
+    for (int t = 0; t < tiles; ++t)
+        for (int q = 0; q < ks; ++q)
+            for (int g = 0; g < 4; ++g)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 16 * t + r, col = 4 * q + g;
+                    if (row < rows && col < cols) img[((size_t)t * ks + q) * 64 + g * 16 + r] = M[(size_t)row * cols + col];
+                }
+}
+
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img) {
     const int tiles = (rows + 15) / 16;
     img.assign((size_t)tiles * FA_KS * 64, 0.0);

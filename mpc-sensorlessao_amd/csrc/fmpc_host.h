@@ -122,6 +122,9 @@ struct FmpcAffineOut {
     std::vector<double> img;            // matrix-core operand images: [tile][k-step][lane = 16 (k mod 4) + (row mod 16)], z tiles then nu tiles
 };
 void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
+// operand images [tile][k-step][lane = 16 (k mod 4) + (row mod 16)] of a rows x cols row-major matrix, ks k-steps of 4 columns
+// (rows padded to tiles of 16, columns to 4 ks, with zeros)
+void fmpc_host_mfma_images(const double* M, int rows, int cols, int ks, std::vector<double>& img);
 // operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img);
 

@@ -650,17 +650,39 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
             am1[ks] = ok ? t1 : 0.0; am2[ks] = ok ? t2 : 0.0;
         }
     }
-    for (int base = 0; base < m * n; base += 8 * 256) {
-        double t[8];
+    // B' and the tile's u1, u2 into LDS: every load of the workgroup is requested before the first LDS write (one round trip
+    // instead of one per 2048 entries): 16 + 2 x 9 loads per thread cover m n <= 4096 and 16 m <= 2304 (m = 144); larger
+    // sizes take further rounds.
+    for (int base = 0; base < m * n; base += 16 * 256) {
+        double t[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = Bt[idx < m * n ? idx : 0]; }
+        for (int k = 0; k < 16; ++k) { const int idx = base + k * 256 + tid; t[k] = Bt[idx < m * n ? idx : 0]; }
+        double tu[2][9];
+        const int len = np * m;
+        if (base == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; if (idx < m * n) sBt[idx] = t[k]; }
+            for (int which = 0; which < 2; ++which) {
+                const double* u = which ? u2 : u1;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { const int idx = k * 256 + tid; tu[which][k] = (u && idx < len) ? u[(size_t)p0 * m + idx] : 0.0; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int idx = base + k * 256 + tid; if (idx < m * n) sBt[idx] = t[k]; }
+        if (base == 0) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int idx = k * 256 + tid;
+                    if (idx < LI_PT * m) { const int pp = idx / m; su[(which * LI_PT + pp) * ldu + idx - pp * m] = tu[which][k]; }
+                }
+        }
     }
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 2; ++which) {                  // (m > 144: the rest of u)
         const double* u = which ? u2 : u1;
         const int len = np * m;
-        for (int base = 0; base < LI_PT * m; base += 8 * 256) {
+        for (int base = 9 * 256; base < LI_PT * m; base += 8 * 256) {
             double t[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const int idx = base + k * 256 + tid; t[k] = (u && idx < len) ? u[(size_t)p0 * m + idx] : 0.0; }

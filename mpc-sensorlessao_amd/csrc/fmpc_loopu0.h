@@ -1,0 +1,20 @@
+// Parameter block of the many-realisation first-move kernel (fmpc_kernel_loopu0.hip).  Internal to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define FL_KS 28                        // k-steps of 4: d = [x0 ; x0_pre ; B u1 ; B u2] (4 n = 108), column 108 = the constant 1, then zeros
+
+struct FlParams {
+    int n, m, T, nb, has_xf, var2, batch, step_ld;
+    const double* x0; const double* x0_pre; const double* v;     // per realisation: n, n, 2 n (the loop-input kernel's outputs)
+    const double* nu0;
+    double* u0out; int* status; int* iters; double* step;
+    int* need; int* handed;
+    const double* imgU;                 // [m / 16][FL_KS][64]: operand images of [K0 | u0c | 0 0 0]
+    const double* imgE; const double* imgEp;    // [7][FL_KS][64]: E, Ep (4 n x 4 n, zero padded to 112 x 112)
+    const double* elin; const double* eplin;    // 2 e, -2 ep (112 entries, zero padded)
+    const double* dx0T;
+    double e0, ep0, normE, norme, normEp, normep, rd2_0;
+};
+
+hipError_t fmpc_launch_loop_u0(const FlParams& P, hipStream_t stream);

@@ -7,6 +7,7 @@
   batch512        configs[2]: 512 problems, cold start
   dense_w512      512 problems with a disturbance w: the dense form of the dual solve with all T n columns of w
   closed512       closed loop, 512 realisations: fmpc_loop_step_device per step
+  closed512u0     closed loop, 512 realisations, first moves only, one call per step (loop inputs + fmpc_loop_u0 + flag mode)
   walk64          closed loop, 64 realisations, a recorded stretch of 300 steps in one call (fmpc_first_move_run: one launch)
   estimator256    phase-diversity estimator, 256 screens of 512 x 512 per call (fmpc_est_psf<4>, fmpc_est_finish, fmpc_est_combine)
   budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
@@ -31,7 +32,7 @@ if target == "estimator256":
     print(target, "ad_est norm", float(ad.norm()))
     est.close()
     sys.exit(0)
-n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512") else (64 if target == "walk64" else 2000))
+n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512", "closed512u0") else (64 if target == "walk64" else 2000))
 model = pkg.synthetic.make_model(n, m, T)
 data = pkg.synthetic.make_replay_batch(model, r=0, steps=B)
 h = pkg.FastMPCHandle(model["A1"], model["A2"], model["B"], model["Q"], model["R"], model["Qf"], model["u_min"], model["u_max"],
@@ -46,10 +47,10 @@ if target in ("general_wave", "general_tiled", "tiled_f32"):
 z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
 st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev)
 u0 = torch.empty((B, m), dtype=torch.float64, device=dev)
-if target == "closed512":
+if target in ("closed512", "closed512u0"):
     a = np.stack([pkg.synthetic.make_realisation(model, r=r, steps=reps + 2)[1:reps + 3] for r in range(B)], axis=1)
     at = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    loop = pkg.ClosedLoop(h, B, n_newton=1, k=1e-2)
+    loop = pkg.ClosedLoop(h, B, n_newton=1, k=1e-2, keep_z=target == "closed512")
     for s_ in range(reps + 2):
         loop.step(at[s_])
     st, it = loop.status, loop.iters
@@ -62,7 +63,7 @@ if target == "walk64":
         loop.run_recorded(at, want_x0=False)
     st, it = loop.status, loop.iters
 wt = torch.from_numpy(0.01 * np.random.default_rng(3).standard_normal((B, T * n))).to(dev) if target == "dense_w512" else None
-for _ in range(0 if target in ("closed512", "walk64") else reps):
+for _ in range(0 if target in ("closed512", "closed512u0", "walk64") else reps):
     h.solve_device(x0, x0p, wt, zi, nu0, 5 if target == "budget5" else 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
 torch.cuda.synchronize()
 assert int((st < 0).sum()) == 0

@@ -161,12 +161,14 @@ def test_loop_step_with_a_newton_budget_and_no_nu0(pkg, gpu):
     h.close()
 
 
-@pytest.mark.parametrize("R,T,first_move", [(1, 30, True), (40, 30, True), (37, 10, True), (5, 30, False), (100, 30, None)])
+@pytest.mark.parametrize("R,T,first_move", [(1, 30, True), (40, 30, True), (37, 10, True), (5, 30, False), (100, 30, "product"),
+                                            (65, 30, "product"), (530, 10, "product"), (100, 30, None)])
 def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     """ClosedLoop(keep_z=False): z_out = NULL at the C ABI (fmpc_loop_step_device), only u[k] = U(1:nu) leaves the solve
     (README.md:589).  Up to 64 realisations the step is ONE launch in the first-move form (fmpc_kernel_first.hip: u0 = u0c + K0 d,
     the decision from two quadratic forms; same algebra, different rounding): trajectories within 1e-11 of the loop that keeps z.
-    With the form switched off (FMPC_NO_FIRST_MOVE=1) or more realisations (d_z without z stores): bit for bit."""
+    More than 64 realisations: the same form as one product over the batch (fmpc_kernel_loopu0.hip), same bound.
+    With the forms switched off (FMPC_NO_FIRST_MOVE=1 / FMPC_NO_LOOP_U0=1; d_z without z stores): bit for bit."""
     import torch
     md = pkg.synthetic.make_model(27, 144, T)
     steps = 8
@@ -176,8 +178,11 @@ def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     h1 = handle_from_model(pkg, md)
     if first_move is False:
         monkeypatch.setenv("FMPC_NO_FIRST_MOVE", "1")
+    if first_move is None:
+        monkeypatch.setenv("FMPC_NO_LOOP_U0", "1")
     h2 = handle_from_model(pkg, md)
     monkeypatch.delenv("FMPC_NO_FIRST_MOVE", raising=False)
+    monkeypatch.delenv("FMPC_NO_LOOP_U0", raising=False)
     la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
     lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
     Ua, Xa = la.run(at, nu0)
@@ -186,6 +191,8 @@ def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     assert lb.z is None and h2.last_dispatch() == (pkg.FMPC_PATH_PANEL, 0)
     assert int(la.status.abs().sum()) == 0 and int(lb.status.abs().sum()) == 0
     assert torch.equal(la.iters, lb.iters)
+    # more than 64 realisations: the same form as ONE product per batch on the matrix cores (fmpc_kernel_loopu0.hip; dual form 3)
+    assert h2.last_dual_form() == (3 if first_move == "product" else (1 if first_move else h2.last_dual_form()))
     if first_move:
         assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
         assert rel_err(lb.w.cpu().numpy(), la.w.cpu().numpy()) <= 1e-11
@@ -215,6 +222,36 @@ def test_first_move_form_hands_unclear_realisations_to_the_exact_path(pkg, gpu):
     assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
     U0, X0 = Ub.cpu().numpy(), Xb.cpu().numpy()
     for r in range(R):
+        ref = closed_loop(md, a[:, r], 1, 1e-2)
+        assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
+    h1.close(); h2.close()
+
+
+@pytest.mark.parametrize("ub,var_order", [(0.05, 2), (0.24, 2), (0.24, 1)])
+def test_first_move_product_hands_unclear_realisations_to_the_exact_path(pkg, gpu, ub, var_order):
+    """The product form (more than 64 realisations) with bounds where the decision tips (0.24: flagged and accepted side by side)
+    and where every realisation backtracks (0.05): same status / iterations / step lengths as the four-launch path, trajectories
+    within 1e-11, three realisations against the oracle loop."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 10, var_order=var_order)
+    md["u_min"] = -ub * np.ones(144); md["u_max"] = ub * np.ones(144)
+    R, steps = 75, 4
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    a = a * np.linspace(0.05, 5.0, R)[None, :, None]
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa = la.run(at)
+    Ub, Xb = lb.run(at)
+    torch.cuda.synchronize()
+    assert h2.last_dual_form() == 3
+    handed = h2.last_dispatch()[1]
+    assert handed == R if ub == 0.05 else 0 <= handed <= R
+    assert torch.equal(la.status, lb.status) and torch.equal(la.iters, lb.iters)
+    assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
+    U0, X0 = Ub.cpu().numpy(), Xb.cpu().numpy()
+    for r in (0, R // 2, R - 1):
         ref = closed_loop(md, a[:, r], 1, 1e-2)
         assert rel_err(X0[:, r], ref["x0"]) <= 1e-8 and rel_err(U0[:, r], ref["u0"]) <= 1e-8
     h1.close(); h2.close()
