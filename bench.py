@@ -529,7 +529,8 @@ def _main(real_out):
         extra["closed_loop"] = dict(what="coefficient-space closed loop (README.md:482-497,589; estimator out of scope): every step "
                                          "depends on the previous first move, so only realisations batch; one fmpc_loop_step_device call per step. *_u0_only: z_out = NULL "
                                          "(README.md:589 applies U(1:nu) only); up to 64 realisations that is the first-move form, ONE launch + an exact-path "
-                                         "launch that returns at once (fmpc_kernel_first.hip); *_recorded: the whole stretch in one host call (fmpc_loop_run_device: the reference's "
+                                         "launch that returns at once (fmpc_kernel_first.hip); more realisations: the same form as a product on the matrix "
+                                         "cores between the loop-input kernel and the exact-path launch (fmpc_kernel_loopu0.hip); *_recorded: the whole stretch in one host call (fmpc_loop_run_device: the reference's "
                                          "simulation knows its turbulence coefficients in advance, README.md:51-93), i.e. one launch in which the workgroup of a "
                                          "realisation walks through the steps with its rows of the first-move form in registers, stopping where a step "
                                          "is not clear-cut (the exact path redoes that step)", **cl)
