@@ -293,6 +293,9 @@ int fmpc_set_precision(fmpc_handle h, int mode);
 #define FMPC_PATH_TILED   5   /* tiled kernel, fp64 factor */
 #define FMPC_PATH_TILED_F32 6 /* tiled kernel, fp32 factor + fp64 residuals */
 int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over);
+/* Diagnostic: wavefronts per problem of the last launch of the tiled kernel on this handle (0 = none yet); the kernel runs with
+ * 2, 4 or 8 depending on n, the precision and the batch (few problems: more wavefronts each). */
+int fmpc_last_tiled_wavefronts(fmpc_handle h);
 
 /* FMPC_PATH_PANEL has two forms of the cold-start dual solve nu+ = Y^-1 (ct - b) (inf_newton_solver.m:27-32 at the
  * constant start of fast_mpc_init.m:19-20): the two sweeps through the shared block factor (one CU per 16 problems,

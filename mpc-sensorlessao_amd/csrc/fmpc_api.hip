@@ -130,6 +130,7 @@ struct fmpc_handle_s {
     int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
     struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // bm: padded fp64 images   // [0] fp64, [1] fp32
     double* tl_ws; size_t tl_ws_doubles; int tl_prepared;         // (bit NW: that wavefront count of the fp64 instance is prepared)
+    int tl_last_nw;                       // wavefronts per problem of the last tiled launch (diagnostic)
     int small_tiled;                      // per-problem-factor solves of few problems go to the tiled kernel (FMPC_NO_SMALL_TILED=1: off)
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
@@ -303,6 +304,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
+    h->tl_last_nw = 0;
     h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0; h->fl_valid = 0;
     { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* na = getenv("FMPC_NO_LOOP_U0"); h->fl_disabled = (na && na[0] == '1') ? 1 : 0; }
@@ -792,6 +794,7 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     P.zout = z_out; P.nuout = nu_out; P.status = status; P.iters = iters; P.step = step; P.step_ld = fmpc_step_ld(n_newton);
     P.ws = h->tl_ws; P.ws_stride = L.total; P.u0out = u0_out;
     P.list = list; P.nlist = nlist; P.nuws = nuws;
+    h->tl_last_nw = NWu;
     if (!list) h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
     return fmpc_launch_tiled(P, X.NB, NWu, t, grid, ldsu, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
@@ -1647,6 +1650,8 @@ extern "C" int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_wit
     if (max_batch_with_w >= 0) h->inv_max_batch = max_batch_with_w;
     return FMPC_OK;
 }
+
+extern "C" int fmpc_last_tiled_wavefronts(fmpc_handle h) { return h ? h->tl_last_nw : 0; }
 
 extern "C" int fmpc_last_dispatch(fmpc_handle h, int* path, int* handed_over) {
     if (!h) return FMPC_E_NULL;

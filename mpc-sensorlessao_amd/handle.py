@@ -159,6 +159,10 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_last_dispatch")
         return path.value, cnt.value
 
+    def last_tiled_wavefronts(self):
+        """Wavefronts per problem of the last tiled-kernel launch (fmpc_last_tiled_wavefronts; 0 = none yet)."""
+        return int(self._lib.fmpc_last_tiled_wavefronts(self._h))
+
     def set_dense_form(self, enabled, max_batch_with_w=-1):
         """fmpc_set_dense_form: the cold-start dual solve as one product with J = d nu+ / d [x0; x0_pre; w] (always
         without w; with w up to `max_batch_with_w` problems) instead of the two sweeps through the block factor."""
