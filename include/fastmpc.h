@@ -204,6 +204,10 @@ int fmpc_loop_inputs_device(fmpc_handle h, int batch, const double* a_k, const d
  * only 2 n degrees of freedom, the dense form of the cold-start dual solve (see fmpc_set_dense_form) takes
  * [B u1 ; B u2] in place of the T n entries of w: 28 instead of 217 k-steps per tile at (27, 144, 30), at any batch.
  * z_out may be NULL (first moves only, see fmpc_solve_u0_device).
+ * x0 may alias x0_last here too.  With first moves only, a Newton budget of 1 and more than 64 realisations, a caller that
+ * does NOT update x0 in place (x0_last different from x0 and from x0_pre, or NULL) gets the loop inputs, the first moves and the
+ * step-length decision in ONE launch (fmpc_last_dual_form = 4; with the update in place: three launches, = 3), the same
+ * results to 1e-11 (tests/test_gpu_closed_loop.py); FMPC_NO_LOOP_FUSE=1 switches the one-launch form off.
  */
 int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
                           const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
@@ -316,7 +320,7 @@ int fmpc_last_tiled_wavefronts(fmpc_handle h);
  *                        3 = the first-move form as a product: fmpc_loop_step_device with first moves only (z_out = nu_out =
  *                        NULL, n_newton == 1) and more than 64 realisations: u0 = u0c + K0 [x0; x0_pre; B u1; B u2] and the
  *                        same two-form decision, one product per batch (tests/test_gpu_closed_loop.py; FMPC_NO_LOOP_U0=1
- *                        switches it off). */
+ *                        switches it off).  4 = the same with the loop inputs in the same launch (see fmpc_loop_step_device). */
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)

@@ -27,7 +27,10 @@ class ClosedLoop:
         dev = torch.device("cuda", handle.device) if device is None else device
         f64 = dict(dtype=torch.float64, device=dev)
         n, m, T = handle.n, handle.m, handle.T
-        self.x0 = torch.zeros((batch, n), **f64)
+        # x0 alternates between two buffers (the fused step reads x0[k-1] while it writes x0[k]: with the update in place the
+        # library cannot do loop inputs, first moves and decision in ONE launch -- fmpc_loop_step_device in include/fastmpc.h)
+        self._xb = [torch.zeros((batch, n), **f64) for _ in range(2)]
+        self._cur = 0
         self.x0_pre = torch.zeros((batch, n), **f64)
         self.w = torch.zeros((batch, T * n), **f64)
         self.u = [torch.zeros((batch, m), **f64) for _ in range(3)]     # ring: u[k], u[k-1], u[k-2]
@@ -44,10 +47,15 @@ class ClosedLoop:
         import ctypes as C
         self._C, self._torch, self._dev = C, torch, dev
         vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        self._p = dict(x0=vp(self.x0), x0_pre=vp(self.x0_pre), w=vp(self.w), u=[vp(u) for u in self.u], z=vp(self.z),
+        self._p = dict(xb=[vp(b) for b in self._xb], x0_pre=vp(self.x0_pre), w=vp(self.w), u=[vp(u) for u in self.u], z=vp(self.z),
                        status=vp(self.status), iters=vp(self.iters))
         self._fn = handle._lib.fmpc_loop_step_device
         self._n_newton_c, self._k_c = int(self.n_newton), float(self.k)
+
+    @property
+    def x0(self):
+        """x0 of the last step (batch, n)."""
+        return self._xb[self._cur]
 
     def _step_fused(self, a_k, nu0, s):
         torch, C = self._torch, self._C
@@ -57,13 +65,15 @@ class ClosedLoop:
             raise ValueError("nu0: need a contiguous float64 HIP tensor of shape (batch, nu_len)")
         P = self._p
         u = P["u"]
-        rc = self._fn(self.h._h, self.batch, C.c_void_p(a_k.data_ptr()), P["x0"] if s >= 1 else None, u[(s - 1) % 3] if s >= 1 else None,
-                      u[(s - 2) % 3] if s >= 2 else None, P["x0"], P["x0_pre"], P["w"], None if nu0 is None else C.c_void_p(nu0.data_ptr()),
+        cur = self._cur
+        rc = self._fn(self.h._h, self.batch, C.c_void_p(a_k.data_ptr()), P["xb"][cur] if s >= 1 else None, u[(s - 1) % 3] if s >= 1 else None,
+                      u[(s - 2) % 3] if s >= 2 else None, P["xb"][1 - cur], P["x0_pre"], P["w"], None if nu0 is None else C.c_void_p(nu0.data_ptr()),
                       self._n_newton_c, self._k_c, P["z"], None, P["status"], P["iters"], None, u[s % 3],
                       C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
         if rc != 0:
             from ._lib import FastMPCError
             raise FastMPCError(rc, "fmpc_loop_step_device")
+        self._cur = 1 - cur
 
     def step(self, a_k, nu0=None):
         """One closed-loop step for all realisations.  a_k: (batch, n) device tensor.  Returns u[k] (batch, m),
@@ -97,7 +107,7 @@ class ClosedLoop:
         vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         rc = self.h._lib.fmpc_loop_run_device(self.h._h, self.batch, steps, vp(a), vp(nu0), P["u"][(s - 1) % 3] if s >= 1 else None,
                                               P["u"][(s - 2) % 3] if s >= 2 else None, 1 if s >= 1 else 0, self._n_newton_c, self._k_c,
-                                              P["x0"], P["x0_pre"], P["w"], vp(U0), vp(X0), P["status"], P["iters"],
+                                              P["xb"][self._cur], P["x0_pre"], P["w"], vp(U0), vp(X0), P["status"], P["iters"],
                                               C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
         if rc != 0:
             from ._lib import FastMPCError

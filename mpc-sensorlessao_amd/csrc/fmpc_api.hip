@@ -83,6 +83,7 @@ struct fmpc_handle_s {
     int* fm_walk_i; size_t fm_walk_cap;   // start / stop step per realisation of a walk
     // affine form of the cold-start step without w (fmpc_kernel_affine.hip), built with the first-move form
     FaParams fa_P; int fa_valid, fa_disabled; int* fa_need; size_t fa_need_cap;
+    FlParams fs_P; FlStepIn fs_I; int fs_valid, fs_disabled;   // the fused step (fmpc_loop_step27): images in its column order, B's images
     FlParams fl_P; int fl_valid, fl_disabled;       // first-move form as a product: closed-loop steps of > 64 realisations (fmpc_kernel_loopu0.hip)
     FwModel wave;
     double* wave_pool_d;
@@ -305,9 +306,10 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
     h->tl_last_nw = 0;
-    h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0; h->fl_valid = 0;
+    h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0; h->fl_valid = 0; h->fs_valid = 0;
     { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* na = getenv("FMPC_NO_LOOP_U0"); h->fl_disabled = (na && na[0] == '1') ? 1 : 0; }
+    { const char* na = getenv("FMPC_NO_LOOP_FUSE"); h->fs_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -1054,6 +1056,36 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         fmpc_host_mfma_images(Ep112.data(), kc, kc, FL_KS, iEp);
         oLU = push(iU); oLE = push(iE); oLEp = push(iEp); oLl = push(el); oLlp = push(epl);
     }
+    // the fused step: the same three maps over d in ITS order -- four blocks of 28 (27 entries + a pad), the constant in column 111 --
+    // and B as operand images
+    h->fs_valid = 0;
+    size_t oSU = 0, oSE = 0, oSEp = 0, oSB = 0;
+    const bool fs_ok = fl_ok && !h->fs_disabled && n == 27 && m <= 144;
+    if (fs_ok) {
+        const int nc = 4 * n, kc = 4 * FL_KS, cst = kc - 1;
+        auto col = [&](int c) { return 28 * (c / n) + c % n; };                    // original column of d -> fused column
+        std::vector<double> U((size_t)m * kc, 0.0), E2((size_t)kc * kc, 0.0), Ep2((size_t)kc * kc, 0.0), Brm((size_t)n * m), iU, iE, iEp, iB;
+        for (int j = 0; j < m; ++j) {
+            for (int c = 0; c < nc; ++c) U[(size_t)j * kc + col(c)] = O.K0t[(size_t)c * m + j];
+            U[(size_t)j * kc + cst] = O.u0c[j];
+        }
+        for (int r = 0; r < nc; ++r) {
+            const int rr = col(r);
+            for (int c = 0; c < nc; ++c) {
+                const int cc = col(c);
+                const double wgt = cc / 16 > rr / 16 ? 2.0 : (cc / 16 == rr / 16 ? 1.0 : 0.0);
+                E2[(size_t)rr * kc + cc] = wgt * O.E[(size_t)r * nc + c]; Ep2[(size_t)rr * kc + cc] = wgt * O.Ep[(size_t)r * nc + c];
+            }
+            E2[(size_t)rr * kc + cst] = 2.0 * O.e[r]; Ep2[(size_t)rr * kc + cst] = -2.0 * O.ep[r];
+        }
+        for (int q = 0; q < n; ++q)
+            for (int c = 0; c < m; ++c) Brm[(size_t)q * m + c] = In.bt[(size_t)c * n + q];
+        fmpc_host_mfma_images(U.data(), m, kc, FL_KS, iU);
+        fmpc_host_mfma_images(E2.data(), kc, kc, FL_KS, iE);
+        fmpc_host_mfma_images(Ep2.data(), kc, kc, FL_KS, iEp);
+        fmpc_host_mfma_images(Brm.data(), n, m, (m + 3) / 4, iB);
+        oSU = push(iU); oSE = push(iE); oSEp = push(iEp); oSB = push(iB);
+    }
     if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
     if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
     if (hipMemcpy(h->fm_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
@@ -1079,6 +1111,15 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         L.imgU = h->fm_pool + oLU; L.imgE = h->fm_pool + oLE; L.imgEp = h->fm_pool + oLEp; L.elin = h->fm_pool + oLl; L.eplin = h->fm_pool + oLlp;
         L.dx0T = P.dx0T; L.e0 = O.e0; L.ep0 = O.ep0; L.normE = O.normE; L.norme = O.norme; L.normEp = O.normEp; L.normep = O.normep; L.rd2_0 = h->pn_rd2_0;
         h->fl_valid = 1;
+        if (fs_ok) {
+            h->fs_P = L;
+            h->fs_P.imgU = h->fm_pool + oSU; h->fs_P.imgE = h->fm_pool + oSE; h->fs_P.imgEp = h->fm_pool + oSEp;
+            memset(&h->fs_I, 0, sizeof(h->fs_I));
+            const int Tn = T * n;
+            h->fs_I.rs = (Tn + 63) / 64; h->fs_I.rows = (Tn + h->fs_I.rs - 1) / h->fs_I.rs;
+            h->fs_I.imgB = h->fm_pool + oSB; h->fs_I.M1 = h->loop_M1; h->fs_I.M2 = h->loop_M2;
+            h->fs_valid = 1;
+        }
     }
     return FMPC_OK;
 }
@@ -1441,6 +1482,25 @@ static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const 
     int rc = fmpc_first_move_ensure(h, batch, k, stream, &stride, FMPC_LOOP_U0_MAX_BATCH);
     if (rc != FMPC_OK) return rc;
     if (!h->fl_valid) return FMPC_E_UNSUPPORTED;
+    const int wpw = fmpc_wave_waves_per_wg();
+    int grid = (batch + wpw - 1) / wpw;
+    if (grid > 64) grid = 64;                      // flagged realisations are few: the list is walked by a small grid (as after the affine kernel)
+    // ONE launch for the loop inputs, the first moves and the decision -- when the other workgroups may read x0_last while
+    // x0 and x0_pre are written, i.e. when the caller does not update x0 in place
+    if (h->fs_valid && h->loop_M1 && (x0_last == nullptr || (x0_last != x0 && x0_last != x0_pre))) {
+        FlParams L = h->fs_P;
+        FlStepIn I = h->fs_I;
+        L.batch = batch; L.step_ld = fmpc_step_ld(1);
+        L.nu0 = nu0; L.u0out = u0_out; L.status = status; L.iters = iters; L.step = step; L.need = h->fm_need; L.handed = h->pn_cnt;
+        L.x0w = x0; L.x0pw = x0_pre;
+        I.a = a_k; I.x0_last = x0_last; I.u1 = u1; I.u2 = u2; I.w = w;
+        if (fmpc_launch_loop_step27(L, I, stream) != hipSuccess) return FMPC_E_HIP;
+        if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
+                             fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                             nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;
+        h->last_path = FMPC_PATH_PANEL; h->inv_last = 4;
+        return FMPC_OK;
+    }
     if ((size_t)batch > h->lp_cap) {
         (void)hipDeviceSynchronize();
         if (h->lp_v) (void)hipFree(h->lp_v);
@@ -1455,9 +1515,6 @@ static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const 
     L.x0 = x0; L.x0_pre = x0_pre; L.v = h->lp_v; L.nu0 = nu0;
     L.u0out = u0_out; L.status = status; L.iters = iters; L.step = step; L.need = h->fm_need; L.handed = h->pn_cnt;
     if (fmpc_launch_loop_u0(L, stream) != hipSuccess) return FMPC_E_HIP;
-    const int wpw = fmpc_wave_waves_per_wg();
-    int grid = (batch + wpw - 1) / wpw;
-    if (grid > 64) grid = 64;                      // flagged realisations are few: the list is walked by a small grid (as after the affine kernel)
     if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
                          fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
                          nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;

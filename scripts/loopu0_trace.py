@@ -15,10 +15,18 @@ loop = pkg.ClosedLoop(h, R, n_newton=1, k=1e-2, keep_z=False)
 for s in range(steps):
     loop.step(at[s])
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 2048)()
+out = (C.c_ulonglong * 4096)()
 lib.fmpc_debug_loopu0_trace.argtypes = [C.c_void_p]; lib.fmpc_debug_loopu0_trace(out)
-t = np.array(out[:], dtype=np.int64).reshape(2, 128, 8)
+t = np.array(out[:], dtype=np.int64).reshape(4, 128, 8)
 nb = (R + 15) // 16
+if h.last_dual_form() == 4:                                # the fused step (fmpc_loop_step27): roles w slice 0 / first moves (two halves) / forms
+    t0 = t[:, :nb, 0].min()
+    for y, name in ((0, "w slice 0"), (1, "first moves a"), (2, "first moves b"), (3, "forms")):
+        k = (t[y, :nb] - t0) * 0.01
+        print("%-14s start %.1f..%.1f | operands of B u there %.1f | B u reduced %.1f | %s end %.1f (medians; max end %.1f)"
+              % (name, k[:, 0].min(), k[:, 0].max(), np.median(k[:, 1]), np.median(k[:, 2]), ("forms summed %.1f |" % np.median(k[:, 4])) if y == 3 else "", np.median(k[:, 3]), k[:, 3].max()))
+    sys.exit(0)
+t = t.reshape(-1)[:2048].reshape(2, 128, 8)
 t0 = t[:, :nb, 0].min()
 for y, name in ((0, "first moves"), (1, "forms")):
     k = (t[y, :nb] - t0) * 0.01

@@ -162,7 +162,8 @@ def test_loop_step_with_a_newton_budget_and_no_nu0(pkg, gpu):
 
 
 @pytest.mark.parametrize("R,T,first_move", [(1, 30, True), (40, 30, True), (37, 10, True), (5, 30, False), (100, 30, "product"),
-                                            (65, 30, "product"), (530, 10, "product"), (100, 30, None)])
+                                            (65, 30, "product"), (530, 10, "product"), (100, 30, "product3"), (530, 10, "product3"),
+                                            (100, 30, None)])
 def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     """ClosedLoop(keep_z=False): z_out = NULL at the C ABI (fmpc_loop_step_device), only u[k] = U(1:nu) leaves the solve
     (README.md:589).  Up to 64 realisations the step is ONE launch in the first-move form (fmpc_kernel_first.hip: u0 = u0c + K0 d,
@@ -180,9 +181,12 @@ def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
         monkeypatch.setenv("FMPC_NO_FIRST_MOVE", "1")
     if first_move is None:
         monkeypatch.setenv("FMPC_NO_LOOP_U0", "1")
+    if first_move == "product3":
+        monkeypatch.setenv("FMPC_NO_LOOP_FUSE", "1")
     h2 = handle_from_model(pkg, md)
     monkeypatch.delenv("FMPC_NO_FIRST_MOVE", raising=False)
     monkeypatch.delenv("FMPC_NO_LOOP_U0", raising=False)
+    monkeypatch.delenv("FMPC_NO_LOOP_FUSE", raising=False)
     la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
     lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
     Ua, Xa = la.run(at, nu0)
@@ -192,7 +196,8 @@ def test_closed_loop_first_moves_only(pkg, gpu, R, T, first_move, monkeypatch):
     assert int(la.status.abs().sum()) == 0 and int(lb.status.abs().sum()) == 0
     assert torch.equal(la.iters, lb.iters)
     # more than 64 realisations: the same form as ONE product per batch on the matrix cores (fmpc_kernel_loopu0.hip; dual form 3)
-    assert h2.last_dual_form() == (3 if first_move == "product" else (1 if first_move else h2.last_dual_form()))
+    # (ClosedLoop alternates two x0 buffers, so the loop inputs ride in the same launch: dual form 4; FMPC_NO_LOOP_FUSE=1: 3)
+    assert h2.last_dual_form() == {"product": 4, "product3": 3}.get(first_move, 1 if first_move else h2.last_dual_form())
     if first_move:
         assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
         assert rel_err(lb.w.cpu().numpy(), la.w.cpu().numpy()) <= 1e-11
@@ -227,8 +232,8 @@ def test_first_move_form_hands_unclear_realisations_to_the_exact_path(pkg, gpu):
     h1.close(); h2.close()
 
 
-@pytest.mark.parametrize("ub,var_order", [(0.05, 2), (0.24, 2), (0.24, 1)])
-def test_first_move_product_hands_unclear_realisations_to_the_exact_path(pkg, gpu, ub, var_order):
+@pytest.mark.parametrize("ub,var_order,fuse", [(0.05, 2, True), (0.24, 2, True), (0.24, 1, True), (0.24, 2, False), (0.05, 1, False)])
+def test_first_move_product_hands_unclear_realisations_to_the_exact_path(pkg, gpu, ub, var_order, fuse, monkeypatch):
     """The product form (more than 64 realisations) with bounds where the decision tips (0.24: flagged and accepted side by side)
     and where every realisation backtracks (0.05): same status / iterations / step lengths as the four-launch path, trajectories
     within 1e-11, three realisations against the oracle loop."""
@@ -239,13 +244,17 @@ def test_first_move_product_hands_unclear_realisations_to_the_exact_path(pkg, gp
     a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
     a = a * np.linspace(0.05, 5.0, R)[None, :, None]
     at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
-    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    h1 = handle_from_model(pkg, md)
+    if not fuse:
+        monkeypatch.setenv("FMPC_NO_LOOP_FUSE", "1")
+    h2 = handle_from_model(pkg, md)
+    monkeypatch.delenv("FMPC_NO_LOOP_FUSE", raising=False)
     la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
     lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
     Ua, Xa = la.run(at)
     Ub, Xb = lb.run(at)
     torch.cuda.synchronize()
-    assert h2.last_dual_form() == 3
+    assert h2.last_dual_form() == (4 if fuse else 3)
     handed = h2.last_dispatch()[1]
     assert handed == R if ub == 0.05 else 0 <= handed <= R
     assert torch.equal(la.status, lb.status) and torch.equal(la.iters, lb.iters)
@@ -364,4 +373,35 @@ def test_first_move_decision_forms_against_the_oracle(pkg, gpu, ub):
             assert f[r, 2] <= info["rho2"][0] * (1 + 1e-9)
     assert fn(h._h, None) == 0
     assert worst_e <= 1e-6 and worst_p <= 1e-6, (worst_e, worst_p)
+    h.close()
+
+
+def test_loop_step_in_place_and_with_separate_x0_buffers(pkg, gpu):
+    """fmpc_loop_step_device with more than 64 realisations and first moves only: x0 updated in place (x0_last == x0) takes the
+    three-launch form (dual form 3), separate buffers the one-launch form (4); x0, x0_pre, w and the first moves agree to 1e-12
+    (w and x0 bit for bit: the same products in the same order)."""
+    import ctypes as C
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 30)
+    R, dev = 150, torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh)).to(dev)
+    a, xl, u1, u2 = 0.3 * f(R, 27), 0.3 * f(R, 27), 0.1 * f(R, 144), 0.1 * f(R, 144)
+    nu0 = torch.from_numpy(rng.random((R, 30 * 27))).to(dev)
+    h = handle_from_model(pkg, md)
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    out = {}
+    for mode in ("in_place", "separate"):
+        x0 = xl.clone() if mode == "in_place" else torch.zeros_like(xl)
+        x0p = torch.zeros_like(xl); w = torch.zeros((R, 810), dtype=torch.float64, device=dev); u0 = torch.zeros((R, 144), dtype=torch.float64, device=dev)
+        st = torch.full((R,), -9, dtype=torch.int32, device=dev); it = torch.full((R,), -9, dtype=torch.int32, device=dev)
+        rc = h._lib.fmpc_loop_step_device(h._h, R, vp(a), vp(x0 if mode == "in_place" else xl), vp(u1), vp(u2), vp(x0), vp(x0p), vp(w), vp(nu0), 1, 1e-2,
+                                          None, None, vp(st), vp(it), None, vp(u0), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == 0 and h.last_dual_form() == (3 if mode == "in_place" else 4)
+        out[mode] = [t.cpu().numpy() for t in (x0, x0p, w, u0, st, it)]
+    A, B_ = out["in_place"], out["separate"]
+    assert np.array_equal(A[0], B_[0]) and np.array_equal(A[1], B_[1]) and np.array_equal(A[1], xl.cpu().numpy())
+    assert np.array_equal(A[4], B_[4]) and np.array_equal(A[5], B_[5]) and int(np.abs(A[4]).sum()) == 0
+    assert rel_err(B_[2], A[2]) <= 1e-13 and rel_err(B_[3], A[3]) <= 1e-12
     h.close()
