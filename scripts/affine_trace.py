@@ -21,6 +21,17 @@ for want_z in (True, False):
     out = (C.c_ulonglong * 8192)()
     lib.fmpc_debug_affine_trace.argtypes = [C.c_void_p]; lib.fmpc_debug_affine_trace(out)
     t = np.array(out[:], dtype=np.int64).reshape(1024, 8)
+    if hasattr(lib, "fmpc_debug_affine_trace_cycles"):
+        outc = (C.c_ulonglong * 8192)()
+        lib.fmpc_debug_affine_trace_cycles.argtypes = [C.c_void_p]; lib.fmpc_debug_affine_trace_cycles(outc)
+        tc = np.array(outc[:], dtype=np.int64).reshape(1024, 8)
+        u = t[:, 0] > 0
+        def mhz(a, b):
+            dw = (t[u, b] - t[u, a]) * 0.01; dc = (tc[u, b] - tc[u, a]).astype(np.float64)
+            ok = dw > 0.3
+            return float(np.median(dc[ok] / dw[ok])) if ok.any() else float("nan")
+        print("   shader-clock counter per us of wall clock: start->staged %.0f, staged->first operand %.0f, first tile %.0f, first tile done->end %.0f"
+              % (mhz(0, 1), mhz(1, 5), mhz(5, 6), mhz(6, 3)))
     nf = 0
     used = t[:, 0] > 0
     t0 = t[used, 0].min()
@@ -36,5 +47,5 @@ for want_z in (True, False):
         print("   median end by workgroup slot in its group:", " ".join("%.1f" % v for v in byslot))
         bygrp = [float(np.median(k[(np.arange(len(k)) // wpg) == gq, 3])) for gq in range(len(k) // wpg)]
         print("   median end by group:", " ".join("%.1f" % v for v in bygrp))
-        st = k[:, 0]
-        print("   start by slot:", " ".join("%.1f" % float(np.median(st[np.arange(len(k)) % wpg == sl])) for sl in range(wpg)))
+        st0 = k[:, 0]
+        print("   start by slot:", " ".join("%.1f" % float(np.median(st0[np.arange(len(k)) % wpg == sl])) for sl in range(wpg)))
