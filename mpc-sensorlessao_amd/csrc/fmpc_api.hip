@@ -1030,61 +1030,22 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         oA = push(AO.img); oAE = push(imgE); oAEp = push(imgEp); oAl = push(el); oAlp = push(epl);
         oAd = push(std::vector<double>(4096, 0.0));
     }
-    // the first-move form as a product over many realisations: [K0 | u0c], E, Ep as matrix-core images over d (4 n entries, then 1)
-    h->fl_valid = 0;
-    size_t oLU = 0, oLE = 0, oLEp = 0, oLl = 0, oLlp = 0;
+    // the first-move form as a product over many realisations (fmpc_kernel_loopu0.hip): [K0 | u0c], E, Ep as matrix-core images
+    // over d -- in the order [x0; x0_pre; B u1; B u2; 1] behind the loop-input kernel, in blocks of 28 with the constant in
+    // column 111 for the one-launch step (which also takes B as operand images); built by fmpc_host_build_loop_images
+    h->fl_valid = 0; h->fs_valid = 0;
+    size_t oLU = 0, oLE = 0, oLEp = 0, oSU = 0, oSE = 0, oSEp = 0, oSB = 0;
     const bool fl_ok = !h->fl_disabled && 4 * n + 1 <= 4 * FL_KS;
-    if (fl_ok) {
-        const int nc = 4 * n, kc = 4 * FL_KS;
-        std::vector<double> U((size_t)m * kc, 0.0), E112((size_t)kc * kc, 0.0), Ep112((size_t)kc * kc, 0.0), el(kc, 0.0), epl(kc, 0.0), iU, iE, iEp;
-        for (int j = 0; j < m; ++j) {
-            for (int c = 0; c < nc; ++c) U[(size_t)j * kc + c] = O.K0t[(size_t)c * m + j];
-            U[(size_t)j * kc + nc] = O.u0c[j];
-        }
-        // forms: block-upper triangle of the symmetric E (16-blocks above the diagonal doubled, those below dropped), the linear
-        // term in the column of the constant (d[4 n] = 1; its own row stays zero)
-        for (int r = 0; r < nc; ++r) {
-            for (int c = 0; c < nc; ++c) {
-                const double wgt = c / 16 > r / 16 ? 2.0 : (c / 16 == r / 16 ? 1.0 : 0.0);
-                E112[(size_t)r * kc + c] = wgt * O.E[(size_t)r * nc + c]; Ep112[(size_t)r * kc + c] = wgt * O.Ep[(size_t)r * nc + c];
-            }
-            el[r] = 2.0 * O.e[r]; epl[r] = -2.0 * O.ep[r];
-            E112[(size_t)r * kc + nc] = el[r]; Ep112[(size_t)r * kc + nc] = epl[r];
-        }
-        fmpc_host_mfma_images(U.data(), m, kc, FL_KS, iU);
-        fmpc_host_mfma_images(E112.data(), kc, kc, FL_KS, iE);
-        fmpc_host_mfma_images(Ep112.data(), kc, kc, FL_KS, iEp);
-        oLU = push(iU); oLE = push(iE); oLEp = push(iEp); oLl = push(el); oLlp = push(epl);
-    }
-    // the fused step: the same three maps over d in ITS order -- four blocks of 28 (27 entries + a pad), the constant in column 111 --
-    // and B as operand images
-    h->fs_valid = 0;
-    size_t oSU = 0, oSE = 0, oSEp = 0, oSB = 0;
     const bool fs_ok = fl_ok && !h->fs_disabled && n == 27 && m <= 144;
+    if (fl_ok) {
+        FmpcLoopImages LI;
+        fmpc_host_build_loop_images(O, n, m, FL_KS, false, nullptr, LI);
+        oLU = push(LI.imgU); oLE = push(LI.imgE); oLEp = push(LI.imgEp);
+    }
     if (fs_ok) {
-        const int nc = 4 * n, kc = 4 * FL_KS, cst = kc - 1;
-        auto col = [&](int c) { return 28 * (c / n) + c % n; };                    // original column of d -> fused column
-        std::vector<double> U((size_t)m * kc, 0.0), E2((size_t)kc * kc, 0.0), Ep2((size_t)kc * kc, 0.0), Brm((size_t)n * m), iU, iE, iEp, iB;
-        for (int j = 0; j < m; ++j) {
-            for (int c = 0; c < nc; ++c) U[(size_t)j * kc + col(c)] = O.K0t[(size_t)c * m + j];
-            U[(size_t)j * kc + cst] = O.u0c[j];
-        }
-        for (int r = 0; r < nc; ++r) {
-            const int rr = col(r);
-            for (int c = 0; c < nc; ++c) {
-                const int cc = col(c);
-                const double wgt = cc / 16 > rr / 16 ? 2.0 : (cc / 16 == rr / 16 ? 1.0 : 0.0);
-                E2[(size_t)rr * kc + cc] = wgt * O.E[(size_t)r * nc + c]; Ep2[(size_t)rr * kc + cc] = wgt * O.Ep[(size_t)r * nc + c];
-            }
-            E2[(size_t)rr * kc + cst] = 2.0 * O.e[r]; Ep2[(size_t)rr * kc + cst] = -2.0 * O.ep[r];
-        }
-        for (int q = 0; q < n; ++q)
-            for (int c = 0; c < m; ++c) Brm[(size_t)q * m + c] = In.bt[(size_t)c * n + q];
-        fmpc_host_mfma_images(U.data(), m, kc, FL_KS, iU);
-        fmpc_host_mfma_images(E2.data(), kc, kc, FL_KS, iE);
-        fmpc_host_mfma_images(Ep2.data(), kc, kc, FL_KS, iEp);
-        fmpc_host_mfma_images(Brm.data(), n, m, (m + 3) / 4, iB);
-        oSU = push(iU); oSE = push(iE); oSEp = push(iEp); oSB = push(iB);
+        FmpcLoopImages LI;
+        fmpc_host_build_loop_images(O, n, m, FL_KS, true, In.bt, LI);
+        oSU = push(LI.imgU); oSE = push(LI.imgE); oSEp = push(LI.imgEp); oSB = push(LI.imgB);
     }
     if (h->fm_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->fm_pool); h->fm_pool = nullptr; }
     if (hipMalloc((void**)&h->fm_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
@@ -1108,7 +1069,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         FlParams& L = h->fl_P;
         memset(&L, 0, sizeof(L));
         L.n = n; L.m = m; L.T = T; L.nb = h->nb; L.has_xf = h->has_xf; L.var2 = In.var2;
-        L.imgU = h->fm_pool + oLU; L.imgE = h->fm_pool + oLE; L.imgEp = h->fm_pool + oLEp; L.elin = h->fm_pool + oLl; L.eplin = h->fm_pool + oLlp;
+        L.imgU = h->fm_pool + oLU; L.imgE = h->fm_pool + oLE; L.imgEp = h->fm_pool + oLEp;
         L.dx0T = P.dx0T; L.e0 = O.e0; L.ep0 = O.ep0; L.normE = O.normE; L.norme = O.norme; L.normEp = O.normEp; L.normep = O.normep; L.rd2_0 = h->pn_rd2_0;
         h->fl_valid = 1;
         if (fs_ok) {

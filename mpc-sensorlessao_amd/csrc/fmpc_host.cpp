@@ -531,6 +531,37 @@ void fmpc_host_mfma_images(const double* M, int rows, int cols, int ks, std::vec
                 }
 }
 
+void fmpc_host_build_loop_images(const FmpcFirstOut& O, int n, int m, int ks, bool fused, const double* bt, FmpcLoopImages& out) {
+    const int nc = 4 * n, kc = 4 * ks, cst = fused ? kc - 1 : nc;
+    auto col = [&](int c) { return fused ? ks * (c / n) + c % n : c; };          // column of d -> column of the images
+    std::vector<double> U((size_t)m * kc, 0.0), E2((size_t)kc * kc, 0.0), Ep2((size_t)kc * kc, 0.0);
+    for (int j = 0; j < m; ++j) {
+        for (int c = 0; c < nc; ++c) U[(size_t)j * kc + col(c)] = O.K0t[(size_t)c * m + j];
+        U[(size_t)j * kc + cst] = O.u0c[j];
+    }
+    for (int r = 0; r < nc; ++r) {
+        const int rr = col(r);
+        for (int c = 0; c < nc; ++c) {
+            const int cc = col(c);
+            const double wgt = cc / 16 > rr / 16 ? 2.0 : (cc / 16 == rr / 16 ? 1.0 : 0.0);
+            E2[(size_t)rr * kc + cc] = wgt * O.E[(size_t)r * nc + c];
+            Ep2[(size_t)rr * kc + cc] = wgt * O.Ep[(size_t)r * nc + c];
+        }
+        E2[(size_t)rr * kc + cst] = 2.0 * O.e[r];
+        Ep2[(size_t)rr * kc + cst] = -2.0 * O.ep[r];
+    }
+    fmpc_host_mfma_images(U.data(), m, kc, ks, out.imgU);
+    fmpc_host_mfma_images(E2.data(), kc, kc, ks, out.imgE);
+    fmpc_host_mfma_images(Ep2.data(), kc, kc, ks, out.imgEp);
+    out.imgB.clear();
+    if (fused && bt) {
+        std::vector<double> Brm((size_t)n * m);
+        for (int q = 0; q < n; ++q)
+            for (int c = 0; c < m; ++c) Brm[(size_t)q * m + c] = bt[(size_t)c * n + q];
+        fmpc_host_mfma_images(Brm.data(), n, m, (m + 3) / 4, out.imgB);
+    }
+}
+
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img) {
     const int tiles = (rows + 15) / 16;
     img.assign((size_t)tiles * FA_KS * 64, 0.0);

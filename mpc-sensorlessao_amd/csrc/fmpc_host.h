@@ -125,6 +125,16 @@ void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
 // operand images [tile][k-step][lane = 16 (k mod 4) + (row mod 16)] of a rows x cols row-major matrix, ks k-steps of 4 columns
 // (rows padded to tiles of 16, columns to 4 ks, with zeros)
 void fmpc_host_mfma_images(const double* M, int rows, int cols, int ks, std::vector<double>& img);
+// ---- the first-move form as products over many realisations (fmpc_kernel_loopu0.hip): images over d of ks k-steps
+//   imgU  [ceil(m / 16)][ks][64]   rows of [K0 | u0c]: column of the constant holds u0c
+//   imgE, imgEp [ks / 4][ks][64]   E, Ep (symmetric, 4 n x 4 n) with only the BLOCK-UPPER triangle of 16 x 16 blocks kept
+//                                  (blocks above the diagonal doubled, those below dropped) and the linear term (2 e / -2 ep) in
+//                                  the column of the constant, whose own row is zero: d'E^ d = d'E d + 2 e'd for d[const] = 1
+// Column order of d: fused = false: [x0; x0_pre; B u1; B u2] contiguous (4 n entries), the constant at 4 n;
+//                    fused = true : four blocks of ks (27 entries + a zero pad each, ks = 28), the constant in the last pad slot
+//                                   (column 4 ks - 1), and imgB [2][ceil(m / 4)][64] = operand images of B (n x m) from bt.
+struct FmpcLoopImages { std::vector<double> imgU, imgE, imgEp, imgB; };
+void fmpc_host_build_loop_images(const FmpcFirstOut& O, int n, int m, int ks, bool fused, const double* bt, FmpcLoopImages& out);
 // operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img);
 

@@ -13,7 +13,6 @@ struct FlParams {
     int* need; int* handed;
     const double* imgU;                 // [m / 16][FL_KS][64]: operand images of [K0 | u0c | 0 0 0]
     const double* imgE; const double* imgEp;    // [7][FL_KS][64]: E, Ep (4 n x 4 n, zero padded to 112 x 112)
-    const double* elin; const double* eplin;    // 2 e, -2 ep (112 entries, zero padded)
     const double* dx0T;
     double e0, ep0, normE, norme, normEp, normep, rd2_0;
 };

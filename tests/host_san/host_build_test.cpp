@@ -210,6 +210,45 @@ int main(int argc, char** argv) {
             for (int r = 0; r < nc; ++r) { ld srow = 0.0L; for (int j = 0; j < H; ++j) srow += (ld)Fc[(size_t)j * nc + r] * d[(r + j) % nc]; circ += d[r] * srow; }
             if (fabsl(full - circ) > 1e-12L * scale) { fprintf(stderr, "d'Ed %.17Lg vs circulant %.17Lg\n", full, circ); return fail("first-move form: circulant half does not reproduce d'E d"); }
         }
+        // ---- the same form as matrix-core images over many realisations (fmpc_host_build_loop_images; fmpc_kernel_loopu0.hip), in
+        // both column orders: decoded exactly as the kernels use them -- k-steps 4 t .. ks - 1 of row tile t for the forms (the
+        // block-upper triangle), all k-steps for the first moves -- they must reproduce u0c + K0 d, d'E d + 2 e'd, d'Ep d - 2 ep'd
+        for (int fused = 0; fused < 2; ++fused) {
+            const int ks = 28, kc = 4 * ks, cst = fused ? kc - 1 : nc;
+            FmpcLoopImages LI;
+            fmpc_host_build_loop_images(Fo, n, m, ks, fused != 0, bt.data(), LI);
+            const int mt = (m + 15) / 16;
+            if (LI.imgU.size() != (size_t)mt * ks * 64 || LI.imgE.size() != (size_t)(kc / 16) * ks * 64 || LI.imgEp.size() != LI.imgE.size()) return fail("loop images: sizes");
+            if (fused ? LI.imgB.size() != (size_t)2 * ((m + 3) / 4) * 64 : !LI.imgB.empty()) return fail("loop images: B images");
+            std::vector<ld> d(nc), dd(kc, 0.0L);
+            for (auto& v : d) v = N01(rng);
+            for (int c = 0; c < nc; ++c) dd[fused ? ks * (c / n) + c % n : c] = d[c];
+            dd[cst] = 1.0L;
+            auto at = [&](const std::vector<double>& img, int row, int col) { return (ld)img[((size_t)(row / 16) * ks + col / 4) * 64 + (col % 4) * 16 + row % 16]; };
+            for (int j = 0; j < m; ++j) {
+                ld want = Fo.u0c[j], got = 0.0L, sc = fabsl(want);
+                for (int c = 0; c < nc; ++c) { want += (ld)Fo.K0t[(size_t)c * m + j] * d[c]; sc += fabsl((ld)Fo.K0t[(size_t)c * m + j] * d[c]); }
+                for (int c = 0; c < kc; ++c) got += at(LI.imgU, j, c) * dd[c];
+                if (fabsl(want - got) > 1e-13L * (sc + 1e-300L)) return fail("loop images: first moves");
+            }
+            for (int pass = 0; pass < 2; ++pass) {
+                const std::vector<double>& F = pass ? Fo.Ep : Fo.E; const std::vector<double>& lin = pass ? Fo.ep : Fo.e;
+                const std::vector<double>& img = pass ? LI.imgEp : LI.imgE;
+                ld want = 0.0L, got = 0.0L, sc = 0.0L;
+                for (int r = 0; r < nc; ++r) {
+                    for (int c = 0; c < nc; ++c) { const ld t = d[r] * (ld)F[(size_t)r * nc + c] * d[c]; want += t; sc += fabsl(t); }
+                    const ld t = (pass ? -2.0L : 2.0L) * (ld)lin[r] * d[r]; want += t; sc += fabsl(t);
+                }
+                for (int row = 0; row < kc; ++row)
+                    for (int c = 16 * (row / 16); c < kc; ++c) got += dd[row] * at(img, row, c) * dd[c];      // k-steps 4 t .. ks - 1 only
+                if (fabsl(want - got) > 1e-12L * sc) { fprintf(stderr, "form %d fused %d: %.17Lg vs %.17Lg\n", pass, fused, want, got); return fail("loop images: triangular form"); }
+                for (int c = 0; c < kc; ++c) if (at(img, cst, c) != 0.0L) return fail("loop images: the row of the constant must be zero");
+            }
+            if (fused)
+                for (int q = 0; q < n; ++q)
+                    for (int c = 0; c < m; ++c)
+                        if (LI.imgB[((size_t)(q / 16) * ((m + 3) / 4) + c / 4) * 64 + (c % 4) * 16 + q % 16] != bt[(size_t)c * n + q]) return fail("loop images: B");
+        }
     }
 
     // ---- estimator builders: G = pinv(A'A) A' (full rank: G A = I; a repeated column: the minimum-norm solution treats both alike),
