@@ -330,6 +330,22 @@ int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled);
 int fmpc_last_dual_form(fmpc_handle h);
 
+/*
+ * The MPC part of one timestep of the reference's loop WITH its estimator (README.md:482-497, 548-556, 589), in one call:
+ *     x0 = ad_est[k], x0_pre = ad_est[k-1]        from the estimator (fmpc_est_apply_device), INPUTS here
+ *     w  = b_ref = -M1 B u1 - M2 B u2             (README.md:490-497; u1 = u[k-1], u2 = u[k-2], NULL = zeros), written to w
+ *     [z, nu] = fastMPC step from the cold start, u0_out = U(1:nu)
+ * i.e. fmpc_loop_step_device without the coefficient-space plant x0 = a[k] + B u[k-1].  With first moves only (z_out = nu_out =
+ * NULL) and a Newton budget of 1 it takes the same forms: one launch + the exact-path launch for the realisations whose
+ * step-length decision is not clear-cut.  x0_pre must not be NULL for a VAR(2) model (zeros at the first timestep).
+ * Device pointers as in fmpc_loop_step_device.  tests/test_gpu_estimator.py.
+ */
+int fmpc_ao_step_device(fmpc_handle h, int batch, const double* x0, const double* x0_pre,
+                        const double* u1, const double* u2, double* w,
+                        const double* nu0, int n_newton, double k,
+                        double* z_out, double* nu_out, int* status, int* iters, double* step,
+                        double* u0_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------------
  * Phase-diversity estimator: replaces the "% Estimator" block of the reference's simulation loop (README.md:456-480)
  *

@@ -58,6 +58,7 @@ SIGNATURES = {
     "fmpc_set_small_batch_kernel": (C.c_int, [_vp, C.c_int]),
     "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
     "fmpc_loop_step_device": (C.c_int, [_vp, C.c_int] + [_vp] * 8 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
+    "fmpc_ao_step_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_loop_run_device": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.c_int, C.c_int, C.c_double] + [_vp] * 7 + [_vp]),
     "fmpc_solve_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),

@@ -137,11 +137,12 @@ class AOLoop:
     b_ref from the last two first moves (`fmpc_loop_inputs_device`), the fastMPC solve, u[k] = U(1:nu).
     Z: (n, len, len) mode maps indexed [j, row, column] (piston removed).  Screens are handed over indexed [b, row, column]."""
 
-    def __init__(self, handle, estimator, Z, batch, n_newton=1, k=1e-2):
+    def __init__(self, handle, estimator, Z, batch, n_newton=1, k=1e-2, one_call=True):
         import ctypes as C
         import numpy as np
         import torch
         self.h, self.est, self.batch, self.n_newton, self.k = handle, estimator, int(batch), int(n_newton), float(k)
+        self.one_call = bool(one_call)      # b_ref + fastMPC step as ONE C call (fmpc_ao_step_device); False: loop inputs and solve as two
         dev = torch.device("cuda", handle.device)
         f64 = dict(dtype=torch.float64, device=dev)
         n, m, T = handle.n, handle.m, handle.T
@@ -176,9 +177,16 @@ class AOLoop:
         if s == 0:
             self.x0_pre.zero_()
         self.est.apply_device(self.scrn, noise, colmajor=True, out=self.x0)
-        # b_ref = -M1 B u[k-1] - M2 B u[k-2] (README.md:490-497): the loop-input kernel's w; its x0 / x0_pre go to scratch
-        self.h.loop_inputs_device(self._zero_a, None, u1 if s >= 1 else None, u2 if s >= 2 else None, self._scr_x, self._scr_xp, self.w)
-        self.h.solve_device(self.x0, self.x0_pre, self.w, None, None, self.n_newton, self.k, z_out=None, status=self.status, iters=self.iters,
-                            u0_out=u_new, want_z=False)
+        # b_ref = -M1 B u[k-1] - M2 B u[k-2] (README.md:490-497) and the fastMPC step on (x0, x0_pre, b_ref) in one call
+        if self.one_call:
+            rc = self.h._lib.fmpc_ao_step_device(self.h._h, self.batch, vp(self.x0), vp(self.x0_pre), vp(u1) if s >= 1 else None, vp(u2) if s >= 2 else None,
+                                                 vp(self.w), None, self.n_newton, self.k, None, None, vp(self.status), vp(self.iters), None, vp(u_new), stream)
+            if rc != 0:
+                from ._lib import FastMPCError
+                raise FastMPCError(rc, "fmpc_ao_step_device")
+        else:
+            self.h.loop_inputs_device(self._zero_a, None, u1 if s >= 1 else None, u2 if s >= 2 else None, self._scr_x, self._scr_xp, self.w)
+            self.h.solve_device(self.x0, self.x0_pre, self.w, None, None, self.n_newton, self.k, z_out=None, status=self.status, iters=self.iters,
+                                u0_out=u_new, want_z=False)
         self.steps_done = s + 1
         return u_new, self.x0

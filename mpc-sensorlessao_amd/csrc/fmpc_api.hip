@@ -83,6 +83,7 @@ struct fmpc_handle_s {
     int* fm_walk_i; size_t fm_walk_cap;   // start / stop step per realisation of a walk
     // affine form of the cold-start step without w (fmpc_kernel_affine.hip), built with the first-move form
     FaParams fa_P; int fa_valid, fa_disabled; int* fa_need; size_t fa_need_cap;
+    double* ao_scr; size_t ao_cap;       // fmpc_ao_step_device: a zero a[k] and scratch x0 / x0_pre for the loop-input kernel (3 batch n)
     FlParams fs_P; FlStepIn fs_I; int fs_valid, fs_disabled;   // the fused step (fmpc_loop_step27): images in its column order, B's images
     FlParams fl_P; int fl_valid, fl_disabled;       // first-move form as a product: closed-loop steps of > 64 realisations (fmpc_kernel_loopu0.hip)
     FwModel wave;
@@ -305,7 +306,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
     h->hm_J4_valid = 0; h->hm_J4_k = 0.0; h->fm_pool = nullptr; h->fm_valid = 0; h->fm_disabled = 0; h->fm_k = 0.0; h->fm_need = nullptr; h->fm_need_cap = 0; h->fm_compact = nullptr; h->fm_forms = nullptr; h->fm_walk_i = nullptr; h->fm_walk_cap = 0;
-    h->tl_last_nw = 0;
+    h->tl_last_nw = 0; h->ao_scr = nullptr; h->ao_cap = 0;
     h->fa_valid = 0; h->fa_need = nullptr; h->fa_need_cap = 0; h->fl_valid = 0; h->fs_valid = 0;
     { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* na = getenv("FMPC_NO_LOOP_U0"); h->fl_disabled = (na && na[0] == '1') ? 1 : 0; }
@@ -566,6 +567,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->fm_pool) (void)hipFree(h->fm_pool);
     if (h->fm_need) (void)hipFree(h->fm_need);
     if (h->fa_need) (void)hipFree(h->fa_need);
+    if (h->ao_scr) (void)hipFree(h->ao_scr);
     if (h->fm_compact) (void)hipFree(h->fm_compact);
     if (h->fm_walk_i) (void)hipFree(h->fm_walk_i);
     if (h->lp_v) (void)hipFree(h->lp_v);
@@ -1411,12 +1413,14 @@ static int fmpc_first_move_ensure(fmpc_handle h, int batch, double k, hipStream_
 
 static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
                                 double* x0, double* x0_pre, double* w, const double* nu0, double k,
-                                int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+                                int* status, int* iters, double* step, double* u0_out, hipStream_t stream, int given = 0) {
     size_t stride = 0;
     int rc = fmpc_first_move_ensure(h, batch, k, stream, &stride);
     if (rc != FMPC_OK) return rc;
     FmParams P = h->fm_P;
     P.step_ld = fmpc_step_ld(1);
+    P.x0_given = given;                            // (a_k IS x0, x0_last IS x0_pre: nothing is written to x0 / x0_pre)
+    const double* xs = given ? a_k : x0; const double* xps = given ? x0_last : x0_pre;
     P.a_k = a_k; P.x0_last = x0_last; P.u1 = u1; P.u2 = u2; P.nu0 = nu0;
     P.x0 = x0; P.x0_pre = x0_pre; P.w = w; P.u0out = u0_out; P.status = status; P.iters = iters; P.step = step; P.need = h->fm_need;
     P.forms = h->fm_forms;
@@ -1425,7 +1429,7 @@ static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, con
     // the exact path for flagged realisations (cold start with the shared factor), first moves from its own z
     const int wpw = fmpc_wave_waves_per_wg();
     const int grid = (batch + wpw - 1) / wpw;
-    if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
+    if (fmpc_launch_wave(h->dev, h->wave, batch, grid, xs, xps, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
                          fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
                          nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;
     h->last_path = FMPC_PATH_PANEL; h->inv_last = 1;
@@ -1437,7 +1441,7 @@ static int fmpc_first_move_step(fmpc_handle h, int batch, const double* a_k, con
 #define FMPC_LOOP_U0_MAX_BATCH 65536
 static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const double* x0_last, const double* u1, const double* u2,
                              double* x0, double* x0_pre, double* w, const double* nu0, double k,
-                             int* status, int* iters, double* step, double* u0_out, hipStream_t stream) {
+                             int* status, int* iters, double* step, double* u0_out, hipStream_t stream, int given = 0) {
     if (h->fl_disabled) return FMPC_E_UNSUPPORTED;
     size_t stride = 0;
     int rc = fmpc_first_move_ensure(h, batch, k, stream, &stride, FMPC_LOOP_U0_MAX_BATCH);
@@ -1448,20 +1452,23 @@ static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const 
     if (grid > 64) grid = 64;                      // flagged realisations are few: the list is walked by a small grid (as after the affine kernel)
     // ONE launch for the loop inputs, the first moves and the decision -- when the other workgroups may read x0_last while
     // x0 and x0_pre are written, i.e. when the caller does not update x0 in place
-    if (h->fs_valid && h->loop_M1 && (x0_last == nullptr || (x0_last != x0 && x0_last != x0_pre))) {
+    if (h->fs_valid && h->loop_M1 && (given || x0_last == nullptr || (x0_last != x0 && x0_last != x0_pre))) {
         FlParams L = h->fs_P;
         FlStepIn I = h->fs_I;
+        I.x0_given = given;
+        const double* xs = given ? a_k : x0; const double* xps = given ? x0_last : x0_pre;
         L.batch = batch; L.step_ld = fmpc_step_ld(1);
         L.nu0 = nu0; L.u0out = u0_out; L.status = status; L.iters = iters; L.step = step; L.need = h->fm_need; L.handed = h->pn_cnt;
         L.x0w = x0; L.x0pw = x0_pre;
         I.a = a_k; I.x0_last = x0_last; I.u1 = u1; I.u2 = u2; I.w = w;
         if (fmpc_launch_loop_step27(L, I, stream) != hipSuccess) return FMPC_E_HIP;
-        if (fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
+        if (fmpc_launch_wave(h->dev, h->wave, batch, grid, xs, xps, w, nullptr, nu0, 1, k, h->zs, nullptr, status, iters, step,
                              fmpc_step_ld(1), h->ws, stride, h->wave_lds, stream, 1, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
                              nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fm_need) != hipSuccess) return FMPC_E_HIP;
         h->last_path = FMPC_PATH_PANEL; h->inv_last = 4;
         return FMPC_OK;
     }
+    if (given) return FMPC_E_UNSUPPORTED;          // (the caller takes the general route)
     if ((size_t)batch > h->lp_cap) {
         (void)hipDeviceSynchronize();
         if (h->lp_v) (void)hipFree(h->lp_v);
@@ -1485,12 +1492,15 @@ static int fmpc_loop_u0_step(fmpc_handle h, int batch, const double* a_k, const 
 
 // One closed-loop step: fmpc_loop_inputs_device + fmpc_solve_u0_device under one lock, with the knowledge that
 // w = -M1 (B u1) - M2 (B u2) has only 2 n degrees of freedom.
-extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
-                                     const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
-                                     const double* nu0, int n_newton, double k,
-                                     double* z_out, double* nu_out, int* status, int* iters, double* step,
-                                     double* u0_out, void* stream) {
-    if (!h || !a_k || !x0 || !x0_pre || !w || !u0_out) return FMPC_E_NULL;       // z_out may be NULL: first moves only
+// given = 1 (fmpc_ao_step_device): a_k IS x0 and x0_last IS x0_pre -- the loop with its estimator, where the solver's x0 is the
+// estimated residual and not a[k] + B u[k-1] (README.md:482-497); x0 / x0_pre are not written (may be NULL).
+static int fmpc_loop_step_impl(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                               const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
+                               const double* nu0, int n_newton, double k,
+                               double* z_out, double* nu_out, int* status, int* iters, double* step,
+                               double* u0_out, void* stream, int given) {
+    if (!h || !a_k || (!given && (!x0 || !x0_pre)) || !w || !u0_out) return FMPC_E_NULL;       // z_out may be NULL: first moves only
+    if (given && !x0_last && h->var_order == 2) return FMPC_E_NULL;             // (x0_pre of a VAR(2) model: zeros at the first step, not NULL)
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
@@ -1500,9 +1510,9 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
     const bool lr = h->inv_enabled && h->inv_jimg2 != nullptr && h->n == FP_N;
     if (lr && !z_out && !nu_out && n_newton == 1) {
         // first moves only, a few realisations: one launch instead of four (falls through when the form does not apply)
-        rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream);
+        rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
         if (rc == FMPC_E_UNSUPPORTED && batch > FMPC_FIRST_MOVE_MAX_BATCH)
-            rc = fmpc_loop_u0_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream);
+            rc = fmpc_loop_u0_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
         if (rc != FMPC_E_UNSUPPORTED) { fmpc_guard_end(h, (hipStream_t)stream); return rc; }
         rc = FMPC_OK;
     }
@@ -1513,16 +1523,47 @@ extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k
         if (hipMalloc((void**)&h->lp_v, (size_t)batch * 2 * h->n * sizeof(double)) != hipSuccess) { fmpc_guard_end(h, (hipStream_t)stream); return FMPC_E_ALLOC; }
         h->lp_cap = batch;
     }
-    if (fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_k, x0_last, u1, u2,
-                                x0, x0_pre, w, (hipStream_t)stream, lr ? h->lp_v : nullptr) != hipSuccess) rc = FMPC_E_HIP;
+    const double* a_in = a_k; const double* xl_in = x0_last; double* x0_o = x0; double* x0p_o = x0_pre;
+    if (given) {
+        // the loop-input kernel only has to produce w: a = 0, its x0 / x0_pre go to scratch (3 batch n doubles of the handle)
+        if ((size_t)batch > h->ao_cap) {
+            (void)hipDeviceSynchronize();
+            if (h->ao_scr) (void)hipFree(h->ao_scr);
+            h->ao_scr = nullptr; h->ao_cap = 0;
+            if (hipMalloc((void**)&h->ao_scr, (size_t)3 * batch * h->n * sizeof(double)) != hipSuccess) { fmpc_guard_end(h, (hipStream_t)stream); return FMPC_E_ALLOC; }
+            if (hipMemsetAsync(h->ao_scr, 0, (size_t)batch * h->n * sizeof(double), (hipStream_t)stream) != hipSuccess) { fmpc_guard_end(h, (hipStream_t)stream); return FMPC_E_HIP; }
+            h->ao_cap = batch;
+        }
+        a_in = h->ao_scr; xl_in = nullptr; x0_o = h->ao_scr + (size_t)h->ao_cap * h->n; x0p_o = h->ao_scr + (size_t)2 * h->ao_cap * h->n;
+    }
+    if (fmpc_launch_loop_inputs(h->n, h->m, h->T, batch, h->dev.Bt, h->loop_M1, h->loop_M2, a_in, xl_in, u1, u2,
+                                x0_o, x0p_o, w, (hipStream_t)stream, lr ? h->lp_v : nullptr) != hipSuccess) rc = FMPC_E_HIP;
     if (rc == FMPC_OK) {
         h->lp_hint = lr ? 1 : 0;
-        rc = fmpc_solve_device_inner(h, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+        rc = fmpc_solve_device_inner(h, batch, given ? a_k : x0, given ? x0_last : x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                      u0_out, stream);
         h->lp_hint = 0;
     }
     fmpc_guard_end(h, (hipStream_t)stream);
     return rc;
+}
+
+extern "C" int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const double* x0_last,
+                                     const double* u1, const double* u2, double* x0, double* x0_pre, double* w,
+                                     const double* nu0, int n_newton, double k,
+                                     double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                     double* u0_out, void* stream) {
+    return fmpc_loop_step_impl(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, n_newton, k, z_out, nu_out, status, iters, step, u0_out, stream, 0);
+}
+
+// The MPC part of one timestep of the loop WITH its estimator (README.md:482-497,548-556,589): x0 = ad_est[k], x0_pre = ad_est[k-1]
+// come from the estimator, b_ref = -M1 B u[k-1] - M2 B u[k-2] from the moves applied.  See include/fastmpc.h.
+extern "C" int fmpc_ao_step_device(fmpc_handle h, int batch, const double* x0, const double* x0_pre,
+                                   const double* u1, const double* u2, double* w,
+                                   const double* nu0, int n_newton, double k,
+                                   double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                   double* u0_out, void* stream) {
+    return fmpc_loop_step_impl(h, batch, x0, x0_pre, u1, u2, nullptr, nullptr, w, nu0, n_newton, k, z_out, nu_out, status, iters, step, u0_out, stream, 1);
 }
 
 // A recorded stretch of the loop in ONE host call: steps consecutive fmpc_loop_step_device calls with the first moves fed back

@@ -5,6 +5,7 @@
 
 struct FmParams {
     int n, m, T, nb, var2, has_xf, step_ld;
+    int x0_given;                       // 1: a_k IS x0 and x0_last IS x0_pre (the loop with its estimator: x0 = ad_est, README.md:482-488); x0 / x0_pre are not written
     const double* a_k; const double* x0_last; const double* u1; const double* u2; const double* nu0;   // per realisation (u1, u2, x0_last, nu0 nullable)
     double* x0; double* x0_pre; double* w; double* u0out;
     int* status; int* iters; double* step;

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     }
     __syncthreads();
     if (tid < n) {
-        const double xv = sx[0][tid] + sd[2 * n + tid], xp = P.var2 ? sx[1][tid] : 0.0;
+        const double xv = P.x0_given ? sx[0][tid] : sx[0][tid] + sd[2 * n + tid], xp = P.var2 ? sx[1][tid] : 0.0;
         sd[tid] = xv; sd[n + tid] = xp; sd[nc + tid] = xv; sd[nc + n + tid] = xp;
     }
     __syncthreads();
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(FM_THREADS) fmpc_first_move(FmParams P) {
     __syncthreads();
     // first moves (every realisation: a problem that is handed over gets its u0 overwritten by the exact path)
     if (tid < m) P.u0out[(size_t)p * m + tid] = u0c + ((spart[tid] + spart[m + tid]) + (spart[2 * m + tid] + spart[3 * m + tid]));
-    if (tid < n) { P.x0[(size_t)p * n + tid] = sd[tid]; P.x0_pre[(size_t)p * n + tid] = sx[1][tid]; }
+    if (tid < n && !P.x0_given) { P.x0[(size_t)p * n + tid] = sd[tid]; P.x0_pre[(size_t)p * n + tid] = sx[1][tid]; }
     FM_TICK(4);
     if (p == 0 && tid == 0 && P.handed) *P.handed = 0;
     if (wv == 0) {

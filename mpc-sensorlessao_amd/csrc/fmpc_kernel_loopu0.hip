@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(FS_THREADS, 2) fmpc_loop_step27(FlParams P, Fl
 #endif
     if (role == 0) {
         // ---- x0 = a + B u1, x0_pre = x0_last (one wavefront of the first slice), then the slice of w
-        if (blockIdx.y == 0 && wv == 0 && li < np) {
+        if (blockIdx.y == 0 && wv == 0 && li < np && !I.x0_given) {
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
                 const int q = 4 * ks + lk;
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(FS_THREADS, 2) fmpc_loop_step27(FlParams P, Fl
     double D[FL_KS];
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks) {
-        D[ks] = xa[ks] + bu[0][ks >> 2][ks & 3];
+        D[ks] = I.x0_given ? xa[ks] : xa[ks] + bu[0][ks >> 2][ks & 3];
         D[7 + ks] = P.var2 ? xl[ks] : 0.0;
         D[14 + ks] = bu[0][ks >> 2][ks & 3];
         D[21 + ks] = bu[1][ks >> 2][ks & 3];

@@ -23,6 +23,7 @@ hipError_t fmpc_launch_loop_u0(const FlParams& P, hipStream_t stream);
 // then the images in the fused column order (blocks of 28: 27 entries + a pad, the constant in column 111).
 struct FlStepIn {
     int rs, rows;                       // w: rs slices of `rows` <= 64 rows
+    int x0_given;                       // 1: a IS x0, x0_last IS x0_pre (the loop with its estimator); x0 / x0_pre are not written
     const double* imgB;                 // [2][ceil(m / 4)][64]: operand images of B (n x m)
     const double* M1; const double* M2; // T n x n row-major
     const double* a; const double* x0_last; const double* u1; const double* u2;

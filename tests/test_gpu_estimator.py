@@ -113,15 +113,18 @@ def test_phase_residual_kernel_against_numpy(pkg, gpu):
     h.close()
 
 
-def test_simulation_loop_with_the_estimator_against_the_numpy_loop(pkg, gpu):
+@pytest.mark.parametrize("one_call,R", [(True, 2), (False, 2), (True, 70)])
+def test_simulation_loop_with_the_estimator_against_the_numpy_loop(pkg, gpu, one_call, R):
     """README.md:444-626 for two realisations over six steps at len = 128: residual screen, estimator, fastMPC, correction.
     Turbulence screens in and beyond the span of the modes; the deformable mirror's B scaled so that the loop's correction
     stays in the estimator's linear range.  Against oracle/ao_loop_ref.py: 1e-7 on the estimates and the first moves after
-    six fed-back steps."""
+    six fed-back steps.  one_call: b_ref and the fastMPC step through fmpc_ao_step_device (first-move form: one launch for up to
+    64 realisations, the product form beyond), otherwise loop inputs + solve as two calls; 70 realisations: three against the
+    numpy loop."""
     import torch
     from oracle.ao_loop_ref import ao_loop
     from tests.util import handle_from_model
-    length, steps, R = 128, 6, 2
+    length, steps = 128, 6
     op = pkg.synthetic.estimator_optics(length)
     md = pkg.synthetic.make_model(27, 144, 10)
     rng = np.random.default_rng(4)
@@ -129,7 +132,7 @@ def test_simulation_loop_with_the_estimator_against_the_numpy_loop(pkg, gpu):
     phase = np.tensordot(a, op["Z"][1:], axes=1) + 0.01 * rng.standard_normal((steps, R, length, length))
     h = handle_from_model(pkg, md)
     est = _estimator(pkg, op)
-    loop = pkg.AOLoop(h, est, op["Z"][1:], R, n_newton=1, k=1e-2)
+    loop = pkg.AOLoop(h, est, op["Z"][1:], R, n_newton=1, k=1e-2, one_call=one_call)
     dev = torch.device("cuda:0")
     U, X = [], []
     for s_ in range(steps):
@@ -137,11 +140,55 @@ def test_simulation_loop_with_the_estimator_against_the_numpy_loop(pkg, gpu):
         U.append(u.clone()); X.append(x0.clone())
     torch.cuda.synchronize()
     assert int(loop.status.abs().sum()) == 0
+    if one_call:
+        assert h.last_dual_form() == (1 if R <= 64 else 4) and h.last_dispatch()[0] == pkg.FMPC_PATH_PANEL
     U = torch.stack(U).cpu().numpy(); X = torch.stack(X).cpu().numpy()
-    for r in range(R):
+    for r in (range(R) if R <= 4 else (0, R // 2, R - 1)):
         ref = ao_loop(md, op, phase[:, r], 1, 1e-2)
         assert rel_err(X[:, r], ref["ad_est"]) <= 1e-7, rel_err(X[:, r], ref["ad_est"])
         assert rel_err(U[:, r], ref["u0"]) <= 1e-7, rel_err(U[:, r], ref["u0"])
     # the loop does what it is for: the residual it estimates is smaller than the uncorrected aberration
     assert np.linalg.norm(X[-1]) < np.linalg.norm(a[-1])
     est.close(); h.close()
+
+
+@pytest.mark.parametrize("R,n_newton,keep_z", [(5, 1, False), (90, 1, False), (12, 1, True), (7, 3, False)])
+def test_ao_step_entry_against_loop_inputs_plus_solve(pkg, gpu, R, n_newton, keep_z):
+    """fmpc_ao_step_device(x0, x0_pre, u1, u2) == fmpc_loop_inputs_device (for w = b_ref, with a = 0) + fmpc_solve_u0_device on
+    (x0, x0_pre, w): w within 1e-12, first moves and z within 1e-11 (the first-move forms round differently), status and iteration
+    counts identical; also with z requested and with a Newton budget (the general route of the entry)."""
+    import ctypes as C
+    import torch
+    from tests.util import handle_from_model
+    md = pkg.synthetic.make_model(27, 144, 30)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh)).to(dev)
+    x0, x0p, u1, u2 = 0.3 * f(R, 27), 0.3 * f(R, 27), 0.1 * f(R, 144), 0.1 * f(R, 144)
+    h = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    w = torch.zeros((R, 810), dtype=torch.float64, device=dev); u0 = torch.zeros((R, 144), dtype=torch.float64, device=dev)
+    z = torch.zeros((R, h.nz), dtype=torch.float64, device=dev) if keep_z else None
+    st = torch.full((R,), -9, dtype=torch.int32, device=dev); it = torch.full((R,), -9, dtype=torch.int32, device=dev)
+    x0c, x0pc = x0.clone(), x0p.clone()
+    rc = h._lib.fmpc_ao_step_device(h._h, R, vp(x0), vp(x0p), vp(u1), vp(u2), vp(w), None, n_newton, 1e-2, vp(z), None, vp(st), vp(it), None, vp(u0),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(x0, x0c) and torch.equal(x0p, x0pc)                  # inputs are inputs
+    if n_newton == 1 and not keep_z:
+        assert h.last_dual_form() == (1 if R <= 64 else 4)
+    # the two-call route on a second handle
+    za = torch.zeros((R, 27), dtype=torch.float64, device=dev); sx = torch.zeros_like(za); sxp = torch.zeros_like(za)
+    w2 = torch.zeros_like(w); u02 = torch.zeros_like(u0); z2 = torch.zeros((R, h.nz), dtype=torch.float64, device=dev)
+    st2 = torch.zeros_like(st); it2 = torch.zeros_like(it)
+    h2.loop_inputs_device(za, None, u1, u2, sx, sxp, w2)
+    h2.solve_device(x0, x0p, w2, None, None, n_newton, 1e-2, z_out=z2, status=st2, iters=it2, u0_out=u02)
+    torch.cuda.synchronize()
+    assert rel_err(w.cpu().numpy(), w2.cpu().numpy()) <= 1e-12                            # (the first-move kernel sums b_ref in its own order)
+    assert torch.equal(st, st2) and torch.equal(it, it2) and int(st.abs().sum()) == 0
+    assert rel_err(u0.cpu().numpy(), u02.cpu().numpy()) <= 1e-11
+    if keep_z:
+        assert rel_err(z.cpu().numpy(), z2.cpu().numpy()) <= 1e-11
+    # x0_pre = NULL is refused for a VAR(2) model
+    assert h._lib.fmpc_ao_step_device(h._h, R, vp(x0), None, vp(u1), vp(u2), vp(w), None, 1, 1e-2, None, None, vp(st), vp(it), None, vp(u0), None) == pkg._lib.FMPC_E_NULL
+    h.close(); h2.close()
