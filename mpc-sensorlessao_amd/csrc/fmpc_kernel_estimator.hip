@@ -246,19 +246,45 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
 #define FE_PB 8
 __global__ void __launch_bounds__(256) fmpc_phase_residual(int batch, size_t npx, int n, int m, const double* Bt, const double* phase,
                                                            const double* u, const double* Z, double* out) {
+    __shared__ double sp[8][FE_PB][32];                       // partial sums of ad_cor = B u: [eighth of the actuators][screen][mode]
     __shared__ double sc[FE_PB][32];                          // ad_cor of the group's screens (n <= 32)
     const int tid = threadIdx.x;
     const size_t px = (size_t)blockIdx.x * 256 + tid;
     for (int b0 = 0; b0 < batch; b0 += FE_PB) {
         __syncthreads();
-        if (tid < FE_PB * 32) {
-            const int bb = tid >> 5, j = tid & 31, b = b0 + bb;
-            double a = 0.0;
-            if (u && b < batch && j < n) {
-                const double* ub = u + (size_t)b * m;
-                for (int cidx = 0; cidx < m; ++cidx) a = fma(Bt[(size_t)cidx * n + j], ub[cidx], a);      // Bt[c*n + r] = B[r][c]
+        {
+            // thread (mode j, eighth `part` of the actuators): a chain of m / 8 products per screen instead of m, the rows of B'
+            // loaded once for the group's screens (every workgroup forms B u itself: a chain of 144 dependent loads and products
+            // in front of the pass over the maps was most of this kernel's time for one screen)
+            const int j = tid & 31, part = tid >> 5, per = (m + 7) / 8, c0 = part * per, c1 = c0 + per < m ? c0 + per : m;
+            double a[FE_PB];
+#pragma unroll
+            for (int bb = 0; bb < FE_PB; ++bb) a[bb] = 0.0;
+            if (u && j < n) {
+                for (int cb = c0; cb < c1; cb += 6) {
+                    double bt[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) bt[q] = cb + q < c1 ? Bt[(size_t)(cb + q) * n + j] : 0.0;      // Bt[c*n + r] = B[r][c]
+#pragma unroll
+                    for (int bb = 0; bb < FE_PB; ++bb) {
+                        if (b0 + bb < batch) {
+                            const double* ub = u + (size_t)(b0 + bb) * m;
+#pragma unroll
+                            for (int q = 0; q < 6; ++q) a[bb] = fma(bt[q], cb + q < c1 ? ub[cb + q] : 0.0, a[bb]);
+                        }
+                    }
+                }
             }
-            sc[bb][j] = a;
+#pragma unroll
+            for (int bb = 0; bb < FE_PB; ++bb) sp[part][bb][j] = a[bb];
+        }
+        __syncthreads();
+        {
+            const int bb = tid >> 5, j = tid & 31;
+            double a = 0.0;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) a += sp[part][bb][j];
+            sc[bb][j] = j < n ? a : 0.0;
         }
         __syncthreads();
         if (px < npx) {
@@ -266,10 +292,17 @@ __global__ void __launch_bounds__(256) fmpc_phase_residual(int batch, size_t npx
 #pragma unroll
             for (int bb = 0; bb < FE_PB; ++bb) acc[bb] = b0 + bb < batch ? phase[(size_t)(b0 + bb) * npx + px] : 0.0;
             if (u) {
-                for (int j = 0; j < n; ++j) {
-                    const double z = Z[(size_t)j * npx + px];
+                for (int j0 = 0; j0 < n; j0 += 9) {           // the maps nine at a time: their loads in flight together
+                    double z[9];
 #pragma unroll
-                    for (int bb = 0; bb < FE_PB; ++bb) acc[bb] = fma(sc[bb][j], z, acc[bb]);
+                    for (int q = 0; q < 9; ++q) z[q] = Z[(size_t)(j0 + q < n ? j0 + q : 0) * npx + px];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const int jc = j0 + q < 32 ? j0 + q : 31;      // (sc is zero from n on)
+                        const double zz = j0 + q < n ? z[q] : 0.0;
+#pragma unroll
+                        for (int bb = 0; bb < FE_PB; ++bb) acc[bb] = fma(sc[bb][jc], zz, acc[bb]);
+                    }
                 }
             }
 #pragma unroll
