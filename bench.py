@@ -539,7 +539,8 @@ def _main(real_out):
             op_ = pkg.synthetic.estimator_optics(512)
             est_ = pkg.PhaseDiversityEstimator(op_["pupil"], op_["W"], op_["zd_list"], op_["dx"], op_["range_min"] + 1, op_["range_max"] + 1,
                                                op_["A_s"], op_["b_s"])
-            fl_est = 3 * (8 * 512 * 512 * 32 + 8 * 32 * 512 * 32)        # executed: 8 real flops per complex multiply-add, both products, 32 of 31 columns
+            fl_est = 3 * (6 * 512 * 512 * 32 + 8 * 32 * 512 * 32)        # executed: 6 real flops per complex multiply-add in the first product (three real
+                                                                         # products, Gauss), 8 in the second, 32 of 31 columns
             es = {"what": "phase-diversity estimator at the reference's size (len 512, 31 x 31 window, three diversities; synthetic optics: "
                           "Zs.mat / model_approx.mat are not shipped): PSF windows as partial DFTs on the fp64 matrix cores + ad_est = G (Y_M - b_s)",
                   "executed_flops_per_screen": fl_est}

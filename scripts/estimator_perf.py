@@ -9,7 +9,7 @@ op = pkg.synthetic.estimator_optics(512)
 est = pkg.PhaseDiversityEstimator(op["pupil"], op["W"], op["zd_list"], op["dx"], op["range_min"] + 1, op["range_max"] + 1, op["A_s"], op["b_s"])
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-flops = 3 * (8 * 512 * 512 * 32 + 8 * 32 * 512 * 32)          # 8 real flops per complex multiply-add: both products, per diversity, padded window
+flops = 3 * (6 * 512 * 512 * 32 + 8 * 32 * 512 * 32)          # executed: three real products per complex one in the first (2 flops each), four in the second, per diversity, padded window
 for B in [int(a) for a in sys.argv[1:]] or [1, 8, 64, 256]:
     scr = torch.from_numpy(0.3 * rng.standard_normal((B, 512, 512))).to(dev)
     for _ in range(3):
