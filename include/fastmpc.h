@@ -364,7 +364,8 @@ int fmpc_ao_step_device(fmpc_handle h, int batch, const double* x0, const double
  *                   range_min + 1 <= 32.   ndiv <= 3 diversities;  D_re, D_im: ndiv arrays len x len (column-major, MATLAB
  *                   order) = real / imaginary part of pupil.*exp(1i*zd_list(k)*squeeze(Zs(idx2,:,:))).   scale = dx^4*AU.
  *                   A_s: p x nx column-major, b_s: p, p = ndiv d^2 (model_approx.mat of the reference, piston removed).
- * fmpc_est_apply[_device]   scrn: batch arrays len x len column-major [rad]; noise: batch x p or NULL (Y_M_noise);
+ * fmpc_est_apply[_device]   scrn: batch arrays len x len column-major [rad], |scrn| < 1e6 (a pixel beyond that, or a
+ *                   non-finite one, makes that screen's outputs NaN: the kernel reduces the phase by pi/2 itself); noise: batch x p or NULL (Y_M_noise);
  *                   ad_est: batch x nx;  Y_out: batch x p or NULL (Y_M, for Y_M_acc of the reference).
  * fmpc_est_dims     any pointer may be NULL; rank = numerical rank of A_s'A_s found when G was built.
  */

@@ -32,6 +32,30 @@ typedef double d4e __attribute__((ext_vector_type(4)));
 #define FE_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define FE_TSTRIDE (2 * 16 * 33)         // doubles of one wavefront's partial T in LDS: (re, im) x 16 rows x 32 columns (+1 pad)
 
+// sin and cos of a phase, for |x| < 1e6 without the library's large-argument machinery (its double-double reduction was 85 of
+// the 130 fp64 vector instructions of a k-step, and fp64 vector instructions share the SIMD's units with the matrix instructions):
+// Cody-Waite reduction by pi/2 in three parts (the first two have 33 bits: k * part is exact for |k| < 2^20), then the fdlibm
+// kernels on [-pi/4, pi/4] (< 1 ulp each; 2.1e-16 absolute against long double over +-1e5, checked on the CPU).  Larger or
+// non-finite arguments give NaN (keeping the library routine as a fallback costs the registers the accumulators need: spills).
+__device__ __forceinline__ void fe_sincos(double x, double& sn, double& co) {
+    x = fabs(x) < 1.0e6 ? x : __builtin_nan("");           // (a screen of a million radians is not a phase screen: NaN in, NaN out)
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                           -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double s0 = fma(r * z, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                           2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -sa : sa;
+    co = ((q + 1) & 2) ? -ca : ca;
+}
+
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParams P) {      // (second argument: workgroups per CU here = 2 wavefronts per SIMD either way)
     extern __shared__ double sTd[];                           // [NW][2][16][33]
@@ -77,7 +101,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
             f_n[0] = fp[0]; f_n[1] = fp[64]; f_n[2] = fp[128]; f_n[3] = fp[192];
         }
         double sn, co;
-        sincos(ph, &sn, &co);
+        fe_sincos(ph, sn, co);
         const double fs0 = fr0 + fi0, fs1 = fr1 + fi1;
 #pragma unroll
         for (int k = 0; k < FE_MAXDIV; ++k) {

@@ -75,6 +75,24 @@ def test_estimator_at_the_reference_size_and_recovers_small_aberrations(pkg, gpu
     est.close()
 
 
+def test_estimator_with_large_and_out_of_range_phases(pkg, gpu):
+    """The PSF kernel reduces the phase by pi/2 itself (three-part constant, exact for |phase| < 1e6 rad): screens of thousands of
+    radians -- many turns of the argument reduction -- against the FFT restatement; a pixel beyond the range gives NaN, not a
+    wrong number."""
+    op = pkg.synthetic.estimator_optics(64)
+    est = _estimator(pkg, op)
+    rng = np.random.default_rng(12)
+    scr = _screens(op, 2, seed=3)[1] + 2.0e3 * rng.standard_normal((2, 64, 64)) * op["pupil"]
+    ad, Y = est.apply(scr, want_Y=True)
+    for b in range(2):
+        ado, Yo = er.estimator_step(scr[b], op["pupil"], op["W"], op["zd_list"], op["dx"], op["A_s"], op["b_s"], AU=op["AU"])
+        assert rel_err(Y[b], Yo) <= 1e-9 and rel_err(ad[b], ado) <= 1e-7
+    bad = scr.copy(); bad[1, 32, 32] = 3.0e6
+    adb = est.apply(bad)
+    assert np.all(np.isfinite(adb[0])) and np.all(np.isnan(adb[1]))
+    est.close()
+
+
 def test_estimator_argument_checks(pkg, gpu):
     import ctypes as C
     lib = pkg.load()
