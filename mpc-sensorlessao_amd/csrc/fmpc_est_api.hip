@@ -77,13 +77,13 @@ extern "C" int fmpc_est_apply_device(fmpc_est e, int batch, const double* scrn, 
         size_t cap = 1;
         while (cap < (size_t)batch) cap *= 2;
         if (hipMalloc((void**)&e->part, cap * e->ndiv * (e->len / 16) * 2048 * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&e->shares, cap * e->ndiv * e->nx * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+            hipMalloc((void**)&e->shares, cap * e->ndiv * 4 * e->nx * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
         e->part_batch = cap;
     }
     FeParams P;
     P.len = e->len; P.d = e->d; P.ndiv = e->ndiv; P.nx = e->nx; P.batch = batch; P.scale = e->scale;
     P.scrn = scrn; P.noise = noise; P.Dre = e->pool + e->oDre; P.Dim = e->pool + e->oDim; P.Fimg = e->pool + e->oF;
-    P.G = e->pool + e->oG; P.bs = e->pool + e->ob; P.part = e->part; P.shares = e->shares; P.ad_est = ad_est; P.Yout = Y_out;
+    P.G = e->pool + e->oG; P.bs = e->pool + e->ob; P.part = e->part; P.shares = e->shares; P.shares_cap = e->part_batch * (size_t)e->ndiv * 4 * e->nx; P.nshare = 1; P.ad_est = ad_est; P.Yout = Y_out;
     return fmpc_launch_estimator(P, (hipStream_t)stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 

@@ -228,6 +228,49 @@ __global__ void __launch_bounds__(1024) fmpc_est_finish(FeParams P) {
     }
 }
 
+// fmpc_est_finish for a FEW screens (the reference's loop: one): the same sums by four workgroups of 256 threads per (screen,
+// diversity) -- eight window rows each -- whose threads may hold 256 registers: the 64 loads of a pixel's 32 partial windows and
+// its 27 entries of G are ALL requested before the first is used, one memory round trip where the 1024-thread form (128 registers
+// per thread) has four for the partial windows and three for G.  Shares: [screen][diversity][quarter][nx].
+#define FE_FQ 4
+__global__ void __launch_bounds__(256) fmpc_est_finish_few(FeParams P) {
+    __shared__ double sRed[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = blockIdx.x, k = blockIdx.y, qd = blockIdx.z, d = P.d, nblk = P.len / 16, dd = d * d, p = P.ndiv * dd;
+    const int v = tid & 31, u = 8 * qd + (tid >> 5);          // window column (consecutive lanes: consecutive doubles), row
+    const bool own = u < d && v < d;
+    const int il = v * d + u, idx = k * dd + il;              // reshape(v_im(:,:,k), [], 1): column-major
+    constexpr int NB = 32, NG = 27;                           // (the launcher takes this form for nblk == 32 and nx <= 27 only)
+    double re[NB], im[NB], gv[NG];
+    {
+        const double* src = P.part + (((size_t)r * P.ndiv + k) * nblk * 2) * 1024 + (own ? u * 32 + v : 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { re[b] = src[(size_t)b * 2048]; im[b] = src[(size_t)b * 2048 + 1024]; }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) gv[j] = P.G[(size_t)(j < P.nx ? j : 0) * p + (own ? idx : 0)];
+    }
+    double orr = 0.0, oi = 0.0;                               // the same fixed order as fmpc_est_finish: groups of eight
+#pragma unroll
+    for (int b = 0; b < NB; b += 8) {
+        orr += ((re[b] + re[b + 1]) + (re[b + 2] + re[b + 3])) + ((re[b + 4] + re[b + 5]) + (re[b + 6] + re[b + 7]));
+        oi += ((im[b] + im[b + 1]) + (im[b + 2] + im[b + 3])) + ((im[b + 4] + im[b + 5]) + (im[b + 6] + im[b + 7]));
+    }
+    double y = (orr * orr + oi * oi) * P.scale;
+    if (own && P.noise) y += P.noise[(size_t)r * p + idx];
+    if (own && P.Yout) P.Yout[(size_t)r * p + idx] = y;
+    const double yv = own ? y - P.bs[idx] : 0.0;
+    double* share = P.shares + (((size_t)r * P.ndiv + k) * FE_FQ + qd) * P.nx;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        double a = j < P.nx ? gv[j] * yv : 0.0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) sRed[wv][j] = a;
+    }
+    __syncthreads();
+    if (tid < P.nx) share[tid] = (sRed[0][tid] + sRed[1][tid]) + (sRed[2][tid] + sRed[3][tid]);
+}
+
 // ad_est = sum over the diversities of their shares, in a fixed order.  (A launch of its own: the last-arriving workgroup of
 // fmpc_est_finish doing it needs device-scope release fences, which write back an L2 full of partial windows: 35 % slower at
 // 256 screens, measured.)
@@ -235,9 +278,9 @@ __global__ void __launch_bounds__(256) fmpc_est_combine(FeParams P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.batch * P.nx) return;
     const int r = i / P.nx, j = i - r * P.nx;
-    const double* sh = P.shares + (size_t)r * P.ndiv * P.nx + j;
+    const double* sh = P.shares + (size_t)r * P.ndiv * P.nshare * P.nx + j;
     double a = 0.0;
-    for (int kk = 0; kk < P.ndiv; ++kk) a += sh[(size_t)kk * P.nx];
+    for (int kk = 0; kk < P.ndiv * P.nshare; ++kk) a += sh[(size_t)kk * P.nx];
     P.ad_est[i] = a;
 }
 
@@ -256,9 +299,16 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.len / 16, P.batch), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
     }
-    const size_t lds = ((((size_t)P.d * P.d + 1) & ~(size_t)1) + (size_t)P.nx * 16) * sizeof(double);
-    hipLaunchKernelGGL(fmpc_est_finish, dim3(P.batch, P.ndiv), dim3(1024), lds, stream, P);
-    hipLaunchKernelGGL(fmpc_est_combine, dim3((P.batch * P.nx + 255) / 256), dim3(256), 0, stream, P);
+    FeParams Q = P;
+    if ((size_t)P.batch * P.ndiv <= 64 && P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
+        Q.nshare = FE_FQ;
+        hipLaunchKernelGGL(fmpc_est_finish_few, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
+    } else {
+        Q.nshare = 1;
+        const size_t lds = ((((size_t)P.d * P.d + 1) & ~(size_t)1) + (size_t)P.nx * 16) * sizeof(double);
+        hipLaunchKernelGGL(fmpc_est_finish, dim3(P.batch, P.ndiv), dim3(1024), lds, stream, Q);
+    }
+    hipLaunchKernelGGL(fmpc_est_combine, dim3((P.batch * P.nx + 255) / 256), dim3(256), 0, stream, Q);
     return hipGetLastError();
 }
 
