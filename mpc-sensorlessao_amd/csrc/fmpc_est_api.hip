@@ -14,7 +14,7 @@ struct fmpc_est_s {
     double scale;
     double* pool;                        // D_re | D_im | Fimg | G | b_s
     size_t oDre, oDim, oF, oG, ob;
-    double* part; size_t part_batch;     // workspace, grown with the batch
+    double* part; size_t part_batch, part_doubles;     // workspace, grown with the batch
     double* shares;
     std::mutex mu;
 };
@@ -29,7 +29,7 @@ extern "C" int fmpc_est_create(fmpc_est* out, int len, int first, int d, int ndi
     fmpc_est_s* e = new (std::nothrow) fmpc_est_s();
     if (!e) return FMPC_E_ALLOC;
     e->device = device; e->len = len; e->d = d; e->first = first; e->ndiv = ndiv; e->nx = nx; e->p = p; e->scale = scale;
-    e->pool = nullptr; e->part = nullptr; e->part_batch = 0; e->shares = nullptr;
+    e->pool = nullptr; e->part = nullptr; e->part_batch = 0; e->part_doubles = 0; e->shares = nullptr;
     std::vector<double> G, Fimg;
     e->rank = fmpc_host_estimator_gain(A_s, p, nx, G);
     fmpc_host_estimator_dft_images(len, d, first, Fimg);
@@ -76,14 +76,17 @@ extern "C" int fmpc_est_apply_device(fmpc_est e, int batch, const double* scrn, 
             e->part = nullptr; e->shares = nullptr; e->part_batch = 0;
         size_t cap = 1;
         while (cap < (size_t)batch) cap *= 2;
-        if (hipMalloc((void**)&e->part, cap * e->ndiv * (e->len / 16) * 2048 * sizeof(double)) != hipSuccess ||
+        // (few screens: the PSF kernel may split the columns of a row block over two workgroups -- room for 4 screens x 128 partial windows per diversity)
+        const size_t pw = cap * e->ndiv * (e->len / 16) < (size_t)4 * e->ndiv * 128 ? (size_t)4 * e->ndiv * 128 : cap * e->ndiv * (e->len / 16);
+        e->part_doubles = pw * 2048;
+        if (hipMalloc((void**)&e->part, pw * 2048 * sizeof(double)) != hipSuccess ||
             hipMalloc((void**)&e->shares, cap * e->ndiv * 4 * e->nx * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
         e->part_batch = cap;
     }
     FeParams P;
     P.len = e->len; P.d = e->d; P.ndiv = e->ndiv; P.nx = e->nx; P.batch = batch; P.scale = e->scale;
     P.scrn = scrn; P.noise = noise; P.Dre = e->pool + e->oDre; P.Dim = e->pool + e->oDim; P.Fimg = e->pool + e->oF;
-    P.G = e->pool + e->oG; P.bs = e->pool + e->ob; P.part = e->part; P.shares = e->shares; P.shares_cap = e->part_batch * (size_t)e->ndiv * 4 * e->nx; P.nshare = 1; P.ad_est = ad_est; P.Yout = Y_out;
+    P.G = e->pool + e->oG; P.bs = e->pool + e->ob; P.part = e->part; P.shares = e->shares; P.shares_cap = e->part_batch * (size_t)e->ndiv * 4 * e->nx; P.nshare = 1; P.part_cap = e->part_doubles; P.ad_est = ad_est; P.Yout = Y_out;
     return fmpc_launch_estimator(P, (hipStream_t)stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 

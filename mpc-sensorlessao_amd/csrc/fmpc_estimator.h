@@ -14,7 +14,7 @@ struct FeParams {
     const double* G; const double* bs;  // nx x p row-major, p
     double* part;                       // workspace [batch][ndiv][len / 16][2][32][32]
     double* shares;                     // [batch][ndiv][nshare][nx] shares of ad_est per diversity (and window quarter: few screens)
-    size_t shares_cap;                  // doubles allocated behind `shares`
+    size_t shares_cap, part_cap;        // doubles allocated behind `shares` / `part`
     int nshare;                         // set by the launcher: 1, or 4 for the few-screen finish
     double* ad_est; double* Yout;       // [batch][nx], [batch][p] or NULL
 };

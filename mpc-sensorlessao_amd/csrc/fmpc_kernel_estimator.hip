@@ -60,7 +60,8 @@ template <int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParams P) {      // (second argument: workgroups per CU here = 2 wavefronts per SIMD either way)
     extern __shared__ double sTd[];                           // [NW][2][16][33]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int len = P.len, nq = len / (4 * NW);               // k-steps per wavefront
+    const int CS = gridDim.z, cs = blockIdx.z;                // column split over workgroups (few screens: a lone screen is 32 row blocks)
+    const int len = P.len, nq = len / (4 * NW * CS);          // k-steps per wavefront
     const int blk = blockIdx.x, r = blockIdx.y;
     const int y0 = 16 * blk;
     const size_t npx = (size_t)len * len;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
     //      entry (k-row 4 Q + g, window column 16 t + c) of the B operand.
     //      Everything a k-step reads is requested one k-step ahead (11 loads per lane): a lone screen has nothing else to
     //      hide the memory latency behind.
-    const int Q0 = wv * nq;
+    const int Q0 = (cs * NW + wv) * nq;
     double ph_n, dr_n[FE_MAXDIV], di_n[FE_MAXDIV], f_n[4];
     {
         const size_t px = (size_t)(4 * Q0 + g) * len + (y0 + c);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
             Oi = FE_MFMA(far[q2], ti, Oi); Oi = FE_MFMA(fai[q2], tr, Oi);
         }
         // partial window of these 16 rows: [r][k][blk][re, im][32][32], register rr <-> row 16 tu + 4 rr + g, column 16 tv + c
-        double* dst = P.part + ((((size_t)r * P.ndiv + k) * gridDim.x + blk) * 2) * 1024;
+        double* dst = P.part + ((((size_t)r * P.ndiv + k) * gridDim.x * CS + (blk * CS + cs)) * 2) * 1024;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int o = (16 * tu + 4 * rr + g) * 32 + 16 * tv + c;
@@ -233,27 +234,33 @@ __global__ void __launch_bounds__(1024) fmpc_est_finish(FeParams P) {
 // its 27 entries of G are ALL requested before the first is used, one memory round trip where the 1024-thread form (128 registers
 // per thread) has four for the partial windows and three for G.  Shares: [screen][diversity][quarter][nx].
 #define FE_FQ 4
+template <int NCH>                                           // partial windows per pixel: 32 NCH (column split of the PSF kernel)
 __global__ void __launch_bounds__(256) fmpc_est_finish_few(FeParams P) {
     __shared__ double sRed[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = blockIdx.x, k = blockIdx.y, qd = blockIdx.z, d = P.d, nblk = P.len / 16, dd = d * d, p = P.ndiv * dd;
+    const int r = blockIdx.x, k = blockIdx.y, qd = blockIdx.z, d = P.d, nblk = 32 * NCH, dd = d * d, p = P.ndiv * dd;
     const int v = tid & 31, u = 8 * qd + (tid >> 5);          // window column (consecutive lanes: consecutive doubles), row
     const bool own = u < d && v < d;
     const int il = v * d + u, idx = k * dd + il;              // reshape(v_im(:,:,k), [], 1): column-major
     constexpr int NB = 32, NG = 27;                           // (the launcher takes this form for nblk == 32 and nx <= 27 only)
     double re[NB], im[NB], gv[NG];
-    {
-        const double* src = P.part + (((size_t)r * P.ndiv + k) * nblk * 2) * 1024 + (own ? u * 32 + v : 0);
+    const double* src = P.part + (((size_t)r * P.ndiv + k) * nblk * 2) * 1024 + (own ? u * 32 + v : 0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) { re[b] = src[(size_t)b * 2048]; im[b] = src[(size_t)b * 2048 + 1024]; }
+    for (int b = 0; b < NB; ++b) { re[b] = src[(size_t)b * 2048]; im[b] = src[(size_t)b * 2048 + 1024]; }
 #pragma unroll
-        for (int j = 0; j < NG; ++j) gv[j] = P.G[(size_t)(j < P.nx ? j : 0) * p + (own ? idx : 0)];
-    }
-    double orr = 0.0, oi = 0.0;                               // the same fixed order as fmpc_est_finish: groups of eight
+    for (int j = 0; j < NG; ++j) gv[j] = P.G[(size_t)(j < P.nx ? j : 0) * p + (own ? idx : 0)];
+    double orr = 0.0, oi = 0.0;                               // fixed order: groups of eight
 #pragma unroll
-    for (int b = 0; b < NB; b += 8) {
-        orr += ((re[b] + re[b + 1]) + (re[b + 2] + re[b + 3])) + ((re[b + 4] + re[b + 5]) + (re[b + 6] + re[b + 7]));
-        oi += ((im[b] + im[b + 1]) + (im[b + 2] + im[b + 3])) + ((im[b + 4] + im[b + 5]) + (im[b + 6] + im[b + 7]));
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+        for (int b = 0; b < NB; b += 8) {
+            orr += ((re[b] + re[b + 1]) + (re[b + 2] + re[b + 3])) + ((re[b + 4] + re[b + 5]) + (re[b + 6] + re[b + 7]));
+            oi += ((im[b] + im[b + 1]) + (im[b + 2] + im[b + 3])) + ((im[b + 4] + im[b + 5]) + (im[b + 6] + im[b + 7]));
+        }
+        if (ch + 1 < NCH) {                                   // (a further 32 partial windows: one more round trip)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { re[b] = src[(size_t)((ch + 1) * NB + b) * 2048]; im[b] = src[(size_t)((ch + 1) * NB + b) * 2048 + 1024]; }
+        }
     }
     double y = (orr * orr + oi * oi) * P.scale;
     if (own && P.noise) y += P.noise[(size_t)r * p + idx];
@@ -288,6 +295,13 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
     if (P.len % 64 != 0 || P.len < 64 || P.d < 1 || P.d > 32 || P.ndiv < 1 || P.ndiv > FE_MAXDIV) return hipErrorInvalidValue;
     // few screens: 8 wavefronts per workgroup so that a lone screen is 256 wavefronts, not 128
     const bool wide = (size_t)P.batch * (P.len / 16) < 512 && P.len % 128 == 0;
+    // very few screens of the reference's size: the columns of a row block split over two workgroups as well (a lone screen is
+    // then 64 workgroups of 8 wavefronts), twice the partial windows for the finish pass
+    int csplit = 1;
+    if (P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
+        // (a split of four for ONE screen -- 128 workgroups, four round trips in the finish pass -- measured no faster: 39.6 against 38.1 us)
+        if ((size_t)P.batch * P.ndiv <= 12 && P.part_cap >= (size_t)P.batch * P.ndiv * 64 * 2048) csplit = 2;
+    }
     if (wide) {
         static bool prepared = false;
         const size_t lds8 = (size_t)8 * FE_TSTRIDE * sizeof(double);
@@ -295,14 +309,15 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
             if (hipFuncSetAttribute((const void*)fmpc_est_psf<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess) return hipErrorInvalidValue;
             prepared = true;
         }
-        hipLaunchKernelGGL(fmpc_est_psf<8>, dim3(P.len / 16, P.batch), dim3(512), lds8, stream, P);
+        hipLaunchKernelGGL(fmpc_est_psf<8>, dim3(P.len / 16, P.batch, csplit), dim3(512), lds8, stream, P);
     } else {
         hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.len / 16, P.batch), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
     }
     FeParams Q = P;
     if ((size_t)P.batch * P.ndiv <= 64 && P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
         Q.nshare = FE_FQ;
-        hipLaunchKernelGGL(fmpc_est_finish_few, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
+        if (csplit == 2) hipLaunchKernelGGL(fmpc_est_finish_few<2>, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
+        else hipLaunchKernelGGL(fmpc_est_finish_few<1>, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
     } else {
         Q.nshare = 1;
         const size_t lds = ((((size_t)P.d * P.d + 1) & ~(size_t)1) + (size_t)P.nx * 16) * sizeof(double);
