@@ -159,13 +159,15 @@ class AOLoop:
         self.steps_done = 0
         self._C, self._torch, self._dev = C, torch, dev
 
-    def step(self, phase_k, noise=None):
-        """phase_k: (batch, len, len) float64 HIP tensor indexed [b, row, column] (phase_valid(:,:,k) of every realisation).
+    def step(self, phase_k, noise=None, colmajor=False):
+        """phase_k: (batch, len, len) float64 HIP tensor indexed [b, row, column] (phase_valid(:,:,k) of every realisation);
+        colmajor=True: indexed [b, column, row] already -- the order MATLAB keeps phase_valid(:,:,k) in -- and no copy is made.
         Returns (u[k] (batch, m), ad_est (batch, n)); both views valid until two further steps / the next step."""
         torch, C = self._torch, self._C
         s = self.steps_done
         u_new, u1, u2 = self.u[s % 3], self.u[(s - 1) % 3], self.u[(s - 2) % 3]
-        ph = phase_k.transpose(-1, -2).contiguous()                                   # column-major planes, as the mode maps
+        ph = phase_k if colmajor else phase_k.transpose(-1, -2).contiguous()          # column-major planes, as the mode maps
+        assert ph.is_contiguous() and ph.dtype == torch.float64
         vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
         rc = self.h._lib.fmpc_phase_residual_device(self.h._h, self.batch, self.npx, vp(ph), vp(u1) if s >= 1 else None, vp(self.Z), vp(self.scrn), stream)
