@@ -17,6 +17,8 @@
 #include "fmpc_affine.h"
 #include "fmpc_loopu0.h"
 #include "fmpc_tiled.h"
+#define FMPC_PRODUCT_MIN_BATCH_DEFAULT 65   // closed-loop steps with first moves only: the product form from this many realisations on
+
 
 // kernels / launchers (fmpc_kernel_generic.hip)
 size_t fmpc_generic_lds_bytes(int n, int m);
@@ -84,7 +86,7 @@ struct fmpc_handle_s {
     // affine form of the cold-start step without w (fmpc_kernel_affine.hip), built with the first-move form
     FaParams fa_P; int fa_valid, fa_disabled; int* fa_need; size_t fa_need_cap;
     double* ao_scr; size_t ao_cap;       // fmpc_ao_step_device: a zero a[k] and scratch x0 / x0_pre for the loop-input kernel (3 batch n)
-    FlParams fs_P; FlStepIn fs_I; int fs_valid, fs_disabled;   // the fused step (fmpc_loop_step27): images in its column order, B's images
+    FlParams fs_P; FlStepIn fs_I; int fs_valid, fs_disabled, fs_min_batch;   // the fused step (fmpc_loop_step27): images in its column order, B's images
     FlParams fl_P; int fl_valid, fl_disabled;       // first-move form as a product: closed-loop steps of > 64 realisations (fmpc_kernel_loopu0.hip)
     FwModel wave;
     double* wave_pool_d;
@@ -311,6 +313,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* na = getenv("FMPC_NO_AFFINE"); h->fa_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* na = getenv("FMPC_NO_LOOP_U0"); h->fl_disabled = (na && na[0] == '1') ? 1 : 0; }
     { const char* na = getenv("FMPC_NO_LOOP_FUSE"); h->fs_disabled = (na && na[0] == '1') ? 1 : 0; }
+    { const char* na = getenv("FMPC_PRODUCT_MIN_BATCH"); h->fs_min_batch = (na && atoi(na) >= 1) ? atoi(na) : FMPC_PRODUCT_MIN_BATCH_DEFAULT; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -1510,8 +1513,14 @@ static int fmpc_loop_step_impl(fmpc_handle h, int batch, const double* a_k, cons
     const bool lr = h->inv_enabled && h->inv_jimg2 != nullptr && h->n == FP_N;
     if (lr && !z_out && !nu_out && n_newton == 1) {
         // first moves only, a few realisations: one launch instead of four (falls through when the form does not apply)
-        rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
-        if (rc == FMPC_E_UNSUPPORTED && batch > FMPC_FIRST_MOVE_MAX_BATCH)
+        // few realisations: a workgroup per realisation (fmpc_first_move); from fs_min_batch on (default 65, FMPC_PRODUCT_MIN_BATCH)
+        // the product form, whose 16 workgroups per 16 realisations spread the constants over as many CUs
+        rc = FMPC_E_UNSUPPORTED;
+        if (batch >= h->fs_min_batch)
+            rc = fmpc_loop_u0_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
+        if (rc == FMPC_E_UNSUPPORTED)
+            rc = fmpc_first_move_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
+        if (rc == FMPC_E_UNSUPPORTED && batch > FMPC_FIRST_MOVE_MAX_BATCH && batch < h->fs_min_batch)
             rc = fmpc_loop_u0_step(h, batch, a_k, x0_last, u1, u2, x0, x0_pre, w, nu0, k, status, iters, step, u0_out, (hipStream_t)stream, given);
         if (rc != FMPC_E_UNSUPPORTED) { fmpc_guard_end(h, (hipStream_t)stream); return rc; }
         rc = FMPC_OK;
