@@ -9,6 +9,8 @@
   closed512       closed loop, 512 realisations: fmpc_loop_step_device per step
   closed512u0     closed loop, 512 realisations, first moves only, one call per step (loop inputs + fmpc_loop_u0 + flag mode)
   walk64          closed loop, 64 realisations, a recorded stretch of 300 steps in one call (fmpc_first_move_run: one launch)
+  aoloop1         the loop with its estimator, one realisation: residual screen, PSF windows (columns split over two workgroups), finish by quarters,
+                  combine, first-move kernel, flag-mode launch
   estimator256    phase-diversity estimator, 256 screens of 512 x 512 per call (fmpc_est_psf<4>, fmpc_est_finish, fmpc_est_combine)
   budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
                   + compaction, continuation of the ~9 % that go on by the tiled kernel"""
@@ -22,6 +24,20 @@ if target in ("general_tiled", "tiled_f32"):
 import numpy as np, torch
 pkg = importlib.import_module("mpc-sensorlessao_amd")
 dev = torch.device("cuda:0")
+if target == "aoloop1":
+    # the reference's loop with its estimator, ONE realisation, screens handed over in MATLAB's order (AOLoop, fmpc_ao_step_device)
+    op = pkg.synthetic.estimator_optics(512)
+    md = pkg.synthetic.make_model(27, 144, 30)
+    h = pkg.FastMPCHandle(md["A1"], md["A2"], md["B"], md["Q"], md["R"], md["Qf"], md["u_min"], md["u_max"], md["x_min"], md["x_max"], 30)
+    est = pkg.PhaseDiversityEstimator(op["pupil"], op["W"], op["zd_list"], op["dx"], op["range_min"] + 1, op["range_max"] + 1, op["A_s"], op["b_s"])
+    ph = torch.from_numpy(0.2 * np.random.default_rng(0).standard_normal((1, 512, 512))).to(dev)
+    loop = pkg.AOLoop(h, est, op["Z"][1:], 1, n_newton=1, k=1e-2)
+    for _ in range(10 * reps):
+        loop.step(ph, colmajor=True)
+    torch.cuda.synchronize()
+    print(target, "status", int(loop.status.abs().sum()))
+    est.close(); h.close()
+    sys.exit(0)
 if target == "estimator256":
     op = pkg.synthetic.estimator_optics(512)
     est = pkg.PhaseDiversityEstimator(op["pupil"], op["W"], op["zd_list"], op["dx"], op["range_min"] + 1, op["range_max"] + 1, op["A_s"], op["b_s"])
