@@ -14,6 +14,7 @@ struct fmpc_est_s {
     double scale;
     double* pool;                        // D_re | D_im | Fimg | G | b_s
     size_t oDre, oDim, oF, oG, ob;
+    int* qlist;                          // [len / 16][2]: range of the k-steps inside the pupil per row block
     double* part; size_t part_batch, part_doubles;     // workspace, grown with the batch
     double* shares;
     std::mutex mu;
@@ -29,7 +30,7 @@ extern "C" int fmpc_est_create(fmpc_est* out, int len, int first, int d, int ndi
     fmpc_est_s* e = new (std::nothrow) fmpc_est_s();
     if (!e) return FMPC_E_ALLOC;
     e->device = device; e->len = len; e->d = d; e->first = first; e->ndiv = ndiv; e->nx = nx; e->p = p; e->scale = scale;
-    e->pool = nullptr; e->part = nullptr; e->part_batch = 0; e->part_doubles = 0; e->shares = nullptr;
+    e->pool = nullptr; e->qlist = nullptr; e->part = nullptr; e->part_batch = 0; e->part_doubles = 0; e->shares = nullptr;
     std::vector<double> G, Fimg;
     e->rank = fmpc_host_estimator_gain(A_s, p, nx, G);
     fmpc_host_estimator_dft_images(len, d, first, Fimg);
@@ -41,6 +42,28 @@ extern "C" int fmpc_est_create(fmpc_est* out, int len, int first, int d, int ndi
     e->oG = push(G.data(), G.size()); e->ob = push(b_s, p);
     if (hipMalloc((void**)&e->pool, pool.size() * sizeof(double)) != hipSuccess) { delete e; return FMPC_E_ALLOC; }
     if (hipMemcpy(e->pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e->pool); delete e; return FMPC_E_HIP; }
+    // the range of k-steps of every row block that sees the pupil (fmpc_est_psf skips what lies outside)
+    {
+        const int nblk = len / 16, nks = len / 4;
+        std::vector<int> qr((size_t)2 * nblk, 0);
+        for (int b = 0; b < nblk; ++b) {
+            int lo = nks, hi = 0;
+            for (int Q = 0; Q < nks; ++Q) {
+                bool any = false;
+                for (int k = 0; k < ndiv && !any; ++k)
+                    for (int x = 4 * Q; x < 4 * Q + 4 && !any; ++x)
+                        for (int y = 16 * b; y < 16 * b + 16; ++y) {
+                            const size_t o = (size_t)k * npx + (size_t)x * len + y;            // column-major: (row y, column x)
+                            if (D_re[o] != 0.0 || D_im[o] != 0.0) { any = true; break; }
+                        }
+                if (any) { if (Q < lo) lo = Q; hi = Q + 1; }
+            }
+            if (hi <= lo) { lo = 0; hi = 0; }
+            qr[2 * b] = lo; qr[2 * b + 1] = hi;
+        }
+        if (hipMalloc((void**)&e->qlist, qr.size() * sizeof(int)) != hipSuccess) { (void)hipFree(e->pool); delete e; return FMPC_E_ALLOC; }
+        if (hipMemcpy(e->qlist, qr.data(), qr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e->qlist); (void)hipFree(e->pool); delete e; return FMPC_E_HIP; }
+    }
     *out = e;
     return FMPC_OK;
 }
@@ -50,6 +73,7 @@ extern "C" int fmpc_est_destroy(fmpc_est e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (e->pool) (void)hipFree(e->pool);
+    if (e->qlist) (void)hipFree(e->qlist);
     if (e->part) (void)hipFree(e->part);
     if (e->shares) (void)hipFree(e->shares);
     delete e;
@@ -86,6 +110,7 @@ extern "C" int fmpc_est_apply_device(fmpc_est e, int batch, const double* scrn, 
     FeParams P;
     P.len = e->len; P.d = e->d; P.ndiv = e->ndiv; P.nx = e->nx; P.batch = batch; P.scale = e->scale;
     P.scrn = scrn; P.noise = noise; P.Dre = e->pool + e->oDre; P.Dim = e->pool + e->oDim; P.Fimg = e->pool + e->oF;
+    P.qrange = e->qlist;
     P.G = e->pool + e->oG; P.bs = e->pool + e->ob; P.part = e->part; P.shares = e->shares; P.shares_cap = e->part_batch * (size_t)e->ndiv * 4 * e->nx; P.nshare = 1; P.part_cap = e->part_doubles; P.ad_est = ad_est; P.Yout = Y_out;
     return fmpc_launch_estimator(P, (hipStream_t)stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }

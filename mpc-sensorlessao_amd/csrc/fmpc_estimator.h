@@ -10,6 +10,7 @@ struct FeParams {
     const double* scrn;                 // [batch][len x len column-major]
     const double* noise;                // [batch][ndiv d^2] or NULL
     const double* Dre; const double* Dim;   // [ndiv][len x len column-major]: pupil .* exp(1i zd_k W)
+    const int* qrange;                  // per row block of 16: [first, last + 1) of the k-steps (4 columns) with a pixel inside the pupil
     const double* Fimg;                 // DFT factors of the window as operand images (fmpc_host_estimator_dft_images)
     const double* G; const double* bs;  // nx x p row-major, p
     double* part;                       // workspace [batch][ndiv][len / 16][2][32][32]

@@ -61,8 +61,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
     extern __shared__ double sTd[];                           // [NW][2][16][33]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
     const int CS = gridDim.z, cs = blockIdx.z;                // column split over workgroups (few screens: a lone screen is 32 row blocks)
-    const int len = P.len, nq = len / (4 * NW * CS);          // k-steps per wavefront
-    const int blk = blockIdx.x, r = blockIdx.y;
+    const int len = P.len;
+    // (the screen is the fastest grid index: the workgroups in flight at one time share a few row blocks, whose rows of the
+    //  six D_k arrays -- 12.6 MB in all, more than an L2 -- then come from L2 instead of being streamed once per screen)
+    const int r = blockIdx.x, blk = blockIdx.y, nblk = gridDim.y;
     const int y0 = 16 * blk;
     const size_t npx = (size_t)len * len;
     const double* scrn = P.scrn + (size_t)r * npx;
@@ -77,7 +79,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
     //      entry (k-row 4 Q + g, window column 16 t + c) of the B operand.
     //      Everything a k-step reads is requested one k-step ahead (11 loads per lane): a lone screen has nothing else to
     //      hide the memory latency behind.
-    const int Q0 = (cs * NW + wv) * nq;
+    //      Only the k-steps between the first and the last one that see the pupil are visited (D_k = 0 for every k outside: the
+    //      corners of the reference's pin-hole pupil are 21 % of the grid; a RANGE per row block, built at create time -- a list
+    //      of k-steps put a dependent scalar load in front of every prefetch and cost more than it saved), dealt evenly to the
+    //      wavefronts of the workgroup(s).
+    const int qlo = P.qrange[2 * blk], cnt = P.qrange[2 * blk + 1] - qlo, W = NW * CS, wi = cs * NW + wv;
+    const int i0 = (int)((long long)cnt * wi / W), i1 = (int)((long long)cnt * (wi + 1) / W), nq = i1 - i0;
+    const int Q0 = qlo + i0;
     double ph_n, dr_n[FE_MAXDIV], di_n[FE_MAXDIV], f_n[4];
     {
         const size_t px = (size_t)(4 * Q0 + g) * len + (y0 + c);
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) fmpc_est_psf(FeParam
             Oi = FE_MFMA(far[q2], ti, Oi); Oi = FE_MFMA(fai[q2], tr, Oi);
         }
         // partial window of these 16 rows: [r][k][blk][re, im][32][32], register rr <-> row 16 tu + 4 rr + g, column 16 tv + c
-        double* dst = P.part + ((((size_t)r * P.ndiv + k) * gridDim.x * CS + (blk * CS + cs)) * 2) * 1024;
+        double* dst = P.part + ((((size_t)r * P.ndiv + k) * nblk * CS + (blk * CS + cs)) * 2) * 1024;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int o = (16 * tu + 4 * rr + g) * 32 + 16 * tv + c;
@@ -309,9 +317,9 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
             if (hipFuncSetAttribute((const void*)fmpc_est_psf<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess) return hipErrorInvalidValue;
             prepared = true;
         }
-        hipLaunchKernelGGL(fmpc_est_psf<8>, dim3(P.len / 16, P.batch, csplit), dim3(512), lds8, stream, P);
+        hipLaunchKernelGGL(fmpc_est_psf<8>, dim3(P.batch, P.len / 16, csplit), dim3(512), lds8, stream, P);
     } else {
-        hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.len / 16, P.batch), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
+        hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.batch, P.len / 16), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
     }
     FeParams Q = P;
     if ((size_t)P.batch * P.ndiv <= 64 && P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
