@@ -405,3 +405,23 @@ def test_loop_step_in_place_and_with_separate_x0_buffers(pkg, gpu):
     assert np.array_equal(A[4], B_[4]) and np.array_equal(A[5], B_[5]) and int(np.abs(A[4]).sum()) == 0
     assert rel_err(B_[2], A[2]) <= 1e-13 and rel_err(B_[3], A[3]) <= 1e-12
     h.close()
+
+
+@pytest.mark.parametrize("m,R", [(100, 70), (37, 70), (100, 5)])
+def test_first_move_forms_with_other_actuator_counts(pkg, gpu, m, R):
+    """The first-move forms with m = 100 and 37 actuators (row tiles, k-steps and the wavefronts' shares of the actuators end in
+    partial ones): first moves only against the loop that keeps z, 1e-11 over six fed-back steps."""
+    import torch
+    md = pkg.synthetic.make_model(27, m, 10)
+    steps = 6
+    a = np.stack([pkg.synthetic.make_realisation(md, r=r, steps=steps)[1:steps + 1] for r in range(R)], axis=1)
+    at = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0"))
+    h1 = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    la = pkg.ClosedLoop(h1, R, n_newton=1, k=1e-2)
+    lb = pkg.ClosedLoop(h2, R, n_newton=1, k=1e-2, keep_z=False)
+    Ua, Xa = la.run(at); Ub, Xb = lb.run(at)
+    torch.cuda.synchronize()
+    assert h2.last_dual_form() == (4 if R > 64 else 1) and int(lb.status.abs().sum()) == 0
+    assert rel_err(Ub.cpu().numpy(), Ua.cpu().numpy()) <= 1e-11 and rel_err(Xb.cpu().numpy(), Xa.cpu().numpy()) <= 1e-11
+    assert rel_err(lb.w.cpu().numpy(), la.w.cpu().numpy()) <= 1e-11
+    h1.close(); h2.close()
