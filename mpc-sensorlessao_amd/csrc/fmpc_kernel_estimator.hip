@@ -242,6 +242,9 @@ __global__ void __launch_bounds__(1024) fmpc_est_finish(FeParams P) {
 // its 27 entries of G are ALL requested before the first is used, one memory round trip where the 1024-thread form (128 registers
 // per thread) has four for the partial windows and three for G.  Shares: [screen][diversity][quarter][nx].
 #define FE_FQ 4
+#ifndef FE_FEW_MAX
+#define FE_FEW_MAX 64          // (screens x diversities) up to which the finish pass takes this form
+#endif
 template <int NCH>                                           // partial windows per pixel: 32 NCH (column split of the PSF kernel)
 __global__ void __launch_bounds__(256) fmpc_est_finish_few(FeParams P) {
     __shared__ double sRed[4][32];
@@ -322,7 +325,7 @@ hipError_t fmpc_launch_estimator(const FeParams& P, hipStream_t stream) {
         hipLaunchKernelGGL(fmpc_est_psf<4>, dim3(P.batch, P.len / 16), dim3(256), (size_t)4 * FE_TSTRIDE * sizeof(double), stream, P);
     }
     FeParams Q = P;
-    if ((size_t)P.batch * P.ndiv <= 64 && P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
+    if ((size_t)P.batch * P.ndiv <= FE_FEW_MAX && P.len == 512 && P.nx <= 27 && P.shares_cap >= (size_t)P.batch * P.ndiv * FE_FQ * P.nx) {
         Q.nshare = FE_FQ;
         if (csplit == 2) hipLaunchKernelGGL(fmpc_est_finish_few<2>, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
         else hipLaunchKernelGGL(fmpc_est_finish_few<1>, dim3(P.batch, P.ndiv, FE_FQ), dim3(256), 0, stream, Q);
