@@ -210,3 +210,33 @@ def test_ao_step_entry_against_loop_inputs_plus_solve(pkg, gpu, R, n_newton, kee
     # x0_pre = NULL is refused for a VAR(2) model
     assert h._lib.fmpc_ao_step_device(h._h, R, vp(x0), None, vp(u1), vp(u2), vp(w), None, 1, 1e-2, None, None, vp(st), vp(it), None, vp(u0), None) == pkg._lib.FMPC_E_NULL
     h.close(); h2.close()
+
+
+@pytest.mark.parametrize("R", [3, 80])
+def test_ao_step_entry_with_a_var1_model_and_no_x0_pre(pkg, gpu, R):
+    """VAR(1) model (A2 = 0: the reference's VAR_1 variant without ramp rows): x0_pre = NULL is allowed and means zeros; against loop
+    inputs + solve, both first-move forms."""
+    import ctypes as C
+    import torch
+    from tests.util import handle_from_model
+    md = pkg.synthetic.make_model(27, 144, 10, var_order=1)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    f = lambda *sh: torch.from_numpy(rng.standard_normal(sh)).to(dev)
+    x0, u1, u2 = 0.3 * f(R, 27), 0.1 * f(R, 144), 0.1 * f(R, 144)
+    h = handle_from_model(pkg, md); h2 = handle_from_model(pkg, md)
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    w = torch.zeros((R, 270), dtype=torch.float64, device=dev); u0 = torch.zeros((R, 144), dtype=torch.float64, device=dev)
+    st = torch.full((R,), -9, dtype=torch.int32, device=dev); it = torch.full((R,), -9, dtype=torch.int32, device=dev)
+    rc = h._lib.fmpc_ao_step_device(h._h, R, vp(x0), None, vp(u1), vp(u2), vp(w), None, 1, 1e-2, None, None, vp(st), vp(it), None, vp(u0),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and h.last_dual_form() == (1 if R <= 64 else 4)
+    za = torch.zeros((R, 27), dtype=torch.float64, device=dev); sx = torch.zeros_like(za); sxp = torch.zeros_like(za)
+    w2 = torch.zeros_like(w); u02 = torch.zeros_like(u0); st2 = torch.zeros_like(st); it2 = torch.zeros_like(it)
+    h2.loop_inputs_device(za, None, u1, u2, sx, sxp, w2)
+    h2.solve_device(x0, None, w2, None, None, 1, 1e-2, status=st2, iters=it2, u0_out=u02, want_z=False)
+    torch.cuda.synchronize()
+    assert torch.equal(st, st2) and torch.equal(it, it2) and int(st.abs().sum()) == 0
+    assert rel_err(w.cpu().numpy(), w2.cpu().numpy()) <= 1e-12 and rel_err(u0.cpu().numpy(), u02.cpu().numpy()) <= 1e-11
+    h.close(); h2.close()
