@@ -9,17 +9,21 @@ time.  Every problem is one independent call of the reference exactly as its not
 Inputs (x0, x0_pre, nu0) are resident in HBM before the timed region; synthetic data per SURVEY.md §8(d).
 
 The JSON line carries
-  roofline             the PER-PROBLEM-FACTOR kernel (every problem factors its own Y in every Newton step: explicit
-                       start, Newton budget 5, test_fast_mpc.m:53,59), priced at SURVEY §8(d)'s 11.64 MFLOP per
-                       problem-iteration: the regime §8(d) / BASELINE.md §3 quote the roofline on
-  roofline_cold_start  the headline's own kernels (shared cold-start factor, 1.60 MFLOP per unit), algorithmic and executed
+  roofline             the headline's OWN kernels (what the timed region ran): bound "hbm", SURVEY §8(d)'s compulsory 47 952 B
+                       per problem x problems of a step / device time of a step (HIP events around the timed regions);
+                       `executed` = matrix instructions issued against the fp64 peak
+  roofline_per_problem_factor
+                       the PER-PROBLEM-FACTOR kernel in a leg of its own (every problem factors its own Y: explicit start),
+                       priced at SURVEY §8(d)'s 11.64 MFLOP per problem-iteration, with its own ms_per_step; `n_newton_5` =
+                       the Newton budget of test_fast_mpc.m:53,59, the setting §8(d) quotes the roofline on
   cpu_baseline         the dense op-for-op restatement of the reference on the host (all cores); `cpu_baseline_1thread`
                        and `cpu_baseline_structured` (oracle/banded_cpu.c, the same algorithm as the GPU) beside it
   extra                configs[2] (512 realisations), configs[4] (n = 65, T = 60, fp32 factor), two steps in flight,
                        Newton budget 5, the closed loops, configs[0] (VAR(1) + ramp rows), the literal fmpc_solve_once call
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-For N > 1 launch with torch.distributed.run (one rank per GPU): weak scaling, every rank solves its own 2000-timestep
+For N > 1 either launch with torch.distributed.run (one rank per GPU) or run `python bench.py --gpus N` from a plain shell:
+without WORLD_SIZE in the environment it starts the N ranks itself as child processes (self_launch).  Weak scaling, every rank solves its own 2000-timestep
 replay batch per step and the first moves are all-gathered over RCCL; `extra.configs3_sharded` is BASELINE configs[3]
 literally (4096 realisations sharded over the ranks, one all-gather of u0).
 """
@@ -114,6 +118,24 @@ def cpu_cores():
     return n_
 
 
+def self_launch(n_ranks, real_out):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child process
+    and return its exit code.  The child ranks write their one JSON line (rank 0) to this process's real stdout."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s_:                       # a free port on the loop-back interface
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    real_out.flush()
+    return subprocess.run(cmd, env=env, stdout=real_out.fileno(), stderr=2).returncode
+
+
 def main():
     # Libraries (RCCL prints a version banner) write to stdout; the contract is ONE JSON line there.  Everything written to
     # fd 1 from here on goes to stderr, the JSON line goes to the saved descriptor.
@@ -140,6 +162,11 @@ def _main(real_out):
                                                              "configs[1] figure is 1, two in flight is reported as extra.two_in_flight")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks as CHILD processes (one per GPU) before anything here
+        # has touched the GPU, hand them the real stdout for rank 0's JSON line and leave with their exit code.  Never an exec.
+        raise SystemExit(self_launch(args.gpus, real_out))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -147,9 +174,8 @@ def _main(real_out):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    assert args.gpus == world or os.environ.get("FMPC_BENCH_FORCE_DIST", "0") == "1", \
+        "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU path"
     # Rehearsal on a one-GPU box: FMPC_BENCH_REHEARSE=1 puts every rank on device 0 and gathers over gloo
     rehearse = os.environ.get("FMPC_BENCH_REHEARSE", "0") == "1"
@@ -201,7 +227,8 @@ def _main(real_out):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed(step_fn, steps, warmup, min_ms=MIN_LEG_MS, after=None, exact=False, regions=1, all_regions=None):
+    def timed(step_fn, steps, warmup, min_ms=MIN_LEG_MS, after=None, exact=False, regions=1, all_regions=None, dev_regions=None,
+              rank_times=None):
         """W warm-up steps, then `steps` timed steps between barriers -- exactly `steps` for the headline (exact=True),
         otherwise as many more as it takes for the timed region to last min_ms.  regions > 1 (headline): that many timed
         regions of exactly `steps` steps back to back, each bracketed by barrier + synchronize; the MEDIAN region is
@@ -224,16 +251,27 @@ def _main(real_out):
         kern_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
         if world == 1 and not exact:
             steps = max(steps, int(np.ceil(min_ms / max(kern_ms, 1e-3))))
-        times = []
+        times, rev = [], []
         for _ in range(max(1, regions)):
+            ra, rb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            ra.record()                                                 # HIP events on the stream the steps are enqueued on
             for _ in range(steps):
                 step_fn()
+            rb.record()
             if after:
                 after()
             sync()
             times.append(time.perf_counter() - t0)
+            rev.append((ra, rb))
+        if dev_regions is not None:
+            dev_regions.extend(a.elapsed_time(b) * 1e-3 for a, b in rev)     # seconds of device time per region
         if dist_on:
+            if rank_times is not None:                                  # every rank's own median region, gathered
+                mine = torch.tensor([float(np.median(times))], dtype=torch.float64, device="cpu" if rehearse else dev)
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                rank_times.extend(float(v_.item()) for v_ in allr)
             tmax = torch.tensor(times, dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                 # per region: the slowest rank
             times = [float(v_) for v_ in tmax.tolist()]
@@ -325,10 +363,11 @@ def _main(real_out):
             if gather_state["pending"][s_] is not None:
                 gather_state["pending"][s_].wait(); gather_state["pending"][s_] = None
 
-    head_regions = []
+    head_regions, head_dev_regions, head_rank_times = [], [], []
     if depth == 1:
         elapsed, steps_done, kern_ms = timed(head_step, args.steps, args.warmup, after=head_after, exact=True,
-                                             regions=HEAD_REGIONS, all_regions=head_regions)
+                                             regions=HEAD_REGIONS, all_regions=head_regions, dev_regions=head_dev_regions,
+                                             rank_times=head_rank_times)
     else:
         lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev)
         lane_step = lambda: lanes.submit(x0, x0p, None, None, nu0, args.n_newton, K_BAR, after_current=False)
@@ -380,7 +419,12 @@ def _main(real_out):
         by = bytes_streamed_factor(n, m, T) * cb["iters"] / (cb["kernel_ms"] * 1e-3) / 1e9
         ex_unit = executed_mfma_flops_tiled(n, m, T) if "tiled" in best else 6100 * 2048.0     # wave kernel: DESIGN.md §3
         roof_pp = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                   "traffic": None, "kernel": best, "kernel_ms": cb["kernel_ms"],
+                   "traffic": None, "kernel": best, "kernel_ms": cb["kernel_ms"], "ms_per_step": cb["kernel_ms"],
+                   "n_newton_5": {"what": "the same batch with the Newton budget of the reference's test and its exit test (test_fast_mpc.m:53,59, "
+                                          "inf_newton_solver.m:19-22): the setting SURVEY 8d quotes the roofline on",
+                                  "kernel_ms": cb["budget5"]["kernel_ms"], "units_per_launch": cb["budget5"]["iters"],
+                                  "newton_iters_per_problem": cb["budget5"]["iters"] / B,
+                                  "achieved": cb["budget5"]["tflops"], "frac": cb["budget5"]["tflops"] / FP64_PEAK_TFLOPS},
                    "flops_per_unit": fl_unit, "units_per_launch": cb["iters"], "newton_iters_per_problem": cb["iters"] / B,
                    "workload": "configs[1] batch from an explicit start z_init (no shared factor), ONE Newton step: every problem "
                                "factors its own Y exactly once per launch (the per-problem-factor regime of SURVEY 8d); the Newton-"
@@ -671,10 +715,6 @@ def _main(real_out):
 
     if rank == 0:
         units = iters_head
-        f_first = flops_shared_factor(n, m, T) if shared else flops_per_problem_factor(n, m, T)
-        b_first = bytes_compulsory(n, m, T) if shared else bytes_streamed_factor(n, m, T)
-        ach_tf = f_first * units / (kern_ms * 1e-3) / 1e12
-        ach_gbs = b_first * units / (kern_ms * 1e-3) / 1e9
         ex_fl = executed_mfma_flops_panel(m, T, dense) if path == pkg._lib.FMPC_PATH_PANEL else None
         if affine:      # 14 k-steps per 16 x 16 tile of z (T (n + m) rows), + the two decision forms (4 row tiles each); per problem = / 16
             ex_fl = (((T * (n + m) + 15) // 16) * 14 + 2 * 4 * 14) * 2048.0 / 16.0
@@ -691,23 +731,30 @@ def _main(real_out):
                     traffic, traffic_src = cand_t, "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, " + tj.get("tag", "") + ")"
             except Exception:
                 traffic = None
-        roof_cold = {"bound": "mfma", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+        # the headline's own roofline: SURVEY 8d's compulsory bytes per unit x the units of one step / the device time of one
+        # step, from HIP events around every timed region on the launch stream (median region / its steps)
+        ms_step_wall = elapsed / steps_done * 1e3
+        ms_step_dev = (float(np.median(head_dev_regions)) / steps_done * 1e3) if head_dev_regions else ms_step_wall
+        b_unit = bytes_compulsory(n, m, T)
+        head_kernel = (("fmpc_cold_affine<true> (the whole step as one product z+ = zc + Kz [x0; x0_pre] on the matrix cores, decision forms included) "
+                        "+ fmpc_newton_wave<27> (flag mode: %d problems redone exactly)" % handed) if affine else
+                       ((("fmpc_cold_inv_rg<2,4,1,false> (dense form of the dual solve: nu+ = nuc + J [x0; x0_pre], w = NULL)" if dense else "fmpc_cold_panel")
+                         + " + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
+                        if path == pkg._lib.FMPC_PATH_PANEL else "path %d" % path))
+        ach_gbs = b_unit * units / (ms_step_dev * 1e-3) / 1e9
+        roof_head = {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": ("fmpc_cold_affine<true> (the whole step as one product z+ = zc + Kz [x0; x0_pre] on the matrix cores, decision forms included) "
-                                "+ fmpc_newton_wave<27> (flag mode: %d problems redone exactly)" % handed) if affine else
-                               ((("fmpc_cold_inv_rg<2,4,1,false> (dense form of the dual solve: nu+ = nuc + J [x0; x0_pre], w = NULL)" if dense else "fmpc_cold_panel")
-                                 + " + fmpc_cold_dz + fmpc_newton_wave<27> (decision pass; %d problems redone exactly)" % handed)
-                                if path == pkg._lib.FMPC_PATH_PANEL else "path %d" % path),
-                     "kernel_ms": kern_ms, "flops_per_unit": f_first, "units_per_launch": units,
-                     "executed": None if ex_fl is None else {"mfma_flops_per_unit": ex_fl, "tflops": ex_fl * units / (kern_ms * 1e-3) / 1e12,
-                                                              "frac_of_peak": ex_fl * units / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
-                     "hbm": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_unit": b_first},
-                     "note": "the headline's own kernels: SURVEY 8d's shared-factor figure (1.60 MFLOP, 48 KB per unit) x units / device time "
-                             "of one solve (all its kernels, HIP events); `executed` = MFMAs actually issued on padded tiles. With w = NULL "
-                             "the step is affine in [x0; x0_pre]: most of the survey's 1.60 MFLOP (the banded substitutions) are never "
-                             "executed -- the affine form issues 321 x 14 matrix instructions per 16 problems (0.58 MFLOP per problem) "
-                             "and is bound by the matrix pipes -- so `frac` measures speed in the survey's unit of work, not "
-                             "matrix-core utilisation; `executed.frac_of_peak` does"}
+                     "bytes_per_unit": b_unit, "units_per_launch": units, "ms_per_step_device": ms_step_dev, "ms_per_step_wall": ms_step_wall,
+                     "frac_on_wall_clock": b_unit * units / (ms_step_wall * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel": head_kernel, "kernel_ms_one_step_alone": kern_ms,
+                     "executed": None if ex_fl is None else {"mfma_flops_per_unit": ex_fl, "tflops": ex_fl * units / (ms_step_dev * 1e-3) / 1e12,
+                                                              "peak": FP64_PEAK_TFLOPS,
+                                                              "frac_of_peak": ex_fl * units / (ms_step_dev * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                     "note": "what the timed region ran: achieved = 8 (2n + Tn + T(n+m)) = %d B per problem (SURVEY 8d, compulsory: x0, x0_pre in, z out) "
+                             "x problems of a step / device time of a step (HIP events on the launch stream around each timed region of exactly "
+                             "--steps steps; median region). With w = NULL and one Newton step from the cold start the step is affine in [x0; x0_pre] "
+                             "(SURVEY regime (ii), the factor hoisted per (handle, k)), so the kernel is a product whose output is the traffic; "
+                             "`executed` = matrix instructions actually issued on padded tiles against the fp64 peak" % b_unit}
         out = {
             "metric": "MPC steps/sec (n=27, VAR(2), T=30)",
             "value": world * B * steps_done / elapsed,
@@ -733,9 +780,14 @@ def _main(real_out):
                                                                                    1e3 * min(head_regions or [elapsed]), 1e3 * elapsed, 1e3 * max(head_regions or [elapsed])),
                        "buffers": "%d input/output sets solved in turn (%.0f MB of z in rotation: larger than the 256 MB Infinity Cache)" % (HEAD_SETS, HEAD_SETS * B * T * (n + m) * 8 / 1e6),
                        "ranks": world, "rccl_ranks": dist.get_world_size() if dist_on else 1, "device_ordinal": local_rank},
-            "roofline": roof_pp if roof_pp is not None else roof_cold,
-            "roofline_cold_start": roof_cold,
+            "roofline": roof_head,
         }
+        if roof_pp is not None:
+            out["roofline_per_problem_factor"] = roof_pp
+        if dist_on:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend"] = dist.get_backend()
+            out["ms_per_step_by_rank"] = [t_ / steps_done * 1e3 for t_ in head_rank_times]
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
