@@ -312,7 +312,8 @@ int fmpc_last_tiled_wavefronts(fmpc_handle h);
  *   fmpc_set_dense_form: enabled 0/1, max_batch_with_w < 0 keeps the bound.  FMPC_E_UNSUPPORTED if the handle has
  *                        no panel path (n != 27).
  *   fmpc_last_dual_form: 0 = the sweeps, 1 = the dense form of the dual solve, 2 = the AFFINE FORM of the whole step: with
- *                        w == NULL, n_newton == 1 and nu_out == NULL (the reference's replay call, README.md:548-556) the
+ *                        w == NULL and n_newton == 1 (the reference's replay call, README.md:548-556; nu_out is served too
+ *                        when z_out is given: further row tiles of the same product; nu_out WITHOUT z_out takes form 1) the
  *                        step from the cold start is z+ = zc + Kz [x0; x0_pre], one product per batch on the matrix cores
  *                        (Kz built once per (handle, k) with J; the step-length decision from two quadratic forms of the
  *                        data, problems that are not clear-cut redone by the exact path: tests/test_gpu_affine.py).

@@ -98,11 +98,17 @@ def load():
     # process: with this library first (it resolves /opt/rocm's), a later `import torch` brings a second runtime and the
     # library's hipGetDeviceCount then finds no device.  Let torch, when installed, go first; plain C / ctypes clients
     # without torch are unaffected.
-    if "torch" not in sys.modules:
+    # FMPC_NO_TORCH_PRELOAD=1 opts out (a plain ctypes / numpy client that never imports torch saves its import time and
+    # keeps /opt/rocm's runtime); a torch that fails to import is reported, not hidden.
+    if "torch" not in sys.modules and os.environ.get("FMPC_NO_TORCH_PRELOAD", "0") != "1":
         try:
             import torch  # noqa: F401
-        except Exception:
-            pass
+        except ImportError:
+            pass                                           # no torch installed: nothing to order
+        except Exception as e:                             # a broken install: say so, the library may then see no device
+            import warnings
+            warnings.warn(f"mpc-sensorlessao_amd: `import torch` failed ({e!r}); loading {LIB_PATH} with the system HIP runtime. "
+                          "If a later torch import brings its own runtime the library will report FMPC_E_NO_DEVICE.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

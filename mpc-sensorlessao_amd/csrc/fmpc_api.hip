@@ -1511,7 +1511,8 @@ static int fmpc_loop_step_impl(fmpc_handle h, int batch, const double* a_k, cons
     int rc = fmpc_guard_begin(h, (hipStream_t)stream);
     if (rc != FMPC_OK) return rc;
     const bool lr = h->inv_enabled && h->inv_jimg2 != nullptr && h->n == FP_N;
-    if (lr && !z_out && !nu_out && n_newton == 1) {
+    // (a handle switched to the fp32 factor or to FMPC_TILED=1 takes the kernel it was switched to, whatever outputs are asked for)
+    if (lr && !z_out && !nu_out && n_newton == 1 && h->prec == FMPC_PREC_F64 && !h->force_tiled) {
         // first moves only, a few realisations: one launch instead of four (falls through when the form does not apply)
         // few realisations: a workgroup per realisation (fmpc_first_move); from fs_min_batch on (default 65, FMPC_PRODUCT_MIN_BATCH)
         // the product form, whose 16 workgroups per 16 realisations spread the constants over as many CUs

@@ -305,7 +305,10 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
                     *dst = acc[ct][r];
                 }
         }
-        if (P.u0out != nullptr && 16 * tile < m) {               // uniform: the first m rows again, as the first moves
+        // Without z (ZOUT = false) the first moves are the ONLY stores behind the request above: they must not sit under a
+        // condition, or a wavefront that skipped them would pass fa_await_a<16> with its 14 loads still in flight (found by
+        // tests/test_isa_affine_hazard.py; the launcher only deals the tiles 16 t < m then, and rows >= m go to the dump line).
+        if (!ZOUT || (P.u0out != nullptr && 16 * tile < m)) {    // uniform: the first m rows again, as the first moves
             const unsigned vou = (unsigned)(g * m + row);
             const bool rok = row < m;
 #pragma unroll
@@ -334,6 +337,7 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
 
 hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream) {
     if (P.n != 27 || 2 * P.n + 2 > FA_KC || 7 * FA_THREADS < FA_CT * 16 * P.n) return hipErrorInvalidValue;
+    if (!P.zout && !P.u0out) return hipErrorInvalidValue;         // (fmpc_cold_affine<false> stores the first moves unconditionally)
     const int ncol = (P.batch + 15) / 16, ngroups = (ncol + FA_CT - 1) / FA_CT;
     P.tiles_used = P.zout ? P.tiles + (P.nuout ? P.nu_tiles : 0) : (P.m + 15) / 16;
     // two workgroups of four wavefronts per CU are resident: that many workgroups share the groups of 64 problems (a workgroup

@@ -2,7 +2,7 @@
 // host builders (fmpc_host.cpp) also compile with a plain C++ compiler (the sanitizer build of tests/host_san).
 #pragma once
 #include <stddef.h>
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FMPC_HD __host__ __device__
 #else
 #define FMPC_HD

@@ -371,6 +371,9 @@ def backtracking_inf_newton(z, nu, del_z, del_nu, rp, rd, al, bt, info=None):
     if info is not None:
         info.setdefault("t", []).append(t)
         info.setdefault("halvings", []).append(halvings)
+        # diagnostics for the property tests: the norm the literal test compared at the accepted t, and the one at the start
+        info.setdefault("n_before", []).append(n0)
+        info.setdefault("n_after", []).append(np.linalg.norm(np.concatenate([rp(z + t * del_z), rd(z + t * del_z, nu + t * del_nu)])))
     return z + t * del_z, nu + t * del_nu
 
 
