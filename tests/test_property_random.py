@@ -113,8 +113,11 @@ def _gpu_cases():
         if i == 2:
             n, m, T = 3, 1, 1
         dense_q = bool(rng.integers(0, 4) == 0); dense_r = bool(rng.integers(0, 5) == 0) and m <= 64
+        # (terminal rows x_T = xf only where the horizon has the controls to reach them: with T m < 2 n the equality rows are
+        #  rank deficient or nearly so, chol(Y) fails in the reference too, and WHICH problems fail is decided by round-off)
+        xf_ok = T * m >= 2 * n
         cases.append(dict(seed=1000 + i, n=n, m=m, T=T, var_order=int(rng.integers(1, 3)), dense_q=dense_q, dense_r=dense_r,
-                          xf=bool(rng.integers(0, 3) == 0), lin=bool(rng.integers(0, 2)), k=float(rng.choice([1e-2, 1e-1, 1.0])),
+                          xf=bool(rng.integers(0, 3) == 0) and xf_ok, lin=bool(rng.integers(0, 2)), k=float(rng.choice([1e-2, 1e-1, 1.0])),
                           nw=int(rng.integers(1, 6)), warm=bool(rng.integers(0, 2)), batch=int(rng.integers(5, 7))))
     return cases
 
@@ -133,13 +136,16 @@ def test_hip_equals_structured_oracle_on_random_problems(pkg, gpu):
         except pkg.FastMPCError as e:
             assert e.code == pkg._lib.FMPC_E_UNSUPPORTED, (c, e)          # e.g. a dense R whose factor does not fit the LDS
             continue
-        z, info = h.solve(data["x0"], data["x0_pre"], data["w"], z_init=zi, nu0=data["nu0"], n_newton=c["nw"], k=c["k"], return_info=True)
+        z, info = h.solve(data["x0"], data["x0_pre"], data["w"], z_init=zi, nu0=data["nu0"], n_newton=c["nw"], k=c["k"], return_info=True,
+                          check=False)
         zo, nuo, ito, sto, steps = oracle_batch(model, data, c["nw"], c["k"], z_init=zi)
+        assert np.array_equal(info["status"], sto), (c, info["status"], sto)
+        assert (sto >= 0).all(), (c, sto)                              # the generator keeps the problems well posed
         for p in range(c["batch"]):
             e = rel_err(z[p], zo[p])
             worst = max(worst, e)
             assert e <= 1e-9, (c, p, e)
-        assert np.array_equal(info["iters"], ito) and np.array_equal(info["status"], sto), c
+        assert np.array_equal(info["iters"], ito), c
         solved += c["batch"]
         h.close()
     assert solved >= 200, solved
