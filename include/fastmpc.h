@@ -325,9 +325,12 @@ int fmpc_last_tiled_wavefronts(fmpc_handle h);
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)
- * run on the tiled kernel with 2-4 wavefronts per problem (tiled = 1, default: lowest latency of ONE call) or on the
+ * run on the tiled kernel with TWO wavefronts per problem (tiled = 1, default: lowest latency of ONE call) or on the
  * one-wavefront kernel (tiled = 0: its single wavefronts share the chip better when many handles have solves in flight at the
- * same time; bench.py `budget5_in_flight_12`).  Environment FMPC_NO_SMALL_TILED=1 = tiled 0 at create time. */
+ * same time; bench.py `budget5_in_flight_12`).  tiled = 4 opts in to FOUR wavefronts per problem for batches of at most 512
+ * and for continuations (about 10 % lower latency of one call; not the default since round 4: a sibling instance of the
+ * four-wavefront fp64 kernel was miscompiled by an earlier build and the cause was never established -- DESIGN.md).
+ * Environment at create time: FMPC_NO_SMALL_TILED=1 = tiled 0, FMPC_SMALL_TILED_NW=4 = tiled 4. */
 int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled);
 int fmpc_last_dual_form(fmpc_handle h);
 

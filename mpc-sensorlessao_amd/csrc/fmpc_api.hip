@@ -136,6 +136,8 @@ struct fmpc_handle_s {
     double* tl_ws; size_t tl_ws_doubles; int tl_prepared;         // (bit NW: that wavefront count of the fp64 instance is prepared)
     int tl_last_nw;                       // wavefronts per problem of the last tiled launch (diagnostic)
     int small_tiled;                      // per-problem-factor solves of few problems go to the tiled kernel (FMPC_NO_SMALL_TILED=1: off)
+    int small_nw;                         // ... with this many wavefronts per problem: 2 (default) or 4 (FMPC_SMALL_TILED_NW=4 /
+                                          // fmpc_set_small_batch_kernel(h, 4): opt-in, see the note at FT_DISPATCH in fmpc_kernel_tiled.hip)
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
     int denseQ;                          // Q or Qf not diagonal: tiled kernel only
@@ -304,6 +306,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
     { const char* ns = getenv("FMPC_NO_SMALL_TILED"); h->small_tiled = (ns && ns[0] == '1') ? 0 : 1; }
+    { const char* nw = getenv("FMPC_SMALL_TILED_NW"); h->small_nw = (nw && nw[0] == '4') ? 4 : 2; }
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
@@ -1285,7 +1288,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     const int last = ((volatile int*)h->pn_cnt_host)[1];
                     const int hint = last >= 0 ? last + last / 2 + 16 : 0;
                     const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters,
-                                                      step, u0_out, (hipStream_t)stream, 4, h->pn_list, h->pn_cnt + 1, h->pn_nuws, hint);
+                                                      step, u0_out, (hipStream_t)stream, h->small_nw, h->pn_list, h->pn_cnt + 1, h->pn_nuws, hint);
                     if (rc_t == FMPC_OK) continue;
                     // (no workspace for the tiled kernel: the panel, d_z and decision kernels are already enqueued -- the
                     // one-wavefront kernel below, whose workspace exists, finishes the solve instead of aborting it half-way)
@@ -1307,7 +1310,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             // 2 (4) wavefronts per problem finish a problem in 0.5 (0.4) ms where the one-wavefront kernel needs 1.0 ms;
             // beyond 1024 problems the one-wavefront kernel's 8 problems per CU win (measured: scripts/latency_190.py)
             const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
-                                              u0_out, (hipStream_t)stream, batch <= 512 ? 4 : 2);
+                                              u0_out, (hipStream_t)stream, batch <= 512 ? h->small_nw : 2);
             if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
@@ -1702,6 +1705,7 @@ extern "C" int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled) {
     if (!h) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(h->mu);
     h->small_tiled = tiled ? 1 : 0;
+    if (tiled) h->small_nw = tiled == 4 ? 4 : 2;
     return FMPC_OK;
 }
 

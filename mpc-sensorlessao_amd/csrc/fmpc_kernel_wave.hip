@@ -28,7 +28,9 @@
 #include "fmpc_device.h"
 #include "../../include/fastmpc.h"
 
+#ifndef FW_WAVES
 #define FW_WAVES 8
+#endif
 #define FW_THREADS (FW_WAVES * 64)
 #define FW_MAX_HALVINGS 64
 #define FW_LDB 33                       // leading dimension of B' in LDS (odd)
@@ -45,6 +47,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 typedef __attribute__((address_space(3))) double* fw_lds_t;
 typedef const __attribute__((address_space(3))) double* fw_clds_t;
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) d2v* fw_c2lds_t;
 #define FW_FN __device__ __noinline__
 #define FW_IN __device__ __forceinline__          // sub-phase of a merged phase function (below)
 
@@ -1075,6 +1079,10 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
     const fw_lds_t tA = lds + mp * FW_LDB + wv * C::PER_WAVE;
     const fw_lds_t tB = tA + C::TILE;
     const double* imgs = P->V.img;
+    // experiment (FMPC_WAVE_FLAGS bits 0-7): the second half of the workgroup's wavefronts -- the SIMD partners of the first
+    // half -- enters the factorisation that many units of 1024 cycles late, so that a SIMD's two problems are half a stage apart
+    if ((P->flags & 0xff) && wv >= FW_WAVES / 2)
+        for (int q = 0; q < (P->flags & 0xff); ++q) __builtin_amdgcn_s_sleep(16);
     FW_T0();
 
     d4 Ua[2][2], Ub[2][2], Uc[2][2];
@@ -1260,6 +1268,53 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             if (lane == 0) myrs = rs;
             colb[lane] = lk;
         }
+#ifdef FW_BCAST128
+        // Column k of L from LDS as ALIGNED 16-byte pieces (ds_read_b128, one address for all lanes: 4 LDS cycles per two
+        // entries where ds_read2_b64 takes 8 -- the eight wavefronts of a CU factor in lock-step and the broadcasts of the
+        // column were most of the LDS pipe's time, scripts/probes/dp_valu_rate.hip): the pieces start at the even index
+        // (k + 1) & ~1, an entry in front of column k's first sub-diagonal one is read and not used.
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            fw_wave_fence();
+            const fw_c2lds_t cb2 = (fw_c2lds_t)(colb + (k & 1) * 64);  // L[c][k]: one address for all lanes
+            constexpr int CP = CH / 2;
+            const int clo = (k + 1) & ~1;                              // (compile-time: the loop is unrolled)
+            d2v lc2[CP];
+#pragma unroll
+            for (int q = 0; q < CP; ++q) lc2[q] = cb2[(clo + 2 * q < N ? clo + 2 * q : (N - 1) & ~1) >> 1];
+            double lkn = 0.0, xkn = 0.0;
+            if (k + 1 < N) {
+                const double l1 = fw_readlane(lk, k + 1);
+                row[k + 1] = fma(-lk, l1, row[k + 1]);
+                x[k + 1] = fma(-l1, xk, x[k + 1]);
+                const double d = fw_readlane(row[k + 1], k + 1);
+                if (!(d > 0.0) || isinf(d)) notpd = 1;
+                const double rs = fw_rsqrt(d);
+                lkn = row[k + 1] * rs; xkn = x[k + 1] * rs;
+                row[k + 1] = lkn; x[k + 1] = xkn;
+                if (lane == k + 1) myrs = rs;
+                colb[((k + 1) & 1) * 64 + lane] = lkn;
+            }
+#pragma unroll
+            for (int c0 = clo; c0 < N; c0 += CH) {
+                d2v ln2[CP];
+                if (c0 + CH < N) {
+#pragma unroll
+                    for (int q = 0; q < CP; ++q) ln2[q] = cb2[(c0 + CH + 2 * q < N ? c0 + CH + 2 * q : (N - 1) & ~1) >> 1];
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int c = c0 + q;
+                    const double lcq = (q & 1) ? lc2[q >> 1].y : lc2[q >> 1].x;
+                    if (c > k + 1 && c < N) { row[c] = fma(-lk, lcq, row[c]); x[c] = fma(-lcq, xk, x[c]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < CP; ++q) lc2[q] = ln2[q];
+            }
+            lk = lkn; xk = xkn;
+        }
+#else
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             fw_wave_fence();
@@ -1301,6 +1356,7 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             }
             lk = lkn; xk = xkn;
         }
+#endif
         fw_wave_fence();
         FW_TICK(2);
         // ---- results: U1|y -> tB, U2|y -> tA (layout change) and the factor to HBM
@@ -1440,8 +1496,10 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int j = 0; j < N; ++j) tA[j * LD + lc] = g1[j];
         fw_wave_fence();
+#ifndef FW_KO_BWD_LOADS
 #pragma unroll
         for (int j = 0; j < N; ++j) g1[j] = fp[u1o + j * LDG];
+#endif
         yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
         double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
         {
@@ -1456,8 +1514,13 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         // forward substitution  w = L^-1 cc  (lane r holds row r of L in gl: gl[k] = L[r][k]);  v -= w
         {
             double wres = 0.0;
+#ifdef FW_KO_BWD_CHAIN
+#pragma unroll
+            for (int k = 0; k < 1; ++k) {
+#else
 #pragma unroll
             for (int k = 0; k < N; ++k) {
+#endif
                 const double wk = fw_readlane(cc * rsv, k);
                 if (lane == k) wres = wk;
                 cc = fma(-gl[k], wk, cc);          // meaningful on lanes > k only
@@ -1469,13 +1532,20 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int j = 0; j < N; ++j) tB[j * LD + lc] = gl[j];
         fw_wave_fence();
+#ifndef FW_KO_BWD_LOADS
 #pragma unroll
         for (int j = 0; j < N; ++j) gl[j] = fp[(ex ? j * LDG : C::LOFF(j) - j) + lo];      // (lanes above the diagonal read the tail of an earlier column: unused)
+#endif
         double res = 0.0;
         {
             const fw_clds_t cl = tB + lr * LD;
+#ifdef FW_KO_BWD_CHAIN
+#pragma unroll
+            for (int r = N - 1; r >= N - 1; --r) {
+#else
 #pragma unroll
             for (int r = N - 1; r >= 0; --r) {
+#endif
                 const double xr = fw_readlane(v * rsv, r);
                 if (lane == r) res = xr;
                 v = fma(-cl[r], xr, v);        // meaningful on lanes < r only
@@ -1503,7 +1573,7 @@ template <int N, int BWD>
 FW_FN void fw_phase_sweep_shared(FwKP Pin, int p, int go, double* lds_g) {
     using C = FwCfg<N>;
     constexpr int LDG = C::LDG, TS = N * LDG, ST = 3 * TS, NPRE = (ST + FW_THREADS - 1) / FW_THREADS;
-    static_assert(2 * ST + FW_WAVES * FW_VEC_STRIDE + 4 * 192 <= FW_WAVES * C::PER_WAVE, "stage buffers + vectors must fit the tile region");
+    static_assert(FW_WAVES != 8 || 2 * ST + FW_WAVES * FW_VEC_STRIDE + 4 * 192 <= FW_WAVES * C::PER_WAVE, "stage buffers + vectors must fit the tile region");   // (experiment builds with FW_WAVES != 8 run the explicit-start path only)
     const FwKP P = fw_uniform(Pin);
     p = __builtin_amdgcn_readfirstlane(p);
     go = __builtin_amdgcn_readfirstlane(go);
@@ -1678,7 +1748,13 @@ FW_PH int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
     const FwKP P = fw_uniform(Pin);
     if (P->mode == FW_MODE_EXPORT && (threadIdx.x & 63) == 0) *P->sh_ok = npd ? 0 : 1;
     if (npd) return 1;
+#ifdef FW_TIMING
+    const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
     fw_phase_backward<N>(Pin, p, lds_g);
+#ifdef FW_TIMING
+    if ((threadIdx.x & 63) == 0) atomicAdd(&fw_timing[12], __builtin_readcyclecounter() - tb0);
+#endif
     return 0;
 }
 template <int N> FW_FN void fw_phase_zfix(FwKP Pin, int p, double t);
