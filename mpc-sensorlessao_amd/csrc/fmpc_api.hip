@@ -160,6 +160,7 @@ struct fmpc_handle_s {
     // staging for the host-pointer entry points
     void* stage;
     size_t stage_bytes;
+    void* pin; size_t pin_bytes;         // pinned host twin of the staging block for small host-pointer solves (fmpc_solve_host)
 };
 
 extern "C" int fmpc_version(void) { return FMPC_VERSION; }
@@ -299,6 +300,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->nb = T + h->has_xf; h->device = device;
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0; h->zs = nullptr; h->zs_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
+    h->pin = nullptr; h->pin_bytes = 0;
     h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
     h->generic_ok = generic_ok ? 1 : 0;
@@ -598,6 +600,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->zs) (void)hipFree(h->zs);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return FMPC_OK;
 }
@@ -1799,6 +1802,13 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
 }
 
 // host-pointer solve; u_prev != NULL selects the ramp-rate path
+// Host-pointer entries (fmpc_solve, fmpc_solve_ramp, fmpc_solve_once): stage in, solve, stage out.
+// One device block holds the inputs that are present, then the outputs that are asked for.  Up to FMPC_PIN_LIMIT bytes (the
+// literal drop-in call: ONE problem per timestep, README.md:548-556) the block has a PINNED host twin kept by the handle: the
+// inputs are packed into it and go up in ONE asynchronous copy, the outputs come back in ONE, and the call waits once -- two
+// transfers and one synchronisation where round 3 issued up to six blocking hipMemcpy each way (163 us per call).  Larger
+// batches are bandwidth-bound and copy straight between the caller's arrays and the device block.
+#define FMPC_PIN_LIMIT ((size_t)1 << 20)
 static int fmpc_solve_host(fmpc_handle h, int batch,
                            const double* x0, const double* x0_pre, const double* w, const double* u_prev,
                            const double* z_init, const double* nu0,
@@ -1811,14 +1821,17 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     std::lock_guard<std::mutex> host_lk(h->host_mu);
     const size_t n = h->n, Nz = (size_t)h->T * (h->n + h->m), nbn = (size_t)h->nb * h->n;
     const size_t Tn = (size_t)h->T * h->n, sld = fmpc_step_ld(n_newton), B = batch;
-    // one device staging block: inputs then outputs
     size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_x0 = take(n * B * 8), o_x0p = take(n * B * 8), o_w = take(Tn * B * 8);
-    const size_t o_zi = take(Nz * B * 8), o_nu0 = take(nbn * B * 8), o_z = take(Nz * B * 8);
-    const size_t o_nu = take(nbn * B * 8), o_st = take(B * 4), o_it = take(B * 4), o_step = take(sld * B * 8);
-    const size_t o_up = take(u_prev ? (size_t)h->m * B * 8 : 0);
+    auto take = [&](bool present, size_t bytes) { if (!present) return (size_t)0; size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_x0 = take(true, n * B * 8), o_x0p = take(x0_pre != nullptr, n * B * 8), o_w = take(w != nullptr, Tn * B * 8);
+    const size_t o_zi = take(z_init != nullptr, Nz * B * 8), o_nu0 = take(nu0 != nullptr, nbn * B * 8);
+    const size_t o_up = take(u_prev != nullptr, (size_t)h->m * B * 8);
+    const size_t in_bytes = off;
+    const size_t o_z = take(true, Nz * B * 8), o_nu = take(nu_out != nullptr, nbn * B * 8);
+    const size_t o_st = take(true, B * 4), o_it = take(true, B * 4), o_step = take(step != nullptr, sld * B * 8);
+    const bool pinned = off <= FMPC_PIN_LIMIT;
     char* base;
+    char* pin = nullptr;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         if (off > h->stage_bytes) {
@@ -1827,36 +1840,57 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
             h->stage_bytes = off;
         }
         base = (char*)h->stage;
+        if (pinned) {
+            if (off > h->pin_bytes) {
+                if (h->pin) { (void)hipDeviceSynchronize(); (void)hipHostFree(h->pin); h->pin = nullptr; h->pin_bytes = 0; }
+                size_t want = 64 * 1024;
+                while (want < off) want *= 2;
+                if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) == hipSuccess) h->pin_bytes = want;
+                else h->pin = nullptr;                              // (no pinned memory: the blocking copies below still work)
+            }
+            pin = (char*)h->pin;
+        }
     }
-    auto up = [&](size_t o, const double* src, size_t cnt) -> const double* {
-        if (!src) return nullptr;
-        if (hipMemcpy(base + o, src, cnt * 8, hipMemcpyHostToDevice) != hipSuccess) return (const double*)-1;
-        return (const double*)(base + o);
-    };
-    const double* d_x0 = up(o_x0, x0, n * B);
-    const double* d_x0p = up(o_x0p, x0_pre, n * B);
-    const double* d_w = up(o_w, w, Tn * B);
-    const double* d_zi = up(o_zi, z_init, Nz * B);
-    const double* d_nu0 = up(o_nu0, nu0, nbn * B);
-    const double* d_up = up(o_up, u_prev, (size_t)h->m * B);
-    const double* bad = (const double*)-1;
-    if (d_x0 == bad || d_x0p == bad || d_w == bad || d_zi == bad || d_nu0 == bad || d_up == bad) return FMPC_E_HIP;
+    auto dptr = [&](const void* src, size_t o) -> const double* { return src ? (const double*)(base + o) : nullptr; };
+    if (pin) {
+        auto pack = [&](size_t o, const double* src, size_t cnt) { if (src) memcpy(pin + o, src, cnt * 8); };
+        pack(o_x0, x0, n * B); pack(o_x0p, x0_pre, n * B); pack(o_w, w, Tn * B); pack(o_zi, z_init, Nz * B); pack(o_nu0, nu0, nbn * B);
+        pack(o_up, u_prev, (size_t)h->m * B);
+        if (hipMemcpyAsync(base, pin, in_bytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) return FMPC_E_HIP;
+    } else {
+        auto up = [&](size_t o, const double* src, size_t cnt) { return !src || hipMemcpy(base + o, src, cnt * 8, hipMemcpyHostToDevice) == hipSuccess; };
+        if (!up(o_x0, x0, n * B) || !up(o_x0p, x0_pre, n * B) || !up(o_w, w, Tn * B) || !up(o_zi, z_init, Nz * B) || !up(o_nu0, nu0, nbn * B) ||
+            !up(o_up, u_prev, (size_t)h->m * B)) return FMPC_E_HIP;
+    }
     int* d_st = (int*)(base + o_st);
     int* d_it = (int*)(base + o_it);
-    int rc = u_prev ? fmpc_solve_ramp_device(h, batch, d_x0, d_x0p, d_w, d_up, d_zi, d_nu0, n_newton, k,
-                                             (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
-                                             step ? (double*)(base + o_step) : nullptr, nullptr)
-                    : fmpc_solve_device(h, batch, d_x0, d_x0p, d_w, d_zi, d_nu0, n_newton, k,
-                                        (double*)(base + o_z), (double*)(base + o_nu), d_st, d_it,
-                                        step ? (double*)(base + o_step) : nullptr, nullptr);
-    if (rc != FMPC_OK) return rc;
-    if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
-    std::vector<int> st(B);
-    if (hipMemcpy(z_out, base + o_z, Nz * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
-    if (nu_out && hipMemcpy(nu_out, base + o_nu, nbn * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
-    if (hipMemcpy(st.data(), d_st, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
-    if (iters && hipMemcpy(iters, d_it, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
-    if (step && hipMemcpy(step, base + o_step, sld * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+    double* d_nu = nu_out ? (double*)(base + o_nu) : nullptr;
+    double* d_step = step ? (double*)(base + o_step) : nullptr;
+    int rc = u_prev ? fmpc_solve_ramp_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(u_prev, o_up), dptr(z_init, o_zi),
+                                             dptr(nu0, o_nu0), n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr)
+                    : fmpc_solve_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
+                                        n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr);
+    if (rc != FMPC_OK) { (void)hipDeviceSynchronize(); return rc; }
+    std::vector<int> stv;
+    const int* st;
+    if (pin) {
+        if (hipMemcpyAsync(pin + o_z, base + o_z, off - o_z, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return FMPC_E_HIP;
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return FMPC_E_HIP;
+        memcpy(z_out, pin + o_z, Nz * B * 8);
+        if (nu_out) memcpy(nu_out, pin + o_nu, nbn * B * 8);
+        if (iters) memcpy(iters, pin + o_it, B * 4);
+        if (step) memcpy(step, pin + o_step, sld * B * 8);
+        st = (const int*)(pin + o_st);
+    } else {
+        if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
+        stv.resize(B);
+        if (hipMemcpy(z_out, base + o_z, Nz * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (nu_out && hipMemcpy(nu_out, base + o_nu, nbn * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (hipMemcpy(stv.data(), d_st, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (iters && hipMemcpy(iters, d_it, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (step && hipMemcpy(step, base + o_step, sld * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        st = stv.data();
+    }
     int worst = FMPC_OK;
     for (size_t i = 0; i < B; ++i) {
         if (status) status[i] = st[i];
@@ -1977,19 +2011,33 @@ extern "C" int fmpc_solve_once(int n, int m, int T, int var_order,
     if (!A1 || !B || (var_order == 2 && !A2)) return FMPC_E_NULL;
     if (!Q || !R || !Qf || !x_min || !x_max || !u_min || !u_max) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(once_mu);                  // (also keeps an entry alive while it is in use)
-    std::vector<double> key;
-    key.reserve((size_t)2 * n * n + (size_t)n * m + (size_t)m * m + 8 * (size_t)(n + m) + 32);
+    // The model of a call is compared IN PLACE against the stored keys (same record format as fmpc_host_key_push: a count or -1,
+    // then the values): a hit -- every call but the first of a simulation -- builds no key (round 3 copied ~220 KB per call,
+    // most of it the m x m matrix R, before comparing it).
     const double dims[5] = {(double)n, (double)m, (double)T, (double)var_order, (double)device};
-    fmpc_host_key_push(key, dims, 5);
     const size_t nn = (size_t)n * n;
-    fmpc_host_key_push(key, A1, nn); fmpc_host_key_push(key, var_order == 2 ? A2 : nullptr, nn); fmpc_host_key_push(key, B, (size_t)n * m);
-    fmpc_host_key_push(key, Q, nn); fmpc_host_key_push(key, R, (size_t)m * m); fmpc_host_key_push(key, Qf, nn);
-    fmpc_host_key_push(key, q, n); fmpc_host_key_push(key, r, m); fmpc_host_key_push(key, qf, n);
-    fmpc_host_key_push(key, x_min, n); fmpc_host_key_push(key, x_max, n); fmpc_host_key_push(key, u_min, m); fmpc_host_key_push(key, u_max, m);
-    fmpc_host_key_push(key, xf, n);
-    FmpcLru<fmpc_handle>::Entry* ent = once_cache.find(key);
+    struct Seg { const double* p; size_t cnt; };
+    const Seg segs[15] = {{dims, 5}, {A1, nn}, {var_order == 2 ? A2 : nullptr, nn}, {B, (size_t)n * m}, {Q, nn}, {R, (size_t)m * m}, {Qf, nn},
+                          {q, (size_t)n}, {r, (size_t)m}, {qf, (size_t)n}, {x_min, (size_t)n}, {x_max, (size_t)n}, {u_min, (size_t)m},
+                          {u_max, (size_t)m}, {xf, (size_t)n}};
+    size_t key_len = 0;
+    for (const Seg& sg : segs) key_len += 1 + (sg.p ? sg.cnt : 0);
+    FmpcLru<fmpc_handle>::Entry* ent = nullptr;
+    for (auto& e : once_cache.items) {
+        if (e.key.size() != key_len) continue;
+        const double* kp = e.key.data();
+        bool same = true;
+        for (const Seg& sg : segs) {
+            if (*kp++ != (sg.p ? (double)sg.cnt : -1.0)) { same = false; break; }
+            if (sg.p) { if (memcmp(kp, sg.p, sg.cnt * sizeof(double)) != 0) { same = false; break; } kp += sg.cnt; }
+        }
+        if (same) { ent = &e; break; }
+    }
     int rc;
     if (!ent) {
+        std::vector<double> key;
+        key.reserve(key_len);
+        for (const Seg& sg : segs) fmpc_host_key_push(key, sg.p, sg.cnt);
         fmpc_handle h = nullptr;
         rc = fmpc_create(&h, n, m, T, var_order, A1, A2, B, Q, R, Qf, q, r, qf, x_min, x_max, u_min, u_max, xf, device);
         if (rc != FMPC_OK) return rc;

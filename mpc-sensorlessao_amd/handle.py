@@ -101,10 +101,13 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_set_precision")
 
     def solve(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2,
-              return_info=False, check=True, u_prev=None):
+              return_info=False, check=True, u_prev=None, z_out=None):
         """One `inf_newton_solver` per problem.  x0: (batch, n) or (n,).  Returns z (batch, N_z)
         (or (N_z,) for a single vector input); with return_info also a dict nu/status/iters/step.
-        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`)."""
+        u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`).
+        z_out: a (batch, N_z) float64 C-contiguous array to receive z (a caller that solves batch after batch keeps ONE output
+        array: the first touch of a fresh 82 MB array costs more than the solve and both transfers); nu is then only produced
+        with return_info."""
         single = np.asarray(x0).ndim == 1
         x0 = _f64(x0)
         batch = 1 if single else x0.shape[0]
@@ -115,8 +118,13 @@ class FastMPCHandle:
         nu0 = _f64(nu0, (batch, self.nu_len), "nu0")
         n_newton = 0 if n_newton is None else int(n_newton)
         sld = self._lib.fmpc_step_ld(n_newton)
-        z = np.empty((batch, self.nz))
-        nu = np.empty((batch, self.nu_len))
+        if z_out is not None:
+            if not (isinstance(z_out, np.ndarray) and z_out.dtype == np.float64 and z_out.flags.c_contiguous and z_out.shape == (batch, self.nz)):
+                raise FastMPCError(_lib.FMPC_E_DIM, "z_out must be a C-contiguous float64 array of shape (batch, N_z)")
+            z = z_out
+        else:
+            z = np.empty((batch, self.nz))
+        nu = np.empty((batch, self.nu_len)) if (return_info or z_out is None) else None
         status = np.zeros(batch, dtype=np.int32)
         iters = np.zeros(batch, dtype=np.int32)
         step = np.empty((batch, sld))

@@ -372,3 +372,42 @@ def test_first_moves_only_output(pkg, gpu, case):
                                       None, None, None, None, None, None)
     assert rc == pkg._lib.FMPC_E_NULL
     h.close()
+
+
+@pytest.mark.gpu
+def test_host_pointer_entry_pinned_and_direct_staging_and_output_reuse(pkg, gpu):
+    """fmpc_solve with host pointers: up to 1 MB of staging the inputs / outputs travel through the handle's pinned twin block in
+    one asynchronous copy each way (the literal per-timestep call, README.md:548-556), beyond that straight from / to the
+    caller's arrays.  Both must give what the device-pointer entry gives, with every combination of optional inputs and
+    outputs (absent inputs take no room in the block), and z_out= must write into the caller's array."""
+    import torch
+    md = pkg.synthetic.make_model(27, 144, 6)
+    h = handle_from_model(pkg, md)
+    rng = np.random.default_rng(3)
+    for B in (1, 3, 40):                               # 40 problems x 8.2 KB of z + nu ... > 1 MB? no: (27+144)*6*8 = 8.2 KB -> pinned; see below
+        d = pkg.synthetic.make_replay_batch(md, r=7, steps=B)
+        w = 0.01 * rng.standard_normal((B, 6 * 27))
+        zi = np.tile(np.concatenate([np.zeros(144), np.zeros(27)]), (B, 6)) + 0.1 * rng.standard_normal((B, 6 * 171))
+        for kw in (dict(), dict(w=w), dict(z_init=zi), dict(w=w, z_init=zi, nu0=None)):
+            nu0 = kw.pop("nu0", d["nu0"])
+            z, info = h.solve(d["x0"], d["x0_pre"], kw.get("w"), z_init=kw.get("z_init"), nu0=nu0, n_newton=2, k=1e-2, return_info=True)
+            t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+            nu_d = torch.empty((B, h.nu_len), dtype=torch.float64, device=gpu)
+            zd, st, it = h.solve_device(t(d["x0"]), t(d["x0_pre"]), t(kw.get("w")), t(kw.get("z_init")), t(nu0), 2, 1e-2, nu_out=nu_d)
+            torch.cuda.synchronize()
+            assert np.array_equal(z, zd.cpu().numpy()) and np.array_equal(info["nu"], nu_d.cpu().numpy())
+            assert np.array_equal(info["iters"], it.cpu().numpy()) and np.array_equal(info["status"], st.cpu().numpy())
+            keep = np.full_like(z, np.nan)
+            z2 = h.solve(d["x0"], d["x0_pre"], kw.get("w"), z_init=kw.get("z_init"), nu0=nu0, n_newton=2, k=1e-2, z_out=keep)
+            assert z2 is keep and np.array_equal(keep, z)
+    h.close()
+    # beyond the pinned block: T = 30, 40 problems = 1.6 MB of z
+    md = pkg.synthetic.make_model(27, 144, 30)
+    h = handle_from_model(pkg, md)
+    d = pkg.synthetic.make_replay_batch(md, r=8, steps=40)
+    z, info = h.solve(d["x0"], d["x0_pre"], None, nu0=d["nu0"], n_newton=1, k=1e-2, return_info=True)
+    z1 = np.stack([h.solve(d["x0"][p], d["x0_pre"][p], None, nu0=d["nu0"][p], n_newton=1, k=1e-2) for p in range(40)])   # pinned, one by one
+    assert np.array_equal(z, z1)
+    with pytest.raises(pkg.FastMPCError):
+        h.solve(d["x0"], d["x0_pre"], None, nu0=d["nu0"], z_out=np.empty((39, h.nz)))
+    h.close()

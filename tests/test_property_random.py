@@ -113,9 +113,10 @@ def _gpu_cases():
         if i == 2:
             n, m, T = 3, 1, 1
         dense_q = bool(rng.integers(0, 4) == 0); dense_r = bool(rng.integers(0, 5) == 0) and m <= 64
-        # (terminal rows x_T = xf only where the horizon has the controls to reach them: with T m < 2 n the equality rows are
-        #  rank deficient or nearly so, chol(Y) fails in the reference too, and WHICH problems fail is decided by round-off)
-        xf_ok = T * m >= 2 * n
+        # (terminal rows x_T = xf only where ONE stage has the controls to reach them, m >= n: with fewer the equality rows are
+        #  rank deficient or nearly so -- n = 36, m = 7, T = 11 gave cond(Y) = 2.5e14, the two CPU restatements then differ by
+        #  3e-7 -- chol(Y) may fail in the reference too, and WHICH problems fail is decided by round-off)
+        xf_ok = m >= n
         cases.append(dict(seed=1000 + i, n=n, m=m, T=T, var_order=int(rng.integers(1, 3)), dense_q=dense_q, dense_r=dense_r,
                           xf=bool(rng.integers(0, 3) == 0) and xf_ok, lin=bool(rng.integers(0, 2)), k=float(rng.choice([1e-2, 1e-1, 1.0])),
                           nw=int(rng.integers(1, 6)), warm=bool(rng.integers(0, 2)), batch=int(rng.integers(5, 7))))
