@@ -15,6 +15,8 @@ struct FaParams {
     const double* x0; const double* x0p; const double* nu0;
     double* zout; double* nuout; double* u0out; int* status; int* iters; double* step;
     int* need; int* handed;
+    int* nflag;                         // += 1 per problem flagged in `need` (device counter, zero at entry: the exact-path launch behind this
+                                        // kernel reads it first and leaves at once when nothing was flagged, without scanning `need`)
     double* dump;                       // 4096 doubles nobody reads: where lanes without a valid target store (no branch around a store)
 };
 

@@ -60,7 +60,8 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
                             const double* nuws = nullptr, double* u0out = nullptr,
-                            int pphase = 0, const double* rnp = nullptr, int* list = nullptr, int u0_done = 0);
+                            int pphase = 0, const double* rnp = nullptr, int* list = nullptr, int u0_done = 0,
+                            const int* nflag = nullptr, int* nflag_zero = nullptr);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -105,6 +106,8 @@ struct fmpc_handle_s {
     double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
     size_t pn_o_simg, pn_o_limg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
     int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
+    int* fa_nflag; int fa_parity;        // affine form: two counters of flagged problems used in turn (the exact-path launch of a call
+                                         // reads the one its affine kernel added to and zeroes the other for the next call)
     size_t pn_cap;                       // per-batch buffers of the panel path, grown together
     double* pn_gate; double* pn_epsp; double* pn_nuws;
     double* pn_rnp; int* pn_list;        // budgets > 1: next-exit-test partials, compacted list of the problems that go on
@@ -321,6 +324,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* na = getenv("FMPC_PRODUCT_MIN_BATCH"); h->fs_min_batch = (na && atoi(na) >= 1) ? atoi(na) : FMPC_PRODUCT_MIN_BATCH_DEFAULT; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
+    h->fa_nflag = nullptr; h->fa_parity = 0;
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -519,9 +523,10 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                 h->pn_o_aimg = PL.o_aimg; h->pn_o_vec = PL.o_vec; h->pn_o_ucon = PL.o_ucon; h->pn_o_dz = PL.o_dz;
                 h->pn_doubles = PL.pool_doubles;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->fa_nflag, 2 * sizeof(int)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_sched, (size_t)2 * FP_MAX_STEPS(h->nb) * FP_STEP_INTS * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));     // [handed over, length of the continuation list]
+                (void)hipMemset(h->fa_nflag, 0, 2 * sizeof(int));
                 if (hipHostMalloc((void**)&h->pn_cnt_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 h->pn_cnt_host[0] = -1; h->pn_cnt_host[1] = -1;   // nothing known yet
                 h->pn_dz_lds = fmpc_dz_lds_bytes(pmp, 1);
@@ -581,6 +586,7 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->lp_v) (void)hipFree(h->lp_v);
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
+    if (h->fa_nflag) (void)hipFree(h->fa_nflag);
     if (h->pn_sched) (void)hipFree(h->pn_sched);
     if (h->pn_gate) (void)hipFree(h->pn_gate);
     if (h->pn_epsp) (void)hipFree(h->pn_epsp);
@@ -1234,11 +1240,16 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     A.batch = batch; A.step_ld = fmpc_step_ld(n_newton);
                     A.x0 = x0; A.x0p = x0_pre; A.nu0 = nu0; A.zout = z_null ? nullptr : z_out; A.nuout = nu_out; A.u0out = u0_out;
                     A.status = status; A.iters = iters; A.step = step; A.need = h->fa_need; A.handed = h->pn_cnt;
+                    int* const nf = h->fa_nflag + h->fa_parity;           // this call's counter of flagged problems (zero: the previous
+                    int* const nfz = h->fa_nflag + (h->fa_parity ^ 1);    // call's exact-path launch, or the allocation, left it so)
+                    h->fa_parity ^= 1;
+                    static const bool no_nflag = [] { const char* e = getenv("FMPC_NO_NFLAG"); return e && e[0] == '1'; }();   // A/B switch
+                    A.nflag = no_nflag ? nullptr : nf;
                     if (fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
                     int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
                     e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nu_out, status, iters, step,
                                          fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,
-                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need);
+                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need, 0, no_nflag ? nullptr : nf, nfz);
                     h->last_path = FMPC_PATH_PANEL; h->inv_last = 2;
                     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
                 }

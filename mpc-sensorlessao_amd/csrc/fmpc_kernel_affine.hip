@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
                     const double sn = (sF[0][2][i] + sF[1][2][i]) + (sF[2][2][i] + sF[3][2][i]);
                     const bool clear = fa_decide(P, se, sp, rdl[r], sn);
                     P.need[pp] = clear ? 0 : 1;
+                    if (!clear && P.nflag) atomicAdd(P.nflag, 1);
                     if (clear) {
                         if (P.status) P.status[pp] = FMPC_OK;
                         if (P.iters) P.iters[pp] = 1;
