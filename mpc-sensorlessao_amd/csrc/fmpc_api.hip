@@ -106,6 +106,7 @@ struct fmpc_handle_s {
     double* pn_pool;                     // [simg | btimg | aimg | vec | ucon]
     size_t pn_o_simg, pn_o_limg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
     int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
+    int* gn_list; double* gn_nu; int* gn_cnt; int* gn_cnt_host; size_t gn_cap; int gn_split;   // explicit-start batches with a budget > 1: first step / continuation split (FMPC_NO_GENERAL_SPLIT=1: one launch)
     int* fa_nflag; int fa_parity;        // affine form: two counters of flagged problems used in turn (the exact-path launch of a call
                                          // reads the one its affine kernel added to and zeroes the other for the next call)
     size_t pn_cap;                       // per-batch buffers of the panel path, grown together
@@ -325,6 +326,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
     h->fa_nflag = nullptr; h->fa_parity = 0;
+    h->gn_list = nullptr; h->gn_nu = nullptr; h->gn_cnt = nullptr; h->gn_cnt_host = nullptr; h->gn_cap = 0;
+    { const char* gs = getenv("FMPC_NO_GENERAL_SPLIT"); h->gn_split = (gs && gs[0] == '1') ? 0 : 1; }
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return FMPC_E_HIP; }
@@ -587,6 +590,10 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->pn_pool) (void)hipFree(h->pn_pool);
     if (h->pn_cnt) (void)hipFree(h->pn_cnt);
     if (h->fa_nflag) (void)hipFree(h->fa_nflag);
+    if (h->gn_list) (void)hipFree(h->gn_list);
+    if (h->gn_nu) (void)hipFree(h->gn_nu);
+    if (h->gn_cnt) (void)hipFree(h->gn_cnt);
+    if (h->gn_cnt_host) (void)hipHostFree(h->gn_cnt_host);
     if (h->pn_sched) (void)hipFree(h->pn_sched);
     if (h->pn_gate) (void)hipFree(h->pn_gate);
     if (h->pn_epsp) (void)hipFree(h->pn_epsp);
@@ -1326,6 +1333,43 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                               u0_out, (hipStream_t)stream, batch <= 512 ? h->small_nw : 2);
             if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
+        }
+        if (mode == 0 && max_iter > 1 && h->small_tiled && h->gn_split) {
+            // Explicit-start batch too large for the tiled kernel, budget > 1: with one problem per wavefront slot a launch lasts
+            // as long as its slowest wavefront, so the few per cent of problems that take a second step double it (round 3:
+            // 2.0 ms for 2180 problem-iterations, 1.2 ms for the 2000 first ones).  Two launches instead: the one-wavefront
+            // kernel takes the first step of every problem and the NEXT exit test (pphase 4), appending the problems that go on
+            // to a list; the tiled kernel (two wavefronts per problem: half the latency of one problem) works through that list.
+            const size_t nbn = (size_t)h->nb * h->n;
+            if ((size_t)batch > h->gn_cap) {
+                (void)hipDeviceSynchronize();
+                if (h->gn_list) (void)hipFree(h->gn_list);
+                if (h->gn_nu) (void)hipFree(h->gn_nu);
+                if (h->gn_cnt) (void)hipFree(h->gn_cnt);
+                h->gn_list = nullptr; h->gn_nu = nullptr; h->gn_cnt = nullptr; h->gn_cap = 0;
+                if (hipMalloc((void**)&h->gn_list, (size_t)batch * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->gn_cnt, 2 * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&h->gn_nu, (size_t)batch * nbn * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                h->gn_cap = batch;
+            }
+            if (!h->gn_cnt_host) {
+                if (hipHostMalloc((void**)&h->gn_cnt_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) return FMPC_E_ALLOC;
+                h->gn_cnt_host[0] = -1; h->gn_cnt_host[1] = -1;
+            }
+            double* nu_arr = nu_out ? nu_out : h->gn_nu;               // nu after the first step, per problem: what the continuation starts from
+            if (hipMemsetAsync(h->gn_cnt, 0, 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+            e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
+                                 z_out, nu_arr, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
+                                 h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
+                                 nullptr, nullptr, h->gn_cnt, nullptr, u0_out, 4, nullptr, h->gn_list);
+            if (e != hipSuccess) return FMPC_E_HIP;
+            h->last_path = FMPC_PATH_WAVE;
+            const int last = ((volatile int*)h->gn_cnt_host)[1];       // list length an EARLIER call reported (never waited for)
+            const int hint = last >= 0 ? last + last / 2 + 16 : 0;
+            const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_arr, status, iters, step,
+                                              u0_out, (hipStream_t)stream, h->small_nw, h->gn_list, h->gn_cnt + 1, nullptr, hint);
+            if (rc_t != FMPC_OK) return rc_t;
+            if (hipMemcpyAsync(h->gn_cnt_host, h->gn_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+            return FMPC_OK;
         }
         e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                              z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,

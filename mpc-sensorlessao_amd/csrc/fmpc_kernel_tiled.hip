@@ -978,7 +978,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     for (int item_p = blockIdx.x; item_p < nitems; item_p += gridDim.x) {
         int p = item_p;
         bool cont = false;                                           // continue behind the panel path's first step
-        if (P.list) { const int e = P.list[item_p]; p = e & (FT_LIST_HANDED - 1); cont = !(e & FT_LIST_HANDED); }
+        bool gen = false;                                            // ... behind one step of the one-wavefront kernel (FT_LIST_GENERAL)
+        if (P.list) { const int e = P.list[item_p]; p = e & (FT_LIST_GENERAL - 1); cont = !(e & FT_LIST_HANDED); gen = (e & FT_LIST_GENERAL) != 0; }
         double* zp = P.zout + (size_t)p * Nz;
         const double* x0v = P.x0 + (size_t)p * n;
         const double* x0pv = P.x0p ? P.x0p + (size_t)p * n : nullptr;
@@ -994,7 +995,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
         }
         for (int idx = tid; idx < nbn; idx += NT) {
             // (continuation: nu+ of the first step sits in the panel workspace, [panel][row][16 problems])
-            nu[idx] = cont ? P.nuws[((size_t)(p >> 4) * nbn + idx) * 16 + (p & 15)] : (P.nu0 ? P.nu0[(size_t)p * nbn + idx] : 0.0);
+            nu[idx] = gen ? P.nuout[(size_t)p * nbn + idx]
+                          : cont ? P.nuws[((size_t)(p >> 4) * nbn + idx) * 16 + (p & 15)] : (P.nu0 ? P.nu0[(size_t)p * nbn + idx] : 0.0);
             const int i = idx / n, r = idx - i * n;
             double v = (i < T && P.w) ? P.w[(size_t)p * T * n + idx] : 0.0;
             if (i == 0) {
@@ -1011,11 +1013,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             if (i == T) v = M.xf[r];
             b[idx] = v;
         }
-        if (P.step)
+        if (P.step && !gen)                                          // (gen: the record of the first step stands)
             for (int idx = tid; idx < P.step_ld; idx += NT) P.step[(size_t)p * P.step_ld + idx] = (cont && idx == 0) ? 1.0 : -1.0;
         __syncthreads();
 
-        int st = FMPC_OK, nsteps = cont ? 1 : 0;
+        int st = (gen && P.status) ? P.status[p] : FMPC_OK, nsteps = cont ? 1 : 0;     // (gen: a line-search warning of the first step is kept)
         FT_TICK(0);
         for (int it = cont ? 1 : 0; it < P.max_iter; ++it) {
             // ================= P1: residuals.  Every product is a GEMM with the horizon stages as one dimension

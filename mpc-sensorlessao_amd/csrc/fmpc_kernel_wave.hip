@@ -156,6 +156,7 @@ struct FwParams {
                                     // array that only the problems redone here touch)
 };
 #define FW_LIST_HANDED (1 << 30)
+#define FW_LIST_GENERAL (1 << 29)     // (= FT_LIST_GENERAL of fmpc_tiled.h)
 
 typedef const FwParams __attribute__((address_space(4))) * FwKP;
 __device__ __forceinline__ FwKP fw_params() {
@@ -1741,8 +1742,17 @@ template <int N>
 FW_PH void fw_phase_pre(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
     do_init = __builtin_amdgcn_readfirstlane(do_init);
     if (do_init >= 0) fw_phase_init<N>(Pin, p, do_init);
+#ifdef FW_TIMING
+    const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
     fw_phase_CT<N, 0>(Pin, p, lds_g, red_g, first);
+#ifdef FW_TIMING
+    const unsigned long long tp1 = __builtin_readcyclecounter();
+#endif
     fw_phase_C2<N>(Pin, p, lds_g, red_g + 1, first);
+#ifdef FW_TIMING
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&fw_timing[13], tp1 - tp0); atomicAdd(&fw_timing[14], __builtin_readcyclecounter() - tp1); }
+#endif
 }
 template <int N>
 FW_PH int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
@@ -1793,9 +1803,12 @@ FW_PH void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int firs
 #else
 #define FW_ITER FW_FN
 #endif
+// test_only: evaluate the exit test of this iteration and return 4 instead of stepping (pphase 4: the steps behind the first
+// one are taken by the continuation launch over the compacted list).
 template <int N>
-FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init) {
+FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init, int test_only) {
     const FwKP P = fw_uniform(Pin);
+    test_only = __builtin_amdgcn_readfirstlane(test_only);
     fw_phase_pre<N>(Pin, p, lds_g, red_g, first, do_init);
     const fw_lds_t red = (fw_lds_t)red_g;
     fw_wave_fence();
@@ -1804,6 +1817,7 @@ FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int firs
     fw_wave_fence();
     const double rho2 = rd2 + rp2;
     if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) return 1;       // inf_newton_solver.m:19-22
+    if (test_only) return 4;
     if (bad) return 2;
     if (fw_phase_mid<N>(Pin, p, lds_g, first)) return 3;
     fw_phase_post<N>(Pin, p, lds_g, red_g, first, rho2);
@@ -2015,9 +2029,14 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         for (int it = it0; it < max_iter && !done; ++it) {
             const int first = (P->zinit != nullptr && nsteps == 0) ? 1 : 0;     // z_out not written yet: read z_init
 #ifdef FW_ONE_CALL
-            const int code = fw_iteration<N>(P, p, lds, red, first, do_init);
+            // pphase 4 (explicit-start batches with a budget > 1): this launch takes the FIRST step of every problem and, for the
+            // next one, only the exit test (inf_newton_solver.m:19-22); a problem that goes on is appended to the list the
+            // continuation launch works through -- a few per cent of the batch would otherwise hold the whole launch for a
+            // second iteration (with one problem per wavefront slot the launch lasts as long as its slowest wavefront)
+            const int code = fw_iteration<N>(P, p, lds, red, first, do_init, (P->pphase == 4 && nsteps >= 1) ? 1 : 0);
             do_init = -1;
             if (code == 1) break;
+            if (code == 4) { if (lane == 0) P->list[atomicAdd(P->handed + 1, 1)] = p | FW_LIST_GENERAL; break; }
             if (code == 2) { st = FMPC_E_NOT_PD_PHI; break; }
             if (code == 3) { st = FMPC_E_NOT_PD_SCHUR; break; }
 #else
@@ -2030,6 +2049,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             FW_KTICK(1);
             const double rho2 = rd2 + rp2;
             if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;   // inf_newton_solver.m:19-22
+            if (P->pphase == 4 && nsteps >= 1) { if (lane == 0) P->list[atomicAdd(P->handed + 1, 1)] = p | FW_LIST_GENERAL; break; }
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
             FW_KTICK(2);
             const int npd = fw_phase_mid<N>(P, p, lds, first);

@@ -119,6 +119,8 @@ struct FtParams {
     const int* list; const int* nlist; const double* nuws;
 };
 #define FT_LIST_HANDED (1 << 30)       // (= FW_LIST_HANDED of fmpc_kernel_wave.hip)
+#define FT_LIST_GENERAL (1 << 29)      // (= FW_LIST_GENERAL) continue behind ONE step of the one-wavefront kernel from an explicit start: z in
+                                       // zout, nu in nuout (per problem, plain), status / step record of that step kept
 
 // supported (type, NB) pairs
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR = 0);

@@ -68,6 +68,7 @@ for tiled in ((0,) if os.environ.get('FMPC_PERF_WAVE_ONLY') == '1' else (0, 1)):
             print("    %-26s %12.0f  %5.1f%%" % (nm, out[i] / nwv, 100.0 * out[i] / tot))
         print("    total %.0f cycles/wave" % (tot / nwv))
         print("    backward sweep alone (inside P4 / P5)  %12.0f" % (out[12] / nwv))
+        print("    C'nu (r_d, Phi^-1 r_d) %12.0f   C z, rhs %12.0f" % (out[13] / nwv, out[14] / nwv))
         ft = sum(out[i] for i in range(4)) or 1
         for nm, i in [("P3.images + B Rt^-1 B' + U'U (MFMA)", 0), ("P3.tiles -> LDS, row/col loads", 1), ("P3.fused potrf+trsm (VALU)", 2), ("P3.store + readback", 3)]:
             print("      %-38s %12.0f  %5.1f%% of P3" % (nm, out[i] / nwv, 100.0 * out[i] / ft))

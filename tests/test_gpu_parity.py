@@ -4,7 +4,7 @@ status codes and line-search steps identical."""
 import numpy as np
 import pytest
 
-from tests.util import handle_from_model, oracle_batch, rel_err
+from tests.util import canon_steps as canon,  handle_from_model, oracle_batch, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -142,7 +142,14 @@ def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw):
     zc, ic = h.solve(rep(data["x0"]), rep(data["x0_pre"]), None, z_init=rep(z0), nu0=rep(data["nu0"]), n_newton=nw, k=1e-2, return_info=True)
     assert h.last_dispatch()[0] == pkg.FMPC_PATH_WAVE
     h.close()
-    assert np.array_equal(zc, zb) and np.array_equal(zb[:24], zw)
+    # (budget > 1: the default handle takes the first step with the one-wavefront kernel and the steps behind it with the tiled
+    #  kernel over the compacted list of problems that go on -- round 4 -- so it agrees with the single launch to rounding only)
+    assert np.array_equal(zb[:24], zw)
+    if nw == 1:
+        assert np.array_equal(zc, zb)
+    else:
+        assert max(rel_err(zc[p], zb[p]) for p in range(1100)) <= 1e-11
+        assert np.array_equal(ic["iters"], ib["iters"]) and np.array_equal(ic["status"], ib["status"]) and np.array_equal(canon(ic["step"]), canon(ib["step"]))
     zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, 1e-2, z0)
     for z_, i_ in ((zt, it_), (zw, iw)):
         assert np.array_equal(i_["status"], sto) and np.array_equal(i_["iters"], ito)
@@ -150,3 +157,59 @@ def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw):
             assert rel_err(z_[p], zo[p]) <= TOL and rel_err(i_["nu"][p], nuo[p]) <= 1e-7
             assert np.array_equal(i_["step"][p][:ito[p]], np.array(steps[p]))
     assert max(rel_err(zt[p], zw[p]) for p in range(24)) <= 1e-11
+
+
+
+@pytest.mark.parametrize("want_nu", [True, False])
+def test_explicit_start_budget5_large_batch_first_step_then_compacted_continuation(pkg, gpu, want_nu):
+    """Explicit start, more problems than the tiled kernel takes (> 1024), Newton budget 5 (test_fast_mpc.m:53,59): the
+    one-wavefront kernel takes the first step of every problem and the next exit test (inf_newton_solver.m:19-22), the problems
+    that go on are compacted into a list and finished by the tiled kernel.  Starts near the bounds for some problems: 2 to 5
+    steps per problem, and first steps whose line search collapses.  Against the oracle problem by problem (z, nu, iteration
+    counts, status, step lengths) and against the single launch (FMPC_NO_GENERAL_SPLIT=1)."""
+    import os
+    import torch
+    model = pkg.synthetic.make_model(27, 144, 8)
+    nb_ = 40
+    data = pkg.synthetic.make_replay_batch(model, r=9, steps=nb_)
+    rng = np.random.default_rng(4)
+    z0 = np.zeros((nb_, 8, 171)); z0[:, :, :144] = rng.uniform(-3, 3, (nb_, 8, 144)); z0[:, :, 144:] = 0.3 * rng.standard_normal((nb_, 8, 27))
+    for p in range(0, nb_, 5):                                    # starts close to the bounds (u in [-28, 28]): more steps, and a first
+        z0[p, :, :144:7] = 27.99 * np.sign(rng.standard_normal((8, 21)))      # step whose line search collapses (status 1 must survive
+    for p in range(2, nb_, 9):                                    # the continuation)
+        z0[p, :, :144:5] = 27.995
+    for p in range(3, nb_, 9):
+        z0[p, :, :144:5] = 27.9999
+    z0 = z0.reshape(nb_, -1)
+    B = 1100
+    rep = lambda a: np.ascontiguousarray(np.tile(a, ((B + nb_ - 1) // nb_, 1))[:B])
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, 5, 1e-2, z0)
+    assert len(set(ito.tolist())) >= 4 and (sto == 1).any() and (sto == 0).any()      # the case exercises what it claims
+    outs = {}
+    for tag, env in (("split", {}), ("one_launch", {"FMPC_NO_GENERAL_SPLIT": "1"})):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            h = handle_from_model(pkg, model)
+        finally:
+            for k_ in env:
+                del os.environ[k_]
+        t = lambda a: torch.from_numpy(rep(a)).to(gpu)
+        nu = torch.empty((B, h.nu_len), dtype=torch.float64, device=gpu) if want_nu else None
+        stp = torch.full((B, 5), -7.0, dtype=torch.float64, device=gpu)
+        u0 = torch.empty((B, 144), dtype=torch.float64, device=gpu)
+        z, st, it = h.solve_device(t(data["x0"]), t(data["x0_pre"]), None, t(z0), t(data["nu0"]), 5, 1e-2, nu_out=nu, step=stp, u0_out=u0)
+        torch.cuda.synchronize()
+        assert h.last_dispatch()[0] == pkg.FMPC_PATH_WAVE
+        outs[tag] = (z.cpu().numpy(), None if nu is None else nu.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), stp.cpu().numpy(), u0.cpu().numpy())
+        h.close()
+    for tag, (z, nu, st, it, stp, u0) in outs.items():
+        for p in range(B):
+            q = p % nb_
+            assert it[p] == ito[q] and st[p] == sto[q], (tag, p, it[p], ito[q], st[p], sto[q])
+            assert rel_err(z[p], zo[q]) <= TOL, (tag, p)
+            assert nu is None or rel_err(nu[p], nuo[q]) <= 1e-7
+            ts = np.full(5, -1.0); ts[:len(steps[q])] = steps[q]
+            assert np.array_equal(canon(stp[p]), canon(ts)), (tag, p, stp[p], ts)
+        assert np.array_equal(u0, z[:, :144])
+    assert max(rel_err(outs["split"][0][p], outs["one_launch"][0][p]) for p in range(B)) <= 1e-11
