@@ -18,6 +18,11 @@ struct FaParams {
     int* nflag;                         // += 1 per problem flagged in `need` (device counter, zero at entry: the exact-path launch behind this
                                         // kernel reads it first and leaves at once when nothing was flagged, without scanning `need`)
     double* dump;                       // 4096 doubles nobody reads: where lanes without a valid target store (no branch around a store)
+    const double* imgJ; const double* imgX; const double* imgBw;   // two-stage form (fmpc_kernel_affine2.hip), NULL: not built
 };
 
 hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream);
+// The same step as TWO chained products per stage (nu+_s = J_s d, u_s = Bw nu+_s; the x rows directly): 20 % fewer matrix
+// instructions and one task per wavefront.  z_out required, nu_out not served (the caller takes fmpc_launch_affine then).
+bool fmpc_affine2_applies(const FaParams& P);
+hipError_t fmpc_launch_affine2(FaParams P, hipStream_t stream);

@@ -1031,7 +1031,8 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
     // affine form of the whole step without w: [Kz | zc] as matrix-core images; the (x0, x0_pre) blocks of E, Ep likewise
     h->fa_valid = 0;
     FmpcAffineOut AO;
-    size_t oA = 0, oAE = 0, oAEp = 0, oAl = 0, oAlp = 0, oAd = 0;
+    size_t oA = 0, oAE = 0, oAEp = 0, oAl = 0, oAlp = 0, oAd = 0, oAJ = 0, oAX = 0, oAB = 0;
+    bool fa2_ok = false;
     bool fa_ok = !h->fa_disabled && 2 * n + 2 <= FA_KC;
     if (fa_ok) {
         FmpcAffineIn AI;
@@ -1053,6 +1054,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         fmpc_host_mfma_a_images(Ep64.data(), 64, imgEp);
         oA = push(AO.img); oAE = push(imgE); oAEp = push(imgEp); oAl = push(el); oAlp = push(epl);
         oAd = push(std::vector<double>(4096, 0.0));
+        if (!AO.imgJ.empty()) { oAJ = push(AO.imgJ); oAX = push(AO.imgX); oAB = push(AO.imgBw); fa2_ok = true; }
     }
     // the first-move form as a product over many realisations (fmpc_kernel_loopu0.hip): [K0 | u0c], E, Ep as matrix-core images
     // over d -- in the order [x0; x0_pre; B u1; B u2; 1] behind the loop-input kernel, in blocks of 28 with the constant in
@@ -1087,6 +1089,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         A.n = n; A.m = m; A.T = T; A.nb = h->nb; A.has_xf = h->has_xf; A.rows = AO.rows; A.tiles = AO.tiles; A.nu_rows = AO.nu_rows; A.nu_tiles = AO.nu_tiles;
         A.img = h->fm_pool + oA; A.imgE = h->fm_pool + oAE; A.imgEp = h->fm_pool + oAEp; A.elin = h->fm_pool + oAl; A.eplin = h->fm_pool + oAlp; A.dump = h->fm_pool + oAd;
         A.dx0T = P.dx0T; A.e0 = O.e0; A.ep0 = O.ep0; A.normE = O.normE; A.norme = O.norme; A.normEp = O.normEp; A.normep = O.normep; A.rd2_0 = h->pn_rd2_0;
+        if (fa2_ok) { A.imgJ = h->fm_pool + oAJ; A.imgX = h->fm_pool + oAX; A.imgBw = h->fm_pool + oAB; }
         h->fa_valid = 1;
     }
     if (fl_ok) {
@@ -1252,7 +1255,11 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     h->fa_parity ^= 1;
                     static const bool no_nflag = [] { const char* e = getenv("FMPC_NO_NFLAG"); return e && e[0] == '1'; }();   // A/B switch
                     A.nflag = no_nflag ? nullptr : nf;
-                    if (fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+                    // the two-stage form (22 % fewer matrix instructions, one task per wavefront): opt-in, FMPC_AFFINE2=1 -- the step is
+                    // bound by the HBM write path, not by the matrix pipes, and the form measured 3 us slower (fmpc_kernel_affine2.hip)
+                    const char* a2e = getenv("FMPC_AFFINE2_MIN_BATCH");
+                    const bool two_stage = batch >= (a2e && a2e[0] ? atoi(a2e) : 1024) && fmpc_affine2_applies(A);
+                    if ((two_stage ? fmpc_launch_affine2(A, (hipStream_t)stream) : fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream)) != hipSuccess) return FMPC_E_HIP;
                     int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
                     e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nu_out, status, iters, step,
                                          fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,

@@ -250,6 +250,29 @@ FW_IN void fw_phase_init(FwKP Pin, int p, int write_z) {
     const double* x0pv = P->x0p ? P->x0p + (size_t)p * N : nullptr;
     const double* w = P->w;
     const double* nu0 = P->nu0;
+    // The prediction terms of b (fast_mpc_eq_const.m:39,44): A1 x0 + A2 x0_pre for block row 0 on lanes 0..N-1, A2 x0 for block
+    // row 1 on lanes N..2N-1.  Every lane takes part with clamped indices and the operands are requested nine columns at a
+    // time BEFORE they are used: as three loops of N dependent load + multiply-add pairs under a divergent condition this was
+    // 3 % of a Newton iteration (66 k cycles per wavefront, round 4 timing build).
+    double pred = 0.0;
+    {
+        const int blk = lane >= N ? 1 : 0, r = lane - blk * N, rc = (r < N) ? r : 0;
+        const double* Aa = blk ? P->M.A2t : P->M.A1t;          // block row 0: A1 x0 ; block row 1: A2 x0
+        const bool two = W.var2 && x0pv != nullptr;
+        const bool on_a = blk == 0 || W.var2, on_b = blk == 0 && two;
+#pragma unroll
+        for (int c0 = 0; c0 < N; c0 += 9) {
+            double aa[9], ab[9], xa[9], xb[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int c = c0 + q < N ? c0 + q : N - 1;
+                aa[q] = Aa[c * N + rc]; ab[q] = P->M.A2t[c * N + rc]; xa[q] = x0v[c]; xb[q] = two ? x0pv[c] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                if (c0 + q < N) { pred = fma(on_a ? aa[q] : 0.0, xa[q], pred); pred = fma(on_b ? ab[q] : 0.0, xb[q], pred); }
+        }
+    }
     // every load before the first store: a load issued behind a global store waits for it (vmcnt is in order)
     for (int base = 0; base < nbn; base += 64 * 14) {
         double nv[14], bv[14];
@@ -261,13 +284,7 @@ FW_IN void fw_phase_init(FwKP Pin, int p, int write_z) {
             nv[q] = nu0 ? nu0[(size_t)p * nbn + ic] : 0.0;
             const int i = ic / N, r = ic - i * N;
             double v = (i < W.T && w) ? w[(size_t)p * W.T * N + ic] : 0.0;
-            if (ok && i == 0) {
-                for (int c = 0; c < N; ++c) v += P->M.A1t[c * N + r] * x0v[c];
-                if (W.var2 && x0pv)
-                    for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0pv[c];
-            } else if (ok && i == 1 && i < W.T && W.var2) {
-                for (int c = 0; c < N; ++c) v += P->M.A2t[c * N + r] * x0v[c];
-            }
+            if (base == 0 && q == 0 && ok && i < 2 && i < W.T) v += pred;       // (2 N <= 64: both block rows lie in the first pass)
             if (i == W.T) v = P->M.xf[r];
             bv[q] = v;
         }
