@@ -81,6 +81,26 @@ struct FwCfg {
     static constexpr int LPACK = (N * (N + 1) / 2 + 1) & ~1;
     __host__ __device__ static constexpr int LOFF(int j) { return j * N - j * (j - 1) / 2; }
     static constexpr int TILE = 32 * LD;
+    // Factor stream of a stage, round 4: the wave's two LDS tiles -- U1 | y as [row j][column c], then L as [row r][column j],
+    // leading dimension LD -- dumped LINEARLY, 16 bytes per lane per instruction (DUMP doubles each: N rows rounded up to whole
+    // wave instructions of 128 doubles).  7 + 7 instructions of 1 KB per stage where the packed form took 27 + 27 of 216 bytes:
+    // a CU's load / store path takes a wave instruction every 12-17 cycles whatever its width (scripts/probes/vmem_issue_rate.hip).
+    static constexpr int DUMP = ((N * LD + 127) / 128) * 128;
+    // L: only its strictly lower triangle is streamed, FOLDED -- rows r and N - 1 - r share a tile row of N - 1 entries (row
+    // min(r, N-1-r) of the folded tile: the shorter of the two first) -- LDF doubles per folded row, (N + 1) / 2 rows
+#ifndef FW_LFOLD                                                    // L as a full [row][column] tile, 14 KB per stage.  (FW_LFOLD: only the strict
+                                                                    // lower triangle, folded, 10 KB: measured SLOWER -- the address selects of
+                                                                    // its LDS writes cost the factor phase more than the bytes save)
+    static constexpr int LDF = LD;
+    static constexpr int LFOLD = DUMP;
+    __host__ __device__ static constexpr int LBASE(int r) { return r * LD; }
+#else
+    static constexpr int LDF = N;                                   // (odd)
+    static constexpr int LFOLD = (((N + 1) / 2 * LDF) + 127) / 128 * 128;
+    __host__ __device__ static constexpr int LBASE(int r) { return (r <= (N - 1) / 2 ? r * LDF : (N - 1 - r) * LDF + (N - 1 - r)); }
+#endif
+    static constexpr int FST = DUMP + LFOLD;
+    static_assert(DUMP <= TILE && LFOLD <= TILE, "the dumps must stay inside a tile");
     static constexpr int PER_WAVE = 2 * TILE;                 // tA, tB
     static constexpr int IMG_D = 3 * 4 * 64;                  // subtiles (0,0),(0,1),(1,1)
     static constexpr int IMG_1 = 4 * 4 * 64;                  // full tile
@@ -90,7 +110,7 @@ struct FwCfg {
 
 // per-wave workspace in HBM (doubles)
 struct FwWs { size_t b, nu, rdu, rdx, rp, rhs, y, dnu, phx, rs, fac, total; };
-__host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T, int nb, int LDG) {
+__host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T, int nb, int LDG, int FST = 0) {
     FwWs L; size_t o = 0;
     const size_t nbn = ((size_t)nb * N + 1) & ~(size_t)1;
     L.b = o; o += nbn;  L.nu = o; o += nbn;
@@ -99,7 +119,7 @@ __host__ __device__ static inline FwWs fw_ws_layout(int N, int m, int mp, int T,
     L.phx = o; o += nbn;
     L.rs = o; o += (size_t)nb * 32;
     o = (o + 1) & ~(size_t)1;
-    L.fac = o; o += (size_t)nb * 2 * N * LDG;                // L and U1 per stage (U2 = L^-1 Y2 is not streamed: see fw_phase_backward)
+    L.fac = o; o += (size_t)nb * (FST > 2 * N * LDG ? FST : 2 * N * LDG);    // L and U1 per stage (U2 = L^-1 Y2 is not streamed: see fw_phase_backward)
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -217,7 +237,7 @@ struct FwView {
                             // written z_out (`first`), z_out afterwards -- the start point is never copied
     __device__ __forceinline__ FwView(FwKP P, int p, int first = 0) {
         m = P->M.m; mp = P->V.mp; T = P->M.T; nb = P->M.nb; s = N + m; has_xf = P->M.has_xf; var2 = P->M.var2;
-        const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG);
+        const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG, FwCfg<N>::FST);
         const int wave_g = blockIdx.x * FW_WAVES + (threadIdx.x >> 6);
         double* wsp = P->ws + (size_t)wave_g * P->ws_stride;
         zp = P->zout + (size_t)p * T * s;
@@ -225,7 +245,7 @@ struct FwView {
         b = wsp + L.b; nu = wsp + L.nu; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
         phx = wsp + L.phx; rsg = wsp + L.rs; fac = wsp + L.fac;
-        fstride = FwCfg<N>::LPACK + N * FwCfg<N>::LDG;      // L packed by columns (lower triangle), then the U1 tile
+        fstride = FwCfg<N>::FST;                            // the two tile dumps of a stage (FwCfg::DUMP)
         if (P->mode == FW_MODE_EXPORT) { fac = P->sh_fac; rsg = P->sh_rs; fstride = 6 * N * FwCfg<N>::LDG; }   // the factor IS the product
     }
 };
@@ -1082,7 +1102,7 @@ FW_FN void fw_cold_nu_update(FwKP Pin, int p, double* lds_g, double t) {
 
 // ------------------------------------------------------------------------------------------------
 // P3: block-penta-diagonal Cholesky of Y fused with the forward sweep (inf_newton_solver.m:27,30-31)
-template <int N>
+template <int N, bool EX>
 FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
     using C = FwCfg<N>;
     constexpr int LD = C::LD, LDG = C::LDG, RC = C::RC;
@@ -1387,11 +1407,10 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             const fw_lds_t tdst = (hi ? tA : tB) + (cl < 28 ? cl : 28);
 #pragma unroll
             for (int j = 0; j < N; ++j) tdst[j * LD] = x[j];
-            const bool ex = P->mode == FW_MODE_EXPORT;
-            if (cl < N && (!hi || ex)) {
-                // U1 row-major for the backward sweep.  U2 = L^-1 Y_{i,i+2} is not streamed (the backward sweep applies
-                // L^-1 to the constant block times d_nu_{i+2} instead); only the exported shared factor carries it
-                double* gdst = f + (ex ? (hi ? 2 : 1) * N * LDG : C::LPACK) + cl;
+            constexpr bool ex = EX;                                  // (the export launch is an instance of its own)
+            if (ex && cl < N) {
+                // the exported shared factor: U1, U2 row-major tiles
+                double* gdst = f + (hi ? 2 : 1) * N * LDG + cl;
 #pragma unroll
                 for (int j = 0; j < N; ++j) gdst[j * LDG] = x[j];
             }
@@ -1402,13 +1421,6 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
                     double* gl = f + lane;
 #pragma unroll
                     for (int j = 0; j < N; ++j) gl[j * LDG] = (j >= lane) ? 0.0 : row[j];
-                } else {
-                    // packed lower triangle: lane r writes L[r][j] to LOFF(j) + r - j = (LOFF(j) - j) + r -- one per-lane base and a
-                    // constant per column.  No predicate: a lane above the diagonal (r < j) writes into the tail of an EARLIER
-                    // column, which is written afterwards (j descending; a wavefront's stores to one address keep their order)
-                    double* gl = f + lane;
-#pragma unroll
-                    for (int j = N - 1; j >= 0; --j) gl[C::LOFF(j) - j] = row[j];
                 }
                 W.rsg[i * 32 + lane] = myrs;
             }
@@ -1454,6 +1466,44 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             }
         }
         if (lane < N) W.yv[i * N + lane] = tB[lane * LD + RC];
+        if (!EX) {
+            // ---- the factor to HBM (per-problem factor: U1 and L; U2 = L^-1 Y_{i,i+2} is not streamed, the backward sweep applies
+            //      L^-1 to the constant block times d_nu_{i+2} instead): tB holds U1 | y as the backward sweep wants it, and the
+            //      strict lower triangle of L goes, folded, into tA (its U2 tile has just been read back) -- both leave as linear
+            //      dumps, 16 bytes per lane: 7 + 3 instructions, 10 KB per stage
+            double* f = W.fac + (size_t)i * W.fstride;
+            d2v* f2 = (d2v*)f + lane;
+            const fw_c2lds_t tB2 = (fw_c2lds_t)tB + lane;
+            d2v du[C::DUMP / 128];
+#pragma unroll
+            for (int q = 0; q < C::DUMP / 128; ++q) du[q] = tB2[q * 64];
+            {
+                // lane r: L[r][j], j < r, to its half of a folded row; entries on and above the diagonal, and the lanes beyond
+                // N, go to a per-lane parking slot behind the folded rows (an address select: no branch, no store under a condition)
+#ifndef FW_LFOLD
+                if (lane < N) {
+                    const fw_lds_t pr = tA + lane * LD;
+#pragma unroll
+                    for (int j = 0; j < N - 1; ++j) pr[j] = row[j];
+                }
+#else
+                const int rr = lane < N ? lane : N - 1;
+                const int lbase = rr <= (N - 1) / 2 ? rr * C::LDF : (N - 1 - rr) * C::LDF + (N - 1 - rr);
+                const int park = C::LFOLD + lane;
+#pragma unroll
+                for (int j = 0; j < N - 1; ++j) tA[(j < lane && lane < N) ? lbase + j : park] = row[j];
+#endif
+            }
+#pragma unroll
+            for (int q = 0; q < C::DUMP / 128; ++q) f2[q * 64] = du[q];
+            fw_wave_fence();
+            const fw_c2lds_t tA2 = (fw_c2lds_t)tA + lane;
+            d2v dlf[C::LFOLD / 128];
+#pragma unroll
+            for (int q = 0; q < C::LFOLD / 128; ++q) dlf[q] = tA2[q * 64];
+#pragma unroll
+            for (int q = 0; q < C::LFOLD / 128; ++q) f2[(C::DUMP / 128 + q) * 64] = dlf[q];
+        }
         fw_wave_fence();
         FW_TICK(3);
     }
@@ -1470,6 +1520,142 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
 // rows the lanes hold anyway -- a third less factor traffic in both directions for ~130 vector instructions per stage.
 // The factor tiles are read with coalesced loads (one tile row across the lanes per instruction)
 // and turned to the row-/column-per-lane layouts through this wave's LDS tile.
+// Per-problem factor (round 4): the stream holds, per stage, the two LDS tiles of the factor phase as linear dumps (FwCfg::DUMP):
+// 14 loads of 16 bytes per lane bring a stage back, they go into tA (U1 | y, [row][column]) and tB (L, [row r][column j]) as they
+// are -- no transposition -- and the lanes read what they need: row lr of U1, row lr of L for the forward substitution,
+// column lr of L for the backward one.  The loads of stage i - 1 are requested before stage i's substitutions.
+template <int N>
+FW_IN void fw_phase_backward_dump(FwKP Pin, int p, double* lds_g) {
+    using C = FwCfg<N>;
+    constexpr int LD = C::LD, NQ = C::DUMP / 128, NL = C::LFOLD / 128;
+    const FwKP P = fw_uniform(Pin);
+    p = __builtin_amdgcn_readfirstlane(p);
+    const FwView<N> W(P, p);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const fw_lds_t lds = (fw_lds_t)lds_g;
+    const fw_lds_t tA = lds + W.mp * FW_LDB + wv * C::PER_WAVE;
+    const fw_lds_t tB = tA + C::TILE;
+    typedef __attribute__((address_space(3))) d2v* fw_2lds_t;
+    const fw_2lds_t tA2 = (fw_2lds_t)tA + lane, tB2 = (fw_2lds_t)tB + lane;
+    const int lr = lane < N ? lane : N - 1;
+#ifndef FW_LFOLD
+    const int lbase = lr * LD;
+#else
+    const int lbase = lr <= (N - 1) / 2 ? lr * C::LDF : (N - 1 - lr) * C::LDF + (N - 1 - lr);       // this lane's row of L in the folded tile
+#endif
+    const double* facp = W.fac;
+    const double* rsp = W.rsg;
+    const double* imgs = P->V.img + C::IMG_D + C::IMG_1;       // [block][row j][col c] copies of the constant blocks
+    double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
+    // FW_BWD2: two stages in flight, (du, dl) = the stage about to be used, (du2, dl2) = the one behind it -- with the full L tile
+    // the second register set spills inside the loop (backward sweep 2 x slower, measured); default: one stage in flight
+#ifdef FW_BWD2
+    constexpr int DEPTH = 2;
+#else
+    constexpr int DEPTH = 1;
+#endif
+    d2v du[NQ], dl[NL], du2[DEPTH == 2 ? NQ : 1], dl2[DEPTH == 2 ? NL : 1];
+    double y2[N], yv_n, rs_n, yv_n2, rs_n2;
+    int cur2 = -1;                    // block whose rows are in y2
+    {
+        const int i = W.nb - 1, i2 = W.nb >= 2 ? W.nb - 2 : 0;
+        const d2v* f2 = (const d2v*)(facp + (size_t)i * W.fstride) + lane;
+        const d2v* g2 = (const d2v*)(facp + (size_t)i2 * W.fstride) + lane;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) du[q] = f2[q * 64];
+#pragma unroll
+        for (int q = 0; q < NL; ++q) dl[q] = f2[(NQ + q) * 64];
+        yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
+        if (DEPTH == 2) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) du2[q] = g2[q * 64];
+#pragma unroll
+            for (int q = 0; q < NL; ++q) dl2[q] = g2[(NQ + q) * 64];
+            yv_n2 = W.yv[i2 * N + lr]; rs_n2 = rsp[i2 * 32 + lr];
+        } else { yv_n2 = 0.0; rs_n2 = 0.0; }
+    }
+    for (int i = W.nb - 1; i >= 0; --i) {
+        const int ip = i >= DEPTH ? i - DEPTH : 0;             // stage to request now: DEPTH ahead (harmless re-reads at the end)
+        double v = yv_n;
+        const double rsv = rs_n;
+        const int b2 = P->V.i2[i];
+        if (b2 != cur2) {                                      // (wave-uniform; changes once or twice per sweep)
+            const double* yr = imgs + (size_t)b2 * C::IMG_STRIDE + lr * 32;
+#pragma unroll
+            for (int c = 0; c < N; ++c) y2[c] = yr[c];
+            cur2 = b2;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tA2[q * 64] = du[q];
+#pragma unroll
+        for (int q = 0; q < NL; ++q) tB2[q * 64] = dl[q];
+        fw_wave_fence();
+        // [rotate and] request the stage DEPTH ahead into the registers that have just been written out
+        if (DEPTH == 2) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) du[q] = du2[q];
+#pragma unroll
+            for (int q = 0; q < NL; ++q) dl[q] = dl2[q];
+            yv_n = yv_n2; rs_n = rs_n2;
+        }
+#ifndef FW_KO_BWD_LOADS
+        {
+            const d2v* f2 = (const d2v*)(facp + (size_t)ip * W.fstride) + lane;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { if (DEPTH == 2) du2[q] = f2[q * 64]; else du[q] = f2[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < NL; ++q) { if (DEPTH == 2) dl2[q] = f2[(NQ + q) * 64]; else dl[q] = f2[(NQ + q) * 64]; }
+        }
+#endif
+        if (DEPTH == 2) { yv_n2 = W.yv[ip * N + lr]; rs_n2 = rsp[ip * 32 + lr]; }
+        else { yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr]; }
+        double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
+        {
+            const fw_clds_t r1 = tA + lr * LD;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double a = fw_readlane(x1, c), bb = fw_readlane(x2, c);
+                v = fma(-r1[c], a, v);
+                cc = fma(y2[c], bb, cc);
+            }
+        }
+        // forward substitution  w = L^-1 cc  (lane r: row r of L from the folded tile; entries k >= r are other rows' data,
+        // they only touch values nobody reads);  v -= w
+        {
+            const fw_clds_t gl = tB + lbase;
+            double glr[N - 1];
+#pragma unroll
+            for (int k = 0; k < N - 1; ++k) glr[k] = gl[k];
+            double wres = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double wk = fw_readlane(cc * rsv, k);
+                if (lane == k) wres = wk;
+                if (k < N - 1) cc = fma(-glr[k], wk, cc);          // meaningful on lanes > k only
+            }
+            v -= wres;
+        }
+        double res = 0.0;
+        {
+            // column lr of L: L[r][lr] (r > lr) sits at LBASE(r) + lr of the folded tile
+            double clr[N];
+#pragma unroll
+            for (int r = 1; r < N; ++r) clr[r] = tB[C::LBASE(r) + lr];
+#pragma unroll
+            for (int r = N - 1; r >= 0; --r) {
+                const double xr = fw_readlane(v * rsv, r);
+                if (lane == r) res = xr;
+                if (r >= 1) v = fma(-clr[r], xr, v);        // meaningful on lanes < r only
+            }
+        }
+        fw_wave_fence();
+        if (lane < N) W.dnu[i * N + lane] = res;
+        x2 = x1;
+        x1 = res;
+    }
+    fw_mem_fence();
+}
+
 template <int N>
 FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     using C = FwCfg<N>;
@@ -1484,7 +1670,7 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
     const int lr = lane < N ? lane : N - 1;
     const int lc = lane < LDG ? lane : LDG - 1;       // tile rows are LDG doubles long in HBM
     const double* facp = W.fac;
-    const bool ex = P->mode == FW_MODE_EXPORT;                 // the exported shared factor keeps full tiles (FwCfg::LPACK)
+    const bool ex = true;                                      // (only the export launch takes this form: full row-major tiles)
     const int u1o = (ex ? N * LDG : C::LPACK) + lc;
     const int lo = ex ? lc : lr;
     const double* rsp = W.rsg;
@@ -1771,16 +1957,16 @@ FW_PH void fw_phase_pre(FwKP Pin, int p, double* lds_g, double* red_g, int first
     if ((threadIdx.x & 63) == 0) { atomicAdd(&fw_timing[13], tp1 - tp0); atomicAdd(&fw_timing[14], __builtin_readcyclecounter() - tp1); }
 #endif
 }
-template <int N>
+template <int N, bool EX>
 FW_PH int fw_phase_mid(FwKP Pin, int p, double* lds_g, int first) {
-    const int npd = fw_phase_factor<N>(Pin, p, lds_g, first);
+    const int npd = fw_phase_factor<N, EX>(Pin, p, lds_g, first);
     const FwKP P = fw_uniform(Pin);
     if (P->mode == FW_MODE_EXPORT && (threadIdx.x & 63) == 0) *P->sh_ok = npd ? 0 : 1;
     if (npd) return 1;
 #ifdef FW_TIMING
     const unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
-    fw_phase_backward<N>(Pin, p, lds_g);
+    if (EX) fw_phase_backward<N>(Pin, p, lds_g); else fw_phase_backward_dump<N>(Pin, p, lds_g);
 #ifdef FW_TIMING
     if ((threadIdx.x & 63) == 0) atomicAdd(&fw_timing[12], __builtin_readcyclecounter() - tb0);
 #endif
@@ -1822,7 +2008,7 @@ FW_PH void fw_phase_post(FwKP Pin, int p, double* lds_g, double* red_g, int firs
 #endif
 // test_only: evaluate the exit test of this iteration and return 4 instead of stepping (pphase 4: the steps behind the first
 // one are taken by the continuation launch over the compacted list).
-template <int N>
+template <int N, bool EX>
 FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int first, int do_init, int test_only) {
     const FwKP P = fw_uniform(Pin);
     test_only = __builtin_amdgcn_readfirstlane(test_only);
@@ -1836,7 +2022,7 @@ FW_ITER int fw_iteration(FwKP Pin, int p, double* lds_g, double* red_g, int firs
     if (P->mode != FW_MODE_EXPORT && sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) return 1;       // inf_newton_solver.m:19-22
     if (test_only) return 4;
     if (bad) return 2;
-    if (fw_phase_mid<N>(Pin, p, lds_g, first)) return 3;
+    if (fw_phase_mid<N, EX>(Pin, p, lds_g, first)) return 3;
     fw_phase_post<N>(Pin, p, lds_g, red_g, first, rho2);
     return 0;
 }
@@ -1888,7 +2074,9 @@ __device__ __forceinline__ bool fw_panel_converged(FwKP P, int p) {
     return rn2 <= 0.996e-12;                         // false for NaN
 }
 
-template <int N>
+// EX: the launch that computes and exports the handle's shared cold-start factor (batch 1, once per barrier weight) -- an instance
+// of its own, so that the production instance carries none of its branches and streams its factor as tile dumps.
+template <int N, bool EX>
 __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
     using C = FwCfg<N>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -2050,7 +2238,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             // next one, only the exit test (inf_newton_solver.m:19-22); a problem that goes on is appended to the list the
             // continuation launch works through -- a few per cent of the batch would otherwise hold the whole launch for a
             // second iteration (with one problem per wavefront slot the launch lasts as long as its slowest wavefront)
-            const int code = fw_iteration<N>(P, p, lds, red, first, do_init, (P->pphase == 4 && nsteps >= 1) ? 1 : 0);
+            const int code = fw_iteration<N, EX>(P, p, lds, red, first, do_init, (P->pphase == 4 && nsteps >= 1) ? 1 : 0);
             do_init = -1;
             if (code == 1) break;
             if (code == 4) { if (lane == 0) P->list[atomicAdd(P->handed + 1, 1)] = p | FW_LIST_GENERAL; break; }
@@ -2069,7 +2257,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
             if (P->pphase == 4 && nsteps >= 1) { if (lane == 0) P->list[atomicAdd(P->handed + 1, 1)] = p | FW_LIST_GENERAL; break; }
             if (bad) { st = FMPC_E_NOT_PD_PHI; break; }
             FW_KTICK(2);
-            const int npd = fw_phase_mid<N>(P, p, lds, first);
+            const int npd = fw_phase_mid<N, EX>(P, p, lds, first);
             if (npd) { st = FMPC_E_NOT_PD_SCHUR; break; }
             FW_KTICK(4);
             fw_phase_post<N>(P, p, lds, red, first, rho2);  // d_z and z + d_z, line search, nu += t d_nu
@@ -2117,7 +2305,7 @@ int fmpc_wave_mp(int m) { const int q = 4 * FW_KCH; return (m + q - 1) / q * q; 
 int fmpc_wave_img_stride(int n) { return n == 27 ? FwCfg<27>::IMG_STRIDE : 0; }
 int fmpc_wave_waves_per_wg() { return FW_WAVES; }
 size_t fmpc_wave_ws_doubles(int n, int m, int mp, int T, int nb) {
-    return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG).total;
+    return fw_ws_layout(n, m, mp, T, nb, FwCfg<27>::LDG, FwCfg<27>::FST).total;
 }
 size_t fmpc_wave_shared_fac_doubles(int n, int nb) { return (size_t)nb * 6 * n * FwCfg<27>::LDG; }
 void fmpc_wave_cold_layout(int n, int mp, int* off9) {      // 14 entries
@@ -2149,8 +2337,9 @@ void fmpc_wave_make_images(int n, const double* blk, double* out) {
 
 hipError_t fmpc_wave_prepare(int n, size_t lds_bytes) {
     if (n != 27) return hipErrorInvalidValue;
-    return hipFuncSetAttribute((const void*)fmpc_newton_wave<27>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)fmpc_newton_wave<27, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)fmpc_newton_wave<27, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
 hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, int grid,
@@ -2171,6 +2360,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
     P.M = M; P.V = V; P.batch = batch; P.max_iter = max_iter; P.step_ld = step_ld; P.mode = mode; P.sh_fac = sh_fac; P.sh_rs = sh_rs; P.sh_ok = sh_ok; P.cold = cold;
     P.kbar = kbar; P.x0 = x0; P.x0p = x0p; P.w = w; P.zinit = zinit; P.nu0 = nu0; P.zout = zout;
     P.nuout = nuout; P.status = status; P.iters = iters; P.step = step; P.ws = ws; P.ws_stride = ws_stride;
-    hipLaunchKernelGGL(fmpc_newton_wave<27>, dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);
+    if (mode == FW_MODE_EXPORT) hipLaunchKernelGGL((fmpc_newton_wave<27, true>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);
+    else hipLaunchKernelGGL((fmpc_newton_wave<27, false>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, P);
     return hipGetLastError();
 }
