@@ -105,7 +105,11 @@ struct FwCfg {
     static constexpr int IMG_D = 3 * 4 * 64;                  // subtiles (0,0),(0,1),(1,1)
     static constexpr int IMG_1 = 4 * 4 * 64;                  // full tile
     static constexpr int IMG_2 = N * 32;                      // [row j][col c] for column-per-lane loads
-    static constexpr int IMG_STRIDE = IMG_D + IMG_1 + IMG_2;
+    // (round 4) the same subtile images with the registers of a lane in PAIRS, [subtile][r / 2][lane][r % 2]: one 16-byte load per
+    // lane and pair -- 14 wave instructions per stage for the constant tiles instead of 28
+    static constexpr int IMG_P = IMG_D + IMG_1 + IMG_2;             // offset of the paired copy of IMG_D, then of IMG_1
+    static constexpr int IMG_STRIDE = 2 * (IMG_D + IMG_1) + IMG_2;
+    static constexpr int Y2LDS = (N * N + 1) & ~1;                  // LDS copy of the block Y_{i,i+2} shared by the workgroup (doubles)
 };
 
 // per-wave workspace in HBM (doubles)
@@ -1118,6 +1122,7 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
     const fw_clds_t sBt = lds;
     const fw_lds_t tA = lds + mp * FW_LDB + wv * C::PER_WAVE;
     const fw_lds_t tB = tA + C::TILE;
+    const fw_clds_t sY2 = lds + mp * FW_LDB + FW_WAVES * C::PER_WAVE + FW_WAVES * 4;       // [row j][column c], leading dimension N
     const double* imgs = P->V.img;
     // experiment (FMPC_WAVE_FLAGS bits 0-7): the second half of the workgroup's wavefronts -- the SIMD partners of the first
     // half -- enters the factorisation that many units of 1024 cycles late, so that a SIMD's two problems are half a stage apart
@@ -1142,24 +1147,27 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
         const double* img = imgs + (size_t)P->V.iD[i] * C::IMG_STRIDE + lane;
         const double* img1 = imgs + (size_t)P->V.i1[i] * C::IMG_STRIDE + C::IMG_D + lane;
         const double* img2 = imgs + (size_t)P->V.i2[i] * C::IMG_STRIDE + C::IMG_D + C::IMG_1;
+        const bool y2lds = P->V.i2[i] == P->V.i2[0];                // (uniform) the block the workgroup keeps in LDS
         // Everything this stage reads from memory is REQUESTED here and CONSUMED behind the 108 products below (3.7 us): the
         // constant tiles and the rhs column are added to S afterwards.  (A load waits for every older store of the wave --
         // vmcnt is in order -- and the previous stage has just issued 54 factor stores: consumed here, each stage would
         // stand still until those are written.)
         d4 I00, I01, I11;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            I00[r] = img[(0 * 4 + r) * 64];
-            I01[r] = img[(1 * 4 + r) * 64];
-            I11[r] = img[(2 * 4 + r) * 64];
-        }
         d4 M00, M01, M10, M11;
+        {
+            const d2v* ip = (const d2v*)(img - lane + C::IMG_P) + lane;                       // paired copies (FwCfg::IMG_P)
+            const d2v* mp2 = (const d2v*)(img1 - lane - C::IMG_D + C::IMG_P + C::IMG_D) + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            M00[r] = img1[(0 * 4 + r) * 64];
-            M01[r] = img1[(1 * 4 + r) * 64];
-            M10[r] = img1[(2 * 4 + r) * 64];
-            M11[r] = img1[(3 * 4 + r) * 64];
+            for (int rp = 0; rp < 2; ++rp) {
+                const d2v a = ip[(0 * 2 + rp) * 64], b = ip[(1 * 2 + rp) * 64], c = ip[(2 * 2 + rp) * 64];
+                I00[2 * rp] = a.x; I00[2 * rp + 1] = a.y; I01[2 * rp] = b.x; I01[2 * rp + 1] = b.y; I11[2 * rp] = c.x; I11[2 * rp + 1] = c.y;
+            }
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                const d2v a = mp2[(0 * 2 + rp) * 64], b = mp2[(1 * 2 + rp) * 64], c = mp2[(2 * 2 + rp) * 64], d = mp2[(3 * 2 + rp) * 64];
+                M00[2 * rp] = a.x; M00[2 * rp + 1] = a.y; M01[2 * rp] = b.x; M01[2 * rp + 1] = b.y;
+                M10[2 * rp] = c.x; M10[2 * rp + 1] = c.y; M11[2 * rp] = d.x; M11[2 * rp + 1] = d.y;
+            }
         }
         double rh0[4], rh1[4];                   // rhs_i rides in column n of the tile
         {
@@ -1280,6 +1288,12 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
                 const fw_clds_t pc = tB + (cl < 28 ? cl : 28);
 #pragma unroll
                 for (int j = 0; j < N; ++j) x[j] = pc[j * LD];
+            } else if (y2lds) {
+                // the columns of Y_{i,i+2} from the workgroup's LDS copy (the block is the same for all stages but the last ones):
+                // from memory these were 27 loads per stage consumed right away -- an L2 round trip in front of every factorisation
+                const fw_clds_t pc = sY2 + (cl < N ? cl : 0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) x[j] = pc[j * N];
             } else {
                 const double* pc = img2 + cl;
 #pragma unroll
@@ -2119,6 +2133,11 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         if (!__syncthreads_or(any)) return;
     }
     for (int i = threadIdx.x; i < mp * FW_LDB; i += FW_THREADS) lds[i] = P->V.BtP[i];
+    {   // the block Y_{i,i+2} of the first stage (= of nearly all stages) for the factorisations' column loads
+        double* sY2 = lds + (size_t)mp * FW_LDB + (size_t)FW_WAVES * C::PER_WAVE + FW_WAVES * 4;
+        const double* src = P->V.img + (size_t)P->V.i2[0] * C::IMG_STRIDE + C::IMG_D + C::IMG_1;
+        for (int i = threadIdx.x; i < N * N; i += FW_THREADS) { const int j = i / N, c = i - j * N; sY2[i] = src[j * 32 + c]; }
+    }
     {   // this wave's tiles: finite everywhere (pad rows/columns are read by the layout changes)
         double* t = lds + (size_t)mp * FW_LDB + (size_t)wv * C::PER_WAVE;
         for (int i = lane; i < C::PER_WAVE; i += 64) t[i] = 0.0;
@@ -2298,7 +2317,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
 // ---------------------------------------------------------------- host side of the wave kernel
 size_t fmpc_wave_lds_bytes(int n, int mp) {
     if (n != 27) return 0;
-    return ((size_t)mp * FW_LDB + (size_t)FW_WAVES * FwCfg<27>::PER_WAVE + FW_WAVES * 4) * sizeof(double);
+    return ((size_t)mp * FW_LDB + (size_t)FW_WAVES * FwCfg<27>::PER_WAVE + FW_WAVES * 4 + FwCfg<27>::Y2LDS) * sizeof(double);
 }
 bool fmpc_wave_supports(int n) { return n == 27; }
 int fmpc_wave_mp(int m) { const int q = 4 * FW_KCH; return (m + q - 1) / q * q; }
@@ -2333,6 +2352,12 @@ void fmpc_wave_make_images(int n, const double* blk, double* out) {
     double* o2 = o1 + C::IMG_1;
     for (int j = 0; j < n; ++j)
         for (int c = 0; c < 32; ++c) o2[j * 32 + c] = at(j, c);
+    // paired copies of the subtile images: [subtile][r / 2][lane][r % 2]
+    double* op = out + C::IMG_P;
+    for (int sub = 0; sub < 3 + 4; ++sub)
+        for (int r = 0; r < 4; ++r)
+            for (int l = 0; l < 64; ++l)
+                op[((sub * 2 + r / 2) * 64 + l) * 2 + (r & 1)] = out[(sub * 4 + r) * 64 + l];     // (IMG_D and IMG_1 are contiguous: 7 subtiles)
 }
 
 hipError_t fmpc_wave_prepare(int n, size_t lds_bytes) {
