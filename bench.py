@@ -445,7 +445,9 @@ def _main(real_out):
         if os.path.exists(tpp) and B == BATCH:
             try:
                 tj = json.load(open(tpp))
-                cand_t = tj.get("kernels", {}).get(best, {}).get("hbm_bytes_per_launch")
+                # (the profile names the kernel with its template arguments, e.g. fmpc_newton_wave<27, false>: match on the stem)
+                stem = best.split("<")[0]
+                cand_t = next((v_.get("hbm_bytes_per_launch") for k_, v_ in tj.get("kernels", {}).items() if k_.split("<")[0] == stem), None)
                 if cand_t is not None and cand_t >= bytes_compulsory(n, m, T) * B:
                     roof_pp["traffic"] = cand_t
                     roof_pp["traffic_source"] = "profiles/traffic_general_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"

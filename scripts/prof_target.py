@@ -1,6 +1,8 @@
 """One workload, a few launches, for rocprofv3 (scripts/prof_round2.sh):  python3 scripts/prof_target.py <target> [reps]
   headline        configs[1]: 2000 problems, cold start, n_newton 1 (panel path)
   general_wave    2000 problems from an explicit start, n_newton 1: fmpc_newton_wave<27>
+  general_budget5 the same with the Newton budget of the reference's test (5): first step by fmpc_newton_wave<27> (pphase 4), the ~9 % of
+                  problems that go on by fmpc_newton_tiled over the compacted list
   general_tiled   the same through fmpc_newton_tiled<double,2,NW>
   tiled_f32       the same with the fp32 factor
   configs4        n = 65, T = 60, batch 1024, fp32 factor: fmpc_newton_tiled<float,5,8>
@@ -57,7 +59,7 @@ if target == "tiled_f32":
     h.set_precision("f32")
 x0 = torch.from_numpy(data["x0"]).to(dev); x0p = torch.from_numpy(data["x0_pre"]).to(dev); nu0 = torch.from_numpy(data["nu0"]).to(dev)
 zi = None
-if target in ("general_wave", "general_tiled", "tiled_f32"):
+if target in ("general_wave", "general_budget5", "general_tiled", "tiled_f32"):
     zc = np.tile(np.concatenate([(model["u_min"] + model["u_max"]) / 2, (model["x_min"] + model["x_max"]) / 2]), T)
     zi = torch.from_numpy(np.tile(zc, (B, 1))).to(dev)
 z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
@@ -80,7 +82,7 @@ if target == "walk64":
     st, it = loop.status, loop.iters
 wt = torch.from_numpy(0.01 * np.random.default_rng(3).standard_normal((B, T * n))).to(dev) if target == "dense_w512" else None
 for _ in range(0 if target in ("closed512", "closed512u0", "walk64") else reps):
-    h.solve_device(x0, x0p, wt, zi, nu0, 5 if target == "budget5" else 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
+    h.solve_device(x0, x0p, wt, zi, nu0, 5 if target in ("budget5", "general_budget5") else 1, 1e-2, z_out=z, status=st, iters=it, u0_out=u0)
 torch.cuda.synchronize()
 assert int((st < 0).sum()) == 0
 print(target, "path", h.last_dispatch(), "iters", int(it.sum()))
