@@ -588,7 +588,7 @@ def _main(real_out):
             fl_est = 3 * (6 * 512 * 512 * 32 + 8 * 32 * 512 * 32)        # executed: 6 real flops per complex multiply-add in the first product (three real
                                                                          # products, Gauss), 8 in the second, 32 of 31 columns
             es = {"what": "phase-diversity estimator at the reference's size (len 512, 31 x 31 window, three diversities; synthetic optics: "
-                          "Zs.mat / model_approx.mat are not shipped): PSF windows as partial DFTs on the fp64 matrix cores + ad_est = G (Y_M - b_s)",
+                          "Zs.mat is not shipped; the reference's model_approx.mat pins the linear half in tests/test_golden_model_approx.py): PSF windows as partial DFTs on the fp64 matrix cores + ad_est = G (Y_M - b_s)",
                   "executed_flops_per_screen": fl_est}
             rng_ = np.random.default_rng(5)
             for Be in (1, 256):

@@ -86,7 +86,9 @@ def make_test_problem(n=8, m=5, T=10, seed=0, umax=2.0, xf=False, var_order=2, b
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # Synthetic optics for the estimator (README.md:456-480): the reference loads its Zernike modes (Zs.mat) and its linearised
-# image model (model_approx.mat: A_s, b_s) from files it does not ship.  These stand-ins follow the README's pixel arrays
+# image model (model_approx.mat: A_s, b_s).  Zs.mat is not shipped; model_approx.mat IS (tests/golden/model_approx_As_bs.npz holds it,
+# tests/test_golden_model_approx.py pins the estimator's linear half to it) but belongs to the reference's own optics, which cannot be
+# rebuilt without Zs.mat -- so the image-formation tests use these self-consistent stand-ins, which follow the README's pixel arrays
 # (README.md:236-250, 366-396): OSA/ANSI-indexed, Noll-normalised Zernike modes on the len x len grid x = (-N:2:N)/N, the
 # pin-hole pupil, and y = b_s + A_s alpha linearised at alpha = 0 from the same image formation (README.md:406).
 def _zernike_radial(nr, ma, rho):

@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE -- numpy restatement of the reference's simulation loop WITH its estimator (README.md:444-626), for one
-realisation.  PARITY UNPINNED (MATLAB-only reference; Zs.mat, model_approx.mat, SNR_10.mat not shipped: synthetic optics).
+realisation.  PARITY UNPINNED (MATLAB-only reference; Zs.mat and SNR_10.mat are not shipped: synthetic optics; the reference's model_approx.mat
+(A_s, b_s) IS shipped and pins the estimator's linear half in tests/test_golden_model_approx.py).
 
     phase_res(:,:,k) = phase_valid(:,:,k) [+ phase_cor(:,:,k-1)]                          README.md:446-454
     Y_M (three PSF windows) ; ad_est = lsqminnorm(A_s'*A_s, A_s'*(Y_M - b_s))            README.md:456-480  (estimator_ref)

@@ -5,8 +5,10 @@ arrays of README.md:236-240, 366-396), op for op:
         I_defocus = fftshift(fft2(fftshift(P_defocus), res, res)) * dx^2;     im = abs(I_defocus).^2;
         v_im(:,:,k) = im(range_min:range_max, range_min:range_max) * AU;      Y_M = [Y_M; reshape(v_im(:,:,k), [], 1)];
     Y_M = Y_M + Y_M_noise;       ad_est = lsqminnorm(A_s'*A_s, A_s'*(Y_M - b_s));
-PARITY UNPINNED: the reference is MATLAB only; Zs.mat, model_approx.mat (A_s, b_s) and SNR_10.mat are not shipped, so the
-checks run on synthetic Zernike modes and a model linearised from this same image formation.  Checker only: nothing outside
+PARITY UNPINNED for the image formation: the reference is MATLAB only and ships neither Zs.mat (the mode maps) nor SNR_10.mat, so
+those checks run on synthetic Zernike modes and a model linearised from this same image formation.  The LINEAR half is pinned: the
+reference does ship model_approx.mat (A_s, b_s; MATLAB v7.3), read by tests/golden/read_mat73.py into tests/golden/model_approx_As_bs.npz
+and used by tests/test_golden_model_approx.py (`estimate` below against independent routes on the real model).  Checker only: nothing outside
 tests/, smoke() and bench.py's CPU leg may import this module."""
 import numpy as np
 

@@ -1,6 +1,6 @@
 """GPU tests of the phase-diversity estimator (fmpc_kernel_estimator.hip, fmpc_est_*; README.md:456-480): the PSF windows as
 partial DFTs on the matrix cores + ad_est = G (Y_M - b_s), against the numpy restatement of the reference's FFT-based code
-(oracle/estimator_ref.py) on synthetic optics (the reference's Zs.mat / model_approx.mat / SNR_10.mat are not shipped).
+(oracle/estimator_ref.py) on synthetic optics (the reference's Zs.mat / SNR_10.mat are not shipped; its model_approx.mat is: tests/test_golden_model_approx.py).
 Tolerances: 1e-10 relative on Y_M (fp64 both ways; a 512-point sum against an FFT), 1e-8 on ad_est."""
 import numpy as np
 import pytest
