@@ -190,6 +190,8 @@ __device__ __forceinline__ FwKP fw_params() {
 // A function argument arrives in VGPRs; make the kernarg pointer wave-uniform again so that
 // every P->field is a scalar load.
 __device__ __forceinline__ FwKP fw_uniform(FwKP P) {
+    // (round 4: taking the pointer from __builtin_amdgcn_kernarg_segment_ptr() inside the non-inlined phase functions instead --
+    //  it would need no register -- FAULTED on the device: in a callee the builtin is not the calling kernel's segment.  Not used.)
     const unsigned long long a = (unsigned long long)P;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -366,16 +368,21 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
         // A fragments (stage on the row index): v_j[k] for stage j = j0+16I+c16.  (v_{j+1}, v_{j+2} are only needed by the x
         // entries: loaded behind the u entries -- kept live across them, the 42 fragment values were spilled to scratch and
         // every reload waited for all outstanding loads and stores.)
+        // (loads below: a per-lane row base chosen once + a constant per k-step, switched off by factors afterwards -- an index
+        //  chosen per load gives every load an address register pair of its own, which the compiler spills; see fw_phase_C2)
+        const int k6 = (24 + g < N ? 24 + g : N - 1) - 24;                          // last k-step: k = 24 + g clamped to N - 1
+        const double f6 = 24 + g < N ? 1.0 : 0.0;
         double an[2][7];
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < 2; ++I) {
+            const int j = j0 + 16 * I + c16;
+            const double* vp = vec + (size_t)(j < T ? j : 0) * N;
+            const double fj = j < T ? 1.0 : 0.0;
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
-                const bool kk = k < N;
-                const double t0 = vec[(kk && j < T ? j : 0) * N + (kk ? k : 0)];
-                an[I][ks] = (kk && j < T) ? t0 : 0.0;
-            }
+            for (int ks = 0; ks < 7; ++ks) an[I][ks] = vp[ks < 6 ? 4 * ks + g : 24 + k6];
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) an[I][ks] *= ks < 6 ? fj : fj * f6;
+        }
         // ---- u entries: G[j][c] = sum_k v_j[k] B[k][c].  The inputs of column block J + 1 are requested before the
         //      results of block J are stored (a load issued behind a store waits for it: vmcnt is in order).
         const int NJ = (m + 15) >> 4;
@@ -384,9 +391,9 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
         // last block (c >= m) are read as they lie -- z has the x entries of the stage there, the workspace its next row --
         // and masked afterwards: a select on the index gave every block its own 64-bit addresses, which were spilled and
         // reloaded around every load.
-        int zo[8], ro[8];
+        unsigned zo[8], ro[8];               // (unsigned: scalar array base + a 32-bit offset register per load / store, no 64-bit address per element)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { zo[e] = sj[e] * s + c16; ro[e] = sj[e] * m + c16; }
+        for (int e = 0; e < 8; ++e) { zo[e] = (unsigned)(sj[e] * s + c16); ro[e] = (unsigned)(sj[e] * m + c16); }
         double zu[8], in0[8], zun[8], in0n[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -407,7 +414,7 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
             // (per-column constants by the same rule: lane offset + constant; beyond m they read the pool's next array, masked)
             const double cmax = umaxp[c16 + 16 * J], cmin = uminp[c16 + 16 * J], cr2 = R2p[c16 + 16 * J], crl = MODE == 0 ? rlp[c16 + 16 * J] : 0.0;
             {
-                const int jn = 16 * (J + 1 < NJ ? J + 1 : J);
+                const unsigned jn = 16u * (unsigned)(J + 1 < NJ ? J + 1 : J);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     zun[e] = zs[zo[e] + jn];
@@ -440,8 +447,8 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (cok && sok[e]) {
-                    W.rdu[ro[e] + 16 * J] = o0[e];
-                    if (MODE == 1) W.zp[zo[e] + 16 * J] = o1[e];
+                    W.rdu[ro[e] + 16u * (unsigned)J] = o0[e];
+                    if (MODE == 1) W.zp[zo[e] + 16u * (unsigned)J] = o1[e];
                 }
             }
 #pragma unroll
@@ -461,16 +468,16 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
         // ---- x entries (x_jx, jx = j+1 for stage column j): H[j][r] = sum_k v_{j+1}[k] A1[k][r] + v_{j+2}[k] A2[k][r]
         double a1[2][7], a2[2][7];
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < 2; ++I) {
+            const int j = j0 + 16 * I + c16;
+            const double* v1p = vec + (size_t)(j + 1 < T ? j + 1 : 0) * N;
+            const double* v2p = vec + (size_t)(j + 2 < T ? j + 2 : 0) * N;
+            const double f1 = j + 1 < T ? 1.0 : 0.0, f2 = (j + 2 < T && var2) ? 1.0 : 0.0;
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                const int j = j0 + 16 * I + c16, k = 4 * ks + g;
-                const bool kk = k < N;
-                const double t1 = vec[(kk && j + 1 < T ? j + 1 : 0) * N + (kk ? k : 0)];
-                const double t2 = vec[(kk && j + 2 < T ? j + 2 : 0) * N + (kk ? k : 0)];
-                a1[I][ks] = (kk && j + 1 < T) ? t1 : 0.0;
-                a2[I][ks] = (kk && j + 2 < T && var2) ? t2 : 0.0;
-            }
+            for (int ks = 0; ks < 7; ++ks) { const int kq = ks < 6 ? 4 * ks + g : 24 + k6; a1[I][ks] = v1p[kq]; a2[I][ks] = v2p[kq]; }
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) { a1[I][ks] *= ks < 6 ? f1 : f1 * f6; a2[I][ks] *= ks < 6 ? f2 : f2 * f6; }
+        }
         d4 h[2][2];
         double cq2[2], cqf2[2], cql[2], cqfl[2], vprev[2][8], vxf[2][8], xin[2][8], zx[2][8];
 #pragma unroll
@@ -479,27 +486,34 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
             const bool rok = rr < N;
             const int rc = rok ? rr : 0;
             h[J][0] = (d4){0, 0, 0, 0}; h[J][1] = (d4){0, 0, 0, 0};
+            {
+                const double* p1 = A1p + rc;                           // A1[k][rr] at A1p[k N + rr]
+                const double* p2 = A2p + rc;
+                const double frr = rok ? 1.0 : 0.0;
+                double b1[7], b2[7];
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                const int k = 4 * ks + g;
-                const bool ok = k < N && rok;
-                const int off = ok ? k * N + rr : 0;
-                const double t1 = A1p[off], t2 = A2p[off];
-                const double b1 = ok ? t1 : 0.0, b2 = ok ? t2 : 0.0;
-                h[J][0] = MFMA64(a1[0][ks], b1, h[J][0]);
-                h[J][1] = MFMA64(a1[1][ks], b1, h[J][1]);
-                h[J][0] = MFMA64(a2[0][ks], b2, h[J][0]);
-                h[J][1] = MFMA64(a2[1][ks], b2, h[J][1]);
+                for (int ks = 0; ks < 7; ++ks) { const int kq = ks < 6 ? 4 * ks + g : 24 + k6; b1[ks] = p1[kq * N]; b2[ks] = p2[kq * N]; }
+#pragma unroll
+                for (int ks = 0; ks < 7; ++ks) {
+                    const double f = ks < 6 ? frr : frr * f6;
+                    const double c1 = b1[ks] * f, c2 = b2[ks] * f;
+                    h[J][0] = MFMA64(a1[0][ks], c1, h[J][0]);
+                    h[J][1] = MFMA64(a1[1][ks], c1, h[J][1]);
+                    h[J][0] = MFMA64(a2[0][ks], c2, h[J][0]);
+                    h[J][1] = MFMA64(a2[1][ks], c2, h[J][1]);
+                }
             }
             cq2[J] = Q2p[rc]; cqf2[J] = Qf2p[rc];
             cql[J] = MODE == 0 ? qlp[rc] : 0.0; cqfl[J] = MODE == 0 ? qflp[rc] : 0.0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const bool last = sj[e] + 1 == T;
-                vprev[J][e] = vec[sj[e] * N + rc];
-                vxf[J][e] = vec[(last && has_xf ? T : sj[e]) * N + rc];
-                zx[J][e] = zs[sj[e] * s + m + rc];
-                xin[J][e] = MODE == 0 ? 0.0 : W.rdx[sj[e] * N + rc];
+                // (unsigned element offsets from the wave-uniform array bases: scalar base + one 32-bit offset register per load)
+                const unsigned ov = (unsigned)(sj[e] * N + rc), ox = (unsigned)((last && has_xf ? T : sj[e]) * N + rc);
+                vprev[J][e] = vec[ov];
+                vxf[J][e] = vec[ox];
+                zx[J][e] = zs[(unsigned)(sj[e] * s + m + rc)];
+                xin[J][e] = MODE == 0 ? 0.0 : W.rdx[ov];
             }
         }
         // all loads are issued: only now the stores
@@ -610,40 +624,51 @@ FW_IN void fw_phase_C2(FwKP Pin, int p, double* lds_g, double* out1_g, int first
             for (int q = 0; q < FW_KCH; ++q) { v0[q] = v0n[q]; v1[q] = v1n[q]; y0[q] = y0n[q]; y1[q] = y1n[q]; }
         }
         // ---- A1 x_i + A2 x_{i-1}  (K = n): x_j at zs[(j-1)*s + m + k], (Phi^-1 r_d)[x_j] at phx[(j-1)*N + k]
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
-            const int k = 4 * ks + g;
-            double xa[2], xb[2], za[2], zb[2], pa[2], pb[2];
-#pragma unroll
-            for (int J = 0; J < 2; ++J) {
-                const int rr = 16 * J + c16;
-                const bool ok = k < N && rr < N;
-                const int off = ok ? k * N + rr : 0;
-                const double t1 = A1tp[off], t2 = A2tp[off];       // A1[rr][k], A2[rr][k]
-                xa[J] = ok ? t1 : 0.0;
-                xb[J] = ok ? t2 : 0.0;
-            }
+        // Every load here is (a per-lane ROW BASE chosen once) + (a constant per k-step); what must not count is switched off by a
+        // factor 0 / 1 afterwards.  An index chosen per load (`cond ? row * s + k : 0`) gave each of the 84 loads an address of its
+        // own: the compiler spilled them, and every reload waits for all loads in flight (vmcnt(0)) in front of the load it feeds --
+        // one memory round trip per load (round 4: 55 such reloads in this section, 160 k cycles per wavefront and iteration).
+        {
+            const double *zaP[2], *zbP[2], *paP[2], *pbP[2], *a1P[2], *a2P[2];
+            double fa[2], fb[2], fr[2];
+            const int k6 = (24 + g < N ? 24 + g : N - 1) - 24;                      // last k-step: k = 24 + g clamped to N - 1
+            const double f6 = 24 + g < N ? 1.0 : 0.0;
 #pragma unroll
             for (int I = 0; I < 2; ++I) {
                 const int i = j0 + 16 * I + c16;
-                const bool oka = k < N && i >= 1 && i < T;
-                const bool okb = k < N && i >= 2 && i < T && var2;
-                const double ta = zs[oka ? (size_t)(i - 1) * s + m + k : m];
-                const double tb = zs[okb ? (size_t)(i - 2) * s + m + k : m];
-                const double ua = W.phx[oka ? (size_t)(i - 1) * N + k : 0];
-                const double ub = W.phx[okb ? (size_t)(i - 2) * N + k : 0];
-                za[I] = oka ? ta : 0.0; zb[I] = okb ? tb : 0.0;
-                pa[I] = oka ? ua : 0.0; pb[I] = okb ? ub : 0.0;
+                const bool ia = i >= 1 && i < T, ib = i >= 2 && i < T && var2;
+                zaP[I] = zs + (ia ? (size_t)(i - 1) * s : 0) + m; zbP[I] = zs + (ib ? (size_t)(i - 2) * s : 0) + m;
+                paP[I] = W.phx + (ia ? (size_t)(i - 1) * N : 0); pbP[I] = W.phx + (ib ? (size_t)(i - 2) * N : 0);
+                fa[I] = ia ? 1.0 : 0.0; fb[I] = ib ? 1.0 : 0.0;
             }
 #pragma unroll
-            for (int I = 0; I < 2; ++I)
+            for (int J = 0; J < 2; ++J) {
+                const int rr = 16 * J + c16;
+                a1P[J] = A1tp + (rr < N ? rr : 0); a2P[J] = A2tp + (rr < N ? rr : 0);   // A1[rr][k] at A1t[k N + rr]
+                fr[J] = rr < N ? 1.0 : 0.0;
+            }
 #pragma unroll
-                for (int J = 0; J < 2; ++J) {
-                    a[I][J] = MFMA64(za[I], xa[J], a[I][J]);
-                    a[I][J] = MFMA64(zb[I], xb[J], a[I][J]);
-                    c[I][J] = MFMA64(pa[I], xa[J], c[I][J]);
-                    c[I][J] = MFMA64(pb[I], xb[J], c[I][J]);
-                }
+            for (int ks = 0; ks < 7; ++ks) {
+                const int kq = ks < 6 ? 4 * ks + g : 24 + k6;                       // (k < N for ks < 6 since N > 24)
+                double xa[2], xb[2], za[2], zb[2], pa[2], pb[2];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) { xa[J] = a1P[J][kq * N]; xb[J] = a2P[J][kq * N]; }
+#pragma unroll
+                for (int I = 0; I < 2; ++I) { za[I] = zaP[I][kq]; zb[I] = zbP[I][kq]; pa[I] = paP[I][kq]; pb[I] = pbP[I][kq]; }
+#pragma unroll
+                for (int J = 0; J < 2; ++J) { const double f = ks < 6 ? fr[J] : fr[J] * f6; xa[J] *= f; xb[J] *= f; }
+#pragma unroll
+                for (int I = 0; I < 2; ++I) { za[I] *= fa[I]; zb[I] *= fb[I]; pa[I] *= fa[I]; pb[I] *= fb[I]; }
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J) {
+                        a[I][J] = MFMA64(za[I], xa[J], a[I][J]);
+                        a[I][J] = MFMA64(zb[I], xb[J], a[I][J]);
+                        c[I][J] = MFMA64(pa[I], xa[J], c[I][J]);
+                        c[I][J] = MFMA64(pb[I], xb[J], c[I][J]);
+                    }
+            }
         }
         {   // epilogue: element e = (I, J, r): block row i = j0+16I+4r+g, entry 16J+c16
             bool ok[16]; int ir[16], ii[16]; double in0[16], in1[16], in2[16];
