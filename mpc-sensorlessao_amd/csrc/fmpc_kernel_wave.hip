@@ -197,6 +197,10 @@ __device__ __forceinline__ FwKP fw_uniform(FwKP P) {
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     return (FwKP)(((unsigned long long)hi << 32) | lo);
 }
+// Element access as (wave-uniform base) + (32-bit BYTE offset): the form `global_load v, v_offset, s[base:base+1]` -- one offset register
+// per access.  With an element index the compiler extends to 64 bits before scaling and keeps a 64-bit address per access.
+__device__ __forceinline__ double fw_ldb(const double* base, unsigned boff) { return *(const double*)((const char*)base + boff); }
+__device__ __forceinline__ void fw_stb(double* base, unsigned boff, double v) { *(double*)((char*)base + boff) = v; }
 // 1/x: hardware estimate + two Newton steps (<= 1 ulp; the parity tolerance is 1e-9)
 __device__ __forceinline__ double fw_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -393,12 +397,12 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
         // reloaded around every load.
         unsigned zo[8], ro[8];               // (unsigned: scalar array base + a 32-bit offset register per load / store, no 64-bit address per element)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { zo[e] = (unsigned)(sj[e] * s + c16); ro[e] = (unsigned)(sj[e] * m + c16); }
+        for (int e = 0; e < 8; ++e) { zo[e] = 8u * (unsigned)(sj[e] * s + c16); ro[e] = 8u * (unsigned)(sj[e] * m + c16); }   // BYTE offsets
         double zu[8], in0[8], zun[8], in0n[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            zu[e] = zs[zo[e]];
-            in0[e] = MODE == 1 ? W.rdu[ro[e]] : 0.0;
+            zu[e] = fw_ldb(zs, zo[e]);
+            in0[e] = MODE == 1 ? fw_ldb(W.rdu, ro[e]) : 0.0;
         }
         auto utile = [&](const int J) {
             const int c = 16 * J + c16;
@@ -414,11 +418,11 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
             // (per-column constants by the same rule: lane offset + constant; beyond m they read the pool's next array, masked)
             const double cmax = umaxp[c16 + 16 * J], cmin = uminp[c16 + 16 * J], cr2 = R2p[c16 + 16 * J], crl = MODE == 0 ? rlp[c16 + 16 * J] : 0.0;
             {
-                const unsigned jn = 16u * (unsigned)(J + 1 < NJ ? J + 1 : J);
+                const unsigned jn = 128u * (unsigned)(J + 1 < NJ ? J + 1 : J);            // bytes
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    zun[e] = zs[zo[e] + jn];
-                    in0n[e] = MODE == 1 ? W.rdu[ro[e] + jn] : 0.0;
+                    zun[e] = fw_ldb(zs, zo[e] + jn);
+                    in0n[e] = MODE == 1 ? fw_ldb(W.rdu, ro[e] + jn) : 0.0;
                 }
             }
             double o0[8], o1[8];
@@ -447,8 +451,8 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (cok && sok[e]) {
-                    W.rdu[ro[e] + 16u * (unsigned)J] = o0[e];
-                    if (MODE == 1) W.zp[zo[e] + 16u * (unsigned)J] = o1[e];
+                    fw_stb(W.rdu, ro[e] + 128u * (unsigned)J, o0[e]);
+                    if (MODE == 1) fw_stb(W.zp, zo[e] + 128u * (unsigned)J, o1[e]);
                 }
             }
 #pragma unroll
@@ -509,11 +513,11 @@ FW_IN void fw_phase_CT(FwKP Pin, int p, double* lds_g, double* out3_g, int first
             for (int e = 0; e < 8; ++e) {
                 const bool last = sj[e] + 1 == T;
                 // (unsigned element offsets from the wave-uniform array bases: scalar base + one 32-bit offset register per load)
-                const unsigned ov = (unsigned)(sj[e] * N + rc), ox = (unsigned)((last && has_xf ? T : sj[e]) * N + rc);
-                vprev[J][e] = vec[ov];
-                vxf[J][e] = vec[ox];
-                zx[J][e] = zs[(unsigned)(sj[e] * s + m + rc)];
-                xin[J][e] = MODE == 0 ? 0.0 : W.rdx[ov];
+                const unsigned ov = 8u * (unsigned)(sj[e] * N + rc), ox = 8u * (unsigned)((last && has_xf ? T : sj[e]) * N + rc);
+                vprev[J][e] = fw_ldb(vec, ov);
+                vxf[J][e] = fw_ldb(vec, ox);
+                zx[J][e] = fw_ldb(zs, 8u * (unsigned)(sj[e] * s + m + rc));
+                xin[J][e] = MODE == 0 ? 0.0 : fw_ldb(W.rdx, ov);
             }
         }
         // all loads are issued: only now the stores
