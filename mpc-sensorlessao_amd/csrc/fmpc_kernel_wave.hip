@@ -304,24 +304,33 @@ FW_IN void fw_phase_init(FwKP Pin, int p, int write_z) {
         }
     }
     // every load before the first store: a load issued behind a global store waits for it (vmcnt is in order)
+    const double* xfp = W.has_xf ? P->M.xf : P->M.xmid;           // (any readable n-vector when there is no terminal row)
+    const double* nup = nu0 ? nu0 + (size_t)p * nbn : W.nu;        // (nu0 = NULL: zeros -- the loads then read this wave's workspace and a factor drops them)
+    const double nuf = nu0 ? 1.0 : 0.0;
+    const double* wp = w ? w + (size_t)p * W.T * N : nup;          // (w = NULL: zeros, by the same device)
+    const int tn = W.T * N;
     for (int base = 0; base < nbn; base += 64 * 14) {
-        double nv[14], bv[14];
+        double nv[14], bv[14], xfv[14], wv[14];
+        bool isxf[14], wok[14];
 #pragma unroll
         for (int q = 0; q < 14; ++q) {
             const int idx = base + lane + 64 * q;
             const bool ok = idx < nbn;
             const int ic = ok ? idx : 0;
-            nv[q] = nu0 ? nu0[(size_t)p * nbn + ic] : 0.0;
+            nv[q] = nup[ic];
             const int i = ic / N, r = ic - i * N;
-            double v = (i < W.T && w) ? w[(size_t)p * W.T * N + ic] : 0.0;
-            if (base == 0 && q == 0 && ok && i < 2 && i < W.T) v += pred;       // (2 N <= 64: both block rows lie in the first pass)
-            if (i == W.T) v = P->M.xf[r];
+            wv[q] = wp[ic < tn ? ic : 0];
+            wok[q] = w != nullptr && ic < tn;
+            double v = 0.0;
+            if (base == 0 && q == 0 && ok && i < 2 && i < W.T) v = pred;        // (2 N <= 64: both block rows lie in the first pass)
+            xfv[q] = xfp[r];                                          // (unconditional: a load under a condition is a branch with a wait
+            isxf[q] = i == W.T;                                       //  behind it -- fourteen of them serialised the loads of this loop)
             bv[q] = v;
         }
 #pragma unroll
         for (int q = 0; q < 14; ++q) {
             const int idx = base + lane + 64 * q;
-            if (idx < nbn) { W.nu[idx] = nv[q]; W.b[idx] = bv[q]; }
+            if (idx < nbn) { W.nu[idx] = nuf != 0.0 ? nv[q] : 0.0; W.b[idx] = isxf[q] ? xfv[q] : (wok[q] ? wv[q] + bv[q] : bv[q]); }
         }
     }
     if (write_z != 2 && P->step)
