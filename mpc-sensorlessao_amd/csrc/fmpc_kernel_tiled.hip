@@ -38,10 +38,17 @@ extern "C" int fmpc_debug_tiled_timing(unsigned long long* out, int reset) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_timing), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
 #define FT_T0() unsigned long long _t0 = __builtin_readcyclecounter(), _t1
-#define FT_TICK(k) do { _t1 = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) ft_timing[k] += _t1 - _t0; _t0 = _t1; } while (0)
+// (accumulated in LDS by an atomic without return and copied out once at the end: an update in global memory would
+// make every tick wait for all of the wave's loads and stores in flight, which is what the factor phase must not do)
+__shared__ unsigned long long ft_tl[16];
+#define FT_TICK(k) do { _t1 = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ft_tl[k], _t1 - _t0); _t0 = _t1; } while (0)
+#define FT_TL_BEGIN() do { if (threadIdx.x < 16) ft_tl[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define FT_TL_END() do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 16) ft_timing[threadIdx.x] += ft_tl[threadIdx.x]; } while (0)
 #else
 #define FT_T0()
 #define FT_TICK(k)
+#define FT_TL_BEGIN()
+#define FT_TL_END()
 #endif
 
 // upper-triangular tile enumeration (row-major, I <= J)
@@ -266,6 +273,10 @@ __device__ __noinline__ int ft_dense_r(double* sL, const double* R2P, int MP, co
 // nothing but the kernel's parameter block: every pointer and size is rebuilt from it (scalar arithmetic), the LDS map from
 // the same layout function, the tile ownership from the wavefront number.  Returns true when a pivot was not positive.
 typedef const FtParams __attribute__((address_space(4))) * FtKP;
+// The tile-index tables of the constant images (written by the host before the launch, uniform subscripts): read through
+// the constant address space they are scalar loads.  As ordinary global loads each one makes the wave wait for ALL its
+// vector memory traffic in flight (one in-order counter), the tiles requested a stage ahead included.
+typedef const int __attribute__((address_space(4))) * ft_cidx;
 __device__ __forceinline__ FtKP ft_params() { return (FtKP)__builtin_amdgcn_kernarg_segment_ptr(); }
 __device__ __forceinline__ FtKP ft_uniform(FtKP P) {             // a function argument arrives in VGPRs: make it scalar again
     const unsigned long long a = (unsigned long long)P;
@@ -281,6 +292,7 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
     constexpr int SS = (NS + NW - 1) / NW, MS = (NQ + NW - 1) / NW;
     constexpr int STAGE_TILES = 3 * NB * NB, REC_TILES = 3 * NB;
     constexpr bool TS = !(sizeof(R) == 8 && NW == 2);
+    constexpr bool PIPE = sizeof(R) == 4;                   // software-pipelined operand reads (see phase A)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FtKP P = ft_uniform(Pin);
     const int n = P->M.n, m = P->M.m, T = P->M.T, nb = P->M.nb;
@@ -299,7 +311,7 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
     R* fac = (R*)(wsp + L.fac);
     R* gws = (R*)(wsp + L.gt);
     const R* yimg = (const R*)P->V.yimg;
-    const int* Vi1 = P->V.i1; const int* Vi2 = P->V.i2;
+    const ft_cidx Vi1 = (ft_cidx)P->V.i1, Vi2 = (ft_cidx)P->V.i2;
     const int firstS = wv, firstM1 = ((wv - NS) % NW + NW) % NW, firstM2 = ((wv - NS - NQ) % NW + 2 * NW) % NW;
     int sI[SS], sJ[SS];
 #pragma unroll
@@ -315,25 +327,26 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
     // memory -- its S0 tiles and the constant Y_{i,i+1} tiles -- is requested at the top of stage i's phase B,
     // before that stage's factor tiles are stored.
     v4 nS[SS], fS[SS], nM1[MS];                          // S0 tiles of stage i + 1 (loaded, updated in phase A) and i + 2 (in flight)
+    // (every request is unconditional -- a slot without a tile re-reads the last one and nothing uses the result -- so that
+    // the compiler can COUNT the requests between a load and its use: behind a branch it has to assume none were made and
+    // waits for the whole queue instead)
     auto requestS = [&](int i, v4 (&dst)[SS]) {
 #pragma unroll
-        for (int sl = 0; sl < SS; ++sl)
-            if (sI[sl] >= 0) {
-                const R* gt = gws + ((size_t)i * NS + firstS + sl * NW) * FT_TILE;
+        for (int sl = 0; sl < SS; ++sl) {
+            const int t = firstS + sl * NW < NS ? firstS + sl * NW : NS - 1;
+            const R* gt = gws + ((size_t)i * NS + t) * FT_TILE;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[sl][r] = gt[TT::row(g, r) * 16 + c];
-            }
+            for (int r = 0; r < 4; ++r) dst[sl][r] = gt[TT::row(g, r) * 16 + c];
+        }
     };
     auto requestM = [&](int i) {
         const R* Y1 = yimg + (size_t)Vi1[i] * NQ * FT_TILE;
 #pragma unroll
         for (int sl = 0; sl < MS; ++sl) {
-            const int q1 = firstM1 + sl * NW;
-            if (q1 < NQ) {
-                const R* yt = Y1 + (size_t)q1 * FT_TILE;
+            const int q1 = firstM1 + sl * NW < NQ ? firstM1 + sl * NW : NQ - 1;
+            const R* yt = Y1 + (size_t)q1 * FT_TILE;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) nM1[sl][r] = yt[TT::row(g, r) * 16 + c];
-            }
+            for (int r = 0; r < 4; ++r) nM1[sl][r] = yt[TT::row(g, r) * 16 + c];
         }
     };
     v4 cS[SS];                                             // S tiles of the current stage (S0_i - U2_{i-2}' U2_{i-2})
@@ -346,12 +359,78 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
         R* UC = sSLOT + (size_t)(TS ? 1 : uc) * NQ * FT_TILE;
         R* facs = fac + (size_t)i * STAGE_TILES * FT_TILE;
         const R* Y2 = yimg + (size_t)Vi2[i] * NQ * FT_TILE;
+        // the constant Y_{i,i+2} tiles of this stage (no products in phase A: they arrive in its shadow)
+        v4 aM2[MS];
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) {
+            const int q2 = firstM2 + sl * NW < NQ ? firstM2 + sl * NW : NQ - 1;
+            const R* yt = Y2 + (size_t)q2 * FT_TILE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aM2[sl][r] = yt[TT::row(g, r) * 16 + c];
+        }
         // ---------------- phase A: all tiles of the stage, independent
         v4 aS[SS], aM1[MS];
 #pragma unroll
         for (int sl = 0; sl < SS; ++sl) aS[sl] = TS ? cS[sl] : nS[sl];
 #pragma unroll
         for (int sl = 0; sl < MS; ++sl) aM1[sl] = nM1[sl];
+        if constexpr (PIPE) {
+            // fp32: the operands of product j + 1 are in flight while the matrix cores take product j (two accumulators per S
+            // tile, two M1 tiles side by side: no product waits for the one before it either).
+            // The last 16-row block of a stage has NL live rows; the others are zero in every U tile (the rows of W = R^-T
+            // past the block's size are), and product r of a tile pair covers the rows r, 4 + r, 8 + r, 12 + r: with NL < 4
+            // known at compile time only the first NL products of the last block are made (n = 65: one of four).
+            constexpr int KL = (NL > 0 && NL < 4) ? NL : 4;
+            const R* UB2 = TS ? UB : UC;
+#pragma unroll
+            for (int sl = 0; sl < SS; ++sl) {
+                const int I = sI[sl], J = sJ[sl];
+                if (I >= 0) {
+                    const R* pa = UA + (size_t)I * FT_TILE; const R* qa = UA + (size_t)J * FT_TILE;
+                    const R* pb = UB2 + (size_t)I * FT_TILE; const R* qb = UB2 + (size_t)J * FT_TILE;
+                    v4 xa = TT::ld4(pa, lane), za = TT::ld4(qa, lane), xb = TT::ld4(pb, lane), zb = TT::ld4(qb, lane);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        v4 nxa = xa, nza = za, nxb = xb, nzb = zb;
+                        if (j + 1 < NB) {
+                            const int o = (j + 1) * NB * FT_TILE;
+                            nxa = TT::ld4(pa + o, lane); nza = TT::ld4(qa + o, lane); nxb = TT::ld4(pb + o, lane); nzb = TT::ld4(qb + o, lane);
+                        }
+#pragma unroll
+                        for (int r = 0; r < (j == NB - 1 ? KL : 4); ++r) {
+                            aS[sl] = TT::mfma_sub(xa[r], za[r], aS[sl]);
+                            if (TS) nS[sl] = TT::mfma_sub(xb[r], zb[r], nS[sl]);       // for S_{i+1}
+                        }
+                        if (!TS) ft_xtz_sub<R>(aS[sl], xb, zb);
+                        xa = nxa; za = nza; xb = nxb; zb = nzb;
+                    }
+                }
+            }
+            auto m1chain2 = [&](v4& a0, v4& a1, int q0, int q1) {
+                const R* p0 = UA + (size_t)(q0 / NB) * FT_TILE; const R* z0 = UB + (size_t)(q0 % NB) * FT_TILE;
+                const R* p1 = UA + (size_t)(q1 / NB) * FT_TILE; const R* z1 = UB + (size_t)(q1 % NB) * FT_TILE;
+                v4 x0 = TT::ld4(p0, lane), y0 = TT::ld4(z0, lane), x1 = TT::ld4(p1, lane), y1 = TT::ld4(z1, lane);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    v4 nx0 = x0, ny0 = y0, nx1 = x1, ny1 = y1;
+                    if (j + 1 < NB) {
+                        const int o = (j + 1) * NB * FT_TILE;
+                        nx0 = TT::ld4(p0 + o, lane); ny0 = TT::ld4(z0 + o, lane); nx1 = TT::ld4(p1 + o, lane); ny1 = TT::ld4(z1 + o, lane);
+                    }
+#pragma unroll
+                    for (int r = 0; r < (j == NB - 1 ? KL : 4); ++r) { a0 = TT::mfma_sub(x0[r], y0[r], a0); a1 = TT::mfma_sub(x1[r], y1[r], a1); }
+                    x0 = nx0; y0 = ny0; x1 = nx1; y1 = ny1;
+                }
+            };
+#pragma unroll
+            for (int sl = 0; sl < MS; sl += 2) {
+                const int q0 = firstM1 + sl * NW, q1 = firstM1 + (sl + 1) * NW;
+                if (sl + 1 < MS && q1 < NQ) m1chain2(aM1[sl], aM1[sl + 1 < MS ? sl + 1 : sl], q0, q1);
+                else if (q0 < NQ)
+                    ft_xtz_chain<R>(aM1[sl], NB, lane, [&](int j) { return UA + (size_t)(j * NB + q0 / NB) * FT_TILE; },
+                                    [&](int j) { return UB + (size_t)(j * NB + q0 % NB) * FT_TILE; });
+            }
+        } else {
 #pragma unroll
         for (int sl = 0; sl < SS; ++sl) {
             const int I = sI[sl], J = sJ[sl];
@@ -374,26 +453,45 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     ft_xtz_sub<R>(aM1[sl], UA + (size_t)(j * NB + I) * FT_TILE, UB + (size_t)(j * NB + J) * FT_TILE, lane);
             }
         }
+        }
         ft_lds_barrier();                                      // Ua, Ub are dead from here: their slots take U1_i, U2_i
         FT_TICK(3);
         R* U1N = UA; R* U2N = TS ? UB : UC;
-        if (!TS && i + 1 < nb) requestS(i + 1, nS);
-        if (i + 1 < nb) requestM(i + 1);
-        if (TS) requestS(i + 2 < nb ? i + 2 : nb - 1, fS);     // (harmless re-read at the end of the horizon)
-        v4 aM2[MS];                                            // Y_{i,i+2} tiles: constant, no products in phase A
+        if (!TS) requestS(i + 1 < nb ? i + 1 : nb - 1, nS);    // (harmless re-reads at the end of the horizon)
+        requestM(i + 1 < nb ? i + 1 : i);
+        if (TS) requestS(i + 2 < nb ? i + 2 : nb - 1, fS);
+        // aM2 (requested at the top of the stage) has to be there now.  Said here, with the count of the requests just made,
+        // because the loop over kb has stores and no load: the compiler then drains the memory counter once in front of
+        // such a loop if anything used inside is still in flight -- every tile requested above would be waited for here
+        // instead of a stage later.  (An empty statement the compiler cannot see through: it waits for exactly these.)
 #pragma unroll
-        for (int sl = 0; sl < MS; ++sl) {
-            const int q2 = firstM2 + sl * NW;
-            if (q2 < NQ) {
-                const R* yt = Y2 + (size_t)q2 * FT_TILE;
+        for (int sl = 0; sl < MS; ++sl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) aM2[sl][r] = yt[TT::row(g, r) * 16 + c];
-            }
-        }
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(aM2[sl][r]));
+        FT_TICK(11);
         // ---------------- phase B: the 16-row blocks of the stage, in order
         for (int kb = 0; kb < NB; ++kb) {
             int cnt = n - 16 * kb; cnt = cnt > 16 ? 16 : (cnt < 0 ? 0 : cnt);
             // (1) products with the rows of this stage already done
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int sl = 0; sl < SS; ++sl)
+                    if (sI[sl] == kb) {
+                        const int J = sJ[sl];
+                        ft_xtz_chain<R>(aS[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
+                                        [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, J) * FT_TILE; });
+                    }
+#pragma unroll
+                for (int sl = 0; sl < MS; ++sl) {
+                    const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
+                    if (q1 < NQ && q1 / NB == kb)
+                        ft_xtz_chain<R>(aM1[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
+                                        [&](int j) { return U1N + (size_t)(j * NB + q1 % NB) * FT_TILE; });
+                    if (q2 < NQ && q2 / NB == kb)
+                        ft_xtz_chain<R>(aM2[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
+                                        [&](int j) { return U2N + (size_t)(j * NB + q2 % NB) * FT_TILE; });
+                }
+            } else {
 #pragma unroll
             for (int sl = 0; sl < SS; ++sl)
                 if (sI[sl] == kb)
@@ -413,6 +511,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                                       U2N + (size_t)(j * NB + q2 % NB) * FT_TILE, lane);
                 }
             }
+            }
+            FT_TICK(kb == 0 ? 9 : 11 + kb);
             // (2) the rhs column of this row block, still unscaled: shared with the owners of M1(kb,cn), M2(kb,cn);
             //     the owner of the diagonal tile factors it
 #pragma unroll
@@ -446,6 +546,7 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     aS[sl] = Ro;
                 }
             }
+            FT_TICK(10);
             ft_lds_barrier();
             FT_TICK(4);
             // (3) scale the tiles of the row: Rwide(kb, .) = W P(kb, .)
@@ -461,7 +562,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     R* dl = sLT + (size_t)ft_lt_index(NB, kb, sJ[sl]) * FT_TILE;
                     R* dg = facs + (size_t)(kb * REC_TILES + sJ[sl]) * FT_TILE;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                    for (int r = 0; r < 4; ++r) dg[TT::row(g, r) * 16 + c] = o[r];
+                    TT::st4(dl, lane, o);
                     if (sJ[sl] == cn && c == nl) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -487,7 +589,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     R* dl = U1N + (size_t)q1 * FT_TILE;
                     R* dg = facs + (size_t)(kb * REC_TILES + NB + J) * FT_TILE;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                    for (int r = 0; r < 4; ++r) dg[TT::row(g, r) * 16 + c] = o[r];
+                    TT::st4(dl, lane, o);
                 }
                 if (q2 < NQ && q2 / NB == kb) {
                     const int J = q2 % NB;
@@ -502,7 +605,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     R* dl = U2N + (size_t)q2 * FT_TILE;
                     R* dg = facs + (size_t)(kb * REC_TILES + 2 * NB + J) * FT_TILE;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { dl[TT::row(g, r) * 16 + c] = o[r]; dg[TT::row(g, r) * 16 + c] = o[r]; }
+                    for (int r = 0; r < 4; ++r) dg[TT::row(g, r) * 16 + c] = o[r];
+                    TT::st4(dl, lane, o);
                 }
             }
             ft_lds_barrier();
@@ -543,7 +647,7 @@ __device__ __noinline__ void ft_phase_spre(FtKP Pin) {
     double* yv = wsp + L.y;
     R* gws = (R*)(wsp + L.gt);
     const R* yimg = (const R*)P->V.yimg;
-    const int* ViD = P->V.iD;
+    const ft_cidx ViD = (ft_cidx)P->V.iD;
     {
         const R* src = (const R*)P->V.btimg;
         for (int q = tid; q < mb * NB * FT_TILE; q += NT) sBT[q] = src[q];
@@ -925,6 +1029,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
     const int s = n + m, Nz = T * s, nbn = nb * n;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
+    FT_TL_BEGIN();
     const bool var2 = M.var2 != 0;
     const int mb = V.mb, cn = V.cn, nl = V.nl;
 
@@ -1150,6 +1255,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             if (P.iters) P.iters[p] = nsteps;
         }
     }
+    FT_TL_END();
 }
 
 // ---------------------------------------------------------------- host side

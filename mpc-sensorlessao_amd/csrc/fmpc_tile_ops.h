@@ -27,6 +27,10 @@ template <> struct FtT<double> {
         lo = __builtin_amdgcn_readlane(lo, l); hi = __builtin_amdgcn_readlane(hi, l);
         return __hiloint2double(hi, lo);
     }
+    // A tile in LDS as the matrix cores take it: operand r of lane l is element 64 r + l of the row-major tile, which is
+    // also where accumulator register r of that lane belongs (row g + 4 r, column c).
+    static __device__ __forceinline__ v4 ld4(const double* t, int lane) { v4 v = {t[lane], t[64 + lane], t[128 + lane], t[192 + lane]}; return v; }
+    static __device__ __forceinline__ void st4(double* t, int lane, v4 v) { t[lane] = v[0]; t[64 + lane] = v[1]; t[128 + lane] = v[2]; t[192 + lane] = v[3]; }
     static __device__ __forceinline__ double rsqrt(double d) {
         double y = __builtin_amdgcn_rsq(d);
         const double h = 0.5 * d;
@@ -46,6 +50,11 @@ template <> struct FtT<float> {
     static __device__ __forceinline__ float readlane(float v, int l) {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
     }
+    // A tile in LDS is the REGISTER IMAGE of its accumulator: the four registers of lane l (rows 4 g .. 4 g + 3 of column c)
+    // at 4 l .. 4 l + 3, one 16-byte access per lane either way.  As operands of X'Z the k-slot g of product r is then row
+    // 4 g + r of both tiles: a permutation of the sum over rows, the same on both sides.
+    static __device__ __forceinline__ v4 ld4(const float* t, int lane) { return *(const v4*)(t + 4 * lane); }
+    static __device__ __forceinline__ void st4(float* t, int lane, v4 v) { *(v4*)(t + 4 * lane) = v; }
     static __device__ __forceinline__ float rsqrt(float d) {
         float y = __builtin_amdgcn_rsqf(d);
         y = y * fmaf(-0.5f * d * y, y, 1.5f);
@@ -112,10 +121,27 @@ __device__ __forceinline__ void ft_vec_gemm(ft_d4& acc, int K, int g, XF xf, ZF 
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf(k0 + g), zf(k0 + g), acc, 0, 0, 0);
 }
 
-// acc -= X' Z for two row-major 16 x 16 tiles in LDS (64 consecutive elements per operand read)
-template <typename R> __device__ __forceinline__ void ft_xtz_sub(typename FtT<R>::v4& acc, const R* X, const R* Z, int lane) {
+// acc -= X' Z for two 16 x 16 tiles in LDS (layout: FtT<R>::ld4 / st4)
+template <typename R> __device__ __forceinline__ void ft_xtz_sub(typename FtT<R>::v4& acc, typename FtT<R>::v4 x, typename FtT<R>::v4 z) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = FtT<R>::mfma_sub(X[64 * r + lane], Z[64 * r + lane], acc);
+    for (int r = 0; r < 4; ++r) acc = FtT<R>::mfma_sub(x[r], z[r], acc);
+}
+template <typename R> __device__ __forceinline__ void ft_xtz_sub(typename FtT<R>::v4& acc, const R* X, const R* Z, int lane) {
+    ft_xtz_sub<R>(acc, FtT<R>::ld4(X, lane), FtT<R>::ld4(Z, lane));
+}
+// The same over a chain of cnt products into one accumulator, xf(j), zf(j) the operand tiles of product j: the operands
+// of product j + 1 are requested before the matrix cores take product j (an LDS read is ~130 cycles, a product 4 x 32).
+template <typename R, class XF, class ZF>
+__device__ __forceinline__ void ft_xtz_chain(typename FtT<R>::v4& acc, int cnt, int lane, XF xf, ZF zf) {
+    typedef FtT<R> TT;
+    if (cnt <= 0) return;
+    typename TT::v4 x = TT::ld4(xf(0), lane), z = TT::ld4(zf(0), lane);
+    for (int j = 0; j < cnt; ++j) {
+        typename TT::v4 nx = x, nz = z;
+        if (j + 1 < cnt) { nx = TT::ld4(xf(j + 1), lane); nz = TT::ld4(zf(j + 1), lane); }
+        ft_xtz_sub<R>(acc, x, z);
+        x = nx; z = nz;
+    }
 }
 
 // Cholesky of the leading cnt x cnt part of the symmetric tile P (accumulator layout) in the R form, P = R'R, by
