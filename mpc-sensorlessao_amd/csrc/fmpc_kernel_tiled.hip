@@ -57,7 +57,19 @@ __device__ __forceinline__ int ft_lt_index(int NB, int I, int J) { return I * NB
 // P4 as a function of its own (not inlined): the backward sweep needs few registers, but inside the kernel body it
 // inherits the register pressure of the factor phase and its loads get spilled addresses with full waits in front.
 template <typename R, int NB, int NW>
-__device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV, R* sPART, double* sNU, int n, int nb, int NUROWS) {
+__device__ __noinline__ void ft_backward(const R* fac_, const double* yv_, R* sXV_, R* sPART_, double* sNU_, int n, int nb, int NUROWS) {
+    // The arguments arrive as generic pointers: left so, every access below is a FLAT one -- counted on both memory
+    // counters, possibly out of order, so the compiler waits for everything in flight before each use and no request can
+    // stay ahead of the step it is for.  Said with their address spaces they are global loads and LDS accesses.
+    typedef const R __attribute__((address_space(1))) * GR;
+    typedef const double __attribute__((address_space(1))) * GD;
+    typedef R __attribute__((address_space(3))) * LR;
+    typedef const R __attribute__((address_space(3))) * LCR;
+    typedef double __attribute__((address_space(3))) * LD;
+    const GR fac = (GR)fac_;
+    const GD yv = (GD)yv_;
+    const LR sXV = (LR)sXV_, sPART = (LR)sPART_;
+    const LD sNU = (LD)sNU_;
     constexpr int NT = NW * 64, NP = 16 * NB, NQ = NB * NB, REC_TILES = 3 * NB, LDN = 16 * NB + 1;
     (void)NQ;
     const int tid = threadIdx.x;
@@ -70,24 +82,36 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
     for (int q = tid; q < NUROWS * LDN; q += NT) sNU[q] = 0.0;   // d_nu as [stage][state] for P5 (the U slots are dead)
     __syncthreads();
     if (NB > 2) {
-        // one record (block row) per iteration.  (This plain form is what the compiler handles best for the large
-        // blocks: 0.96 M cycles per problem at (65, 144, 60) against 1.4 - 3.7 M for the grouped loop below.)
-        for (int blk = nb * NB - 1; blk >= 0; --blk) {
-            const int i = blk / NB, kb = blk - i * NB;
-            const R* rec = fac + (size_t)blk * REC_TILES * FT_TILE + ta * 16 + tb;
-            R tv[MAXT][RPT], riv[RPT];
+        // One record (block row) per step, the records of the NEXT G steps requested a group ahead: the factor stream of a
+        // problem (4.6 MB at n = 65) comes from HBM, a round trip of a few thousand cycles against ~700 for the step itself.
+        // (Every load unconditional at a constant offset from an opaque record offset: see the grouped loop below.)
+        constexpr int G = 3;
+        R tvA[G][MAXT][RPT], rivA[G][RPT];
+        double ybA[G];
+        auto request = [&](int base, R (&tv)[G][MAXT][RPT], R (&riv)[G][RPT], double (&yb)[G]) {
 #pragma unroll
-            for (int q = 0; q < MAXT; ++q) {
-                const int t = 1 + tg + q * NG;
-                const int tc = t < REC_TILES ? t : REC_TILES - 1;
+            for (int u = 0; u < G; ++u) {
+                const int blk = base - u < 0 ? 0 : base - u;       // (past the top of the horizon: a harmless re-read)
+                unsigned off = (unsigned)blk * (unsigned)(REC_TILES * FT_TILE) + (unsigned)(ta * 16 + tb);
+                asm volatile("" : "+v"(off));
+                const GR rec = fac + off;
 #pragma unroll
-                for (int h = 0; h < RPT; ++h) tv[q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
+                for (int q = 0; q < MAXT; ++q) {
+                    const int t = 1 + tg + q * NG;
+                    const int tc = t < REC_TILES ? t : REC_TILES - 1;
+#pragma unroll
+                    for (int h = 0; h < RPT; ++h) tv[u][q][h] = rec[tc * FT_TILE + RSTEP * h * 16];
+                }
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) riv[u][h] = rec[RSTEP * h * 16];
+                const int i = blk / NB, kb = blk - i * NB, yrow = 16 * kb + tb;
+                yb[u] = yv[i * n + (yrow < n ? yrow : n - 1)];
             }
-#pragma unroll
-            for (int h = 0; h < RPT; ++h) riv[h] = rec[RSTEP * h * 16];
+        };
+        auto step = [&](int blk, R (&tv)[MAXT][RPT], R (&riv)[RPT], double yb) {
+            const int i = blk / NB, kb = blk - i * NB;
             const int yrow = 16 * kb + tb;
-            const R ybv = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
-            R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+            const LR XC = sXV + (i % 3) * NP; const LCR X1 = sXV + ((i + 1) % 3) * NP; const LCR X2 = sXV + ((i + 2) % 3) * NP;
             R accv[RPT];
 #pragma unroll
             for (int h = 0; h < RPT; ++h) accv[h] = (R)0;
@@ -95,7 +119,7 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
             for (int q = 0; q < MAXT; ++q) {
                 const int t = 1 + tg + q * NG;
                 const int tc = t < REC_TILES ? t : REC_TILES - 1;
-                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                const LCR xvv = tc < NB ? (LCR)XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
                 const bool use = t < REC_TILES && (t >= NB || t > kb);
                 const R xraw = xvv[tb];
                 const R xb = use ? xraw : (R)0;
@@ -109,7 +133,7 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
             }
             ft_lds_barrier();
             if (tg == 0) {
-                R sb = yrow < n ? ybv : (R)0;
+                R sb = yrow < n ? (R)yb : (R)0;
 #pragma unroll
                 for (int q = 0; q < NG; ++q) sb -= sPART[q * 16 + tb];
 #pragma unroll
@@ -123,6 +147,31 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
                 }
             }
             ft_lds_barrier();
+        };
+        // the records that do not fill a group first (no branch inside the pipelined loop: behind one the compiler
+        // cannot count the requests in flight and waits for all of them)
+        int base = nb * NB - 1;
+        for (int left = (nb * NB) % G; left > 0; --left, --base) {
+            request(base, tvA, rivA, ybA);
+            step(base, tvA[0], rivA[0], ybA[0]);
+        }
+        request(base, tvA, rivA, ybA);
+        for (; base >= 0; base -= G) {
+            R tvB[G][MAXT][RPT], rivB[G][RPT];
+            double ybB[G];
+            request(base - G, tvB, rivB, ybB);
+#pragma unroll
+            for (int u = 0; u < G; ++u) step(base - u, tvA[u], rivA[u], ybA[u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int q = 0; q < MAXT; ++q)
+#pragma unroll
+                    for (int h = 0; h < RPT; ++h) tvA[u][q][h] = tvB[u][q][h];
+#pragma unroll
+                for (int h = 0; h < RPT; ++h) rivA[u][h] = rivB[u][h];
+                ybA[u] = ybB[u];
+            }
         }
     } else {
     // KBB records (block rows) are requested together: the whole stage for small blocks (one memory round trip per
@@ -139,8 +188,8 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
             //  load into loop-carried registers, spills them, and reloads each -- with a full wait -- before its load)
             unsigned off = (unsigned)(i * NB + kb) * (unsigned)(REC_TILES * FT_TILE) + (unsigned)(ta * 16 + tb);
             asm volatile("" : "+v"(off));
-            const R* rec = fac + off;
-            const R* rtg = rec + tg * FT_TILE;               // this thread group's first tile is 1 + tg: constant strides from here
+            const GR rec = fac + off;
+            const GR rtg = rec + tg * FT_TILE;               // this thread group's first tile is 1 + tg: constant strides from here
             constexpr bool EXACT = (REC_TILES - 1) % NG == 0;   // no group runs past the record: no clamping
 #pragma unroll
             for (int q = 0; q < MAXT; ++q) {
@@ -159,7 +208,7 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
             const int yrow = 16 * kb + tb;
             ybv[kk] = (R)yv[i * n + (yrow < n ? yrow : n - 1)];
         }
-        R* XC = sXV + (i % 3) * NP; const R* X1 = sXV + ((i + 1) % 3) * NP; const R* X2 = sXV + ((i + 2) % 3) * NP;
+        const LR XC = sXV + (i % 3) * NP; const LCR X1 = sXV + ((i + 1) % 3) * NP; const LCR X2 = sXV + ((i + 2) % 3) * NP;
 #pragma unroll
         for (int kk = KBB - 1; kk >= 0; --kk) {
             const int kb = kb0 + kk;
@@ -170,7 +219,7 @@ __device__ __noinline__ void ft_backward(const R* fac, const double* yv, R* sXV,
             for (int q = 0; q < MAXT; ++q) {
                 const int t = 1 + tg + q * NG;         // tile of the record: R(kb, t) | U1(kb, t - NB) | U2(kb, t - 2 NB)
                 const int tc = t < REC_TILES ? t : REC_TILES - 1;
-                const R* xvv = tc < NB ? XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
+                const LCR xvv = tc < NB ? (LCR)XC + 16 * tc : (tc < 2 * NB ? X1 + 16 * (tc - NB) : X2 + 16 * (tc - 2 * NB));
                 const bool use = t < REC_TILES && (t >= NB || t > kb);     // (tiles 1..kb of a record do not exist)
                 const R xraw = xvv[tb];                // (unconditional: always a valid LDS address)
                 const R xb = use ? xraw : (R)0;
@@ -512,7 +561,7 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                 }
             }
             }
-            FT_TICK(kb == 0 ? 9 : 11 + kb);
+            FT_TICK(9);
             // (2) the rhs column of this row block, still unscaled: shared with the owners of M1(kb,cn), M2(kb,cn);
             //     the owner of the diagonal tile factors it
 #pragma unroll
@@ -1202,8 +1251,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fmpc_newton_tiled(FtParams P) {
             // ================= S pre-pass: the initial diagonal blocks S0_i = Y_ii const + B W_i B' (upper-triangular tiles,
             // rhs_i in column n) of EVERY block row, all independent, ahead of the serial factorisation.  The B' tiles are
             // in LDS only for this (the factor phase reuses the space); Phi^-1 of FT_GCH stages at a time in LDS.
+            FT_TICK(12);
             ft_phase_spre<R, NB, NW, DR>(ft_params());                 // (not inlined: see ft_phase_factor)
             __syncthreads();
+            FT_TICK(13);
             // zero the three U slots: stages 0 and 1 then need no special cases
             constexpr bool TS = !(sizeof(R) == 8 && NW == 2);       // two U slots (ft_u_slots): see below
             for (int q = tid; q < (TS ? 2 : 3) * NQ * FT_TILE; q += NT) sSLOT[q] = (R)0;
