@@ -572,12 +572,14 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                 }
                 if (sI[sl] == kb && sJ[sl] == kb) {
                     v4 Ro, Wo;
+                    FT_TICK(14);
                     __builtin_amdgcn_s_setprio(3);             // a chain of dependent steps: issue ahead of the SIMD's other wave
                     bool ok;
                     if (kb < NB - 1) ok = ft_potrf16_ct<R, 16>(aS[sl], c, g, Ro, Wo);        // (all blocks but the last are full)
                     else if (NL >= 0) ok = ft_potrf16_ct<R, (NL >= 0 ? NL : 0)>(aS[sl], c, g, Ro, Wo);
                     else ok = ft_potrf16<R>(aS[sl], cnt, c, g, Ro, Wo);
                     __builtin_amdgcn_s_setprio(0);
+                    FT_TICK(15);
                     if (!ok && lane == 0) sflag[0] = 1;
                     R* ri = facs + (size_t)(kb * REC_TILES) * FT_TILE;   // R(kb,kb)^-1 = W' for the backward sweep
 #pragma unroll

@@ -27,7 +27,7 @@ for rep in range(2):
     lib.fmpc_debug_tiled_timing(out, 0)
 names = {0: "P0 init", 1: "P1 residuals", 12: "P2 rhs", 13: "P2 S pre-pass", 2: "P2 slot clear", 6: "P3 factor + forward sweep (whole phase)", 7: "P4 backward",
          8: "P5 dz + update"}
-sub = {3: "P3.A stage products", 11: "P3.B requests of the next stage's tiles", 9: "P3.B row products", 10: "P3.B diagonal tile (potrf when wave 0 owns it)", 4: "P3.B wait at the barrier",
+sub = {3: "P3.A stage products", 11: "P3.B requests of the next stage's tiles", 9: "P3.B row products", 14: "P3.B before the potrf (wave 0 owns the tile)", 15: "P3.B potrf itself", 10: "P3.B diagonal tile: rest, stores", 4: "P3.B wait at the barrier",
        5: "P3.B scale + store (to barrier)"}
 tot = sum(out[i] for i in names) or 1
 print(f"tiled kernel n={n} T={T} batch={B} {'fp32' if (f32 or n > 47) else 'fp64'}: {a.elapsed_time(b):.3f} ms; cycles of workgroup 0, wave 0 over its problems:")
