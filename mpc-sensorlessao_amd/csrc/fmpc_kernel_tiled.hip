@@ -369,6 +369,17 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
         if (t < NS) { while (t >= NB - I) { t -= NB - I; ++I; } sI[sl] = I; sJ[sl] = I + t; }
         else { sI[sl] = -1; sJ[sl] = -1; }
     }
+    // block row / column of every M1, M2 slot of this wave (-1: no tile), once: the tests in the loop over kb below are
+    // then a compare each.  (That loop visits every slot of the wave per block row to find the three or four that are in
+    // it; the tests, not the products, were a fifth of its time.)
+    int rM1[MS], cM1[MS], rM2[MS], cM2[MS];
+#pragma unroll
+    for (int sl = 0; sl < MS; ++sl) {
+        const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
+        rM1[sl] = q1 < NQ ? q1 / NB : -1; cM1[sl] = q1 % NB;
+        rM2[sl] = q2 < NQ ? q2 / NB : -1; cM2[sl] = q2 % NB;
+    }
+#define FT_UNLIKELY(x) __builtin_expect(!!(x), 0)
     FT_T0();
     bool fail = false;
     int ub = 1, uc = 2;                                     // !TS: roles of the slots 1 and 2
@@ -525,20 +536,23 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
             if constexpr (PIPE) {
 #pragma unroll
                 for (int sl = 0; sl < SS; ++sl)
-                    if (sI[sl] == kb) {
+                    if (FT_UNLIKELY(sI[sl] == kb)) {
                         const int J = sJ[sl];
                         ft_xtz_chain<R>(aS[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
                                         [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, J) * FT_TILE; });
                     }
 #pragma unroll
                 for (int sl = 0; sl < MS; ++sl) {
-                    const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
-                    if (q1 < NQ && q1 / NB == kb)
+                    if (FT_UNLIKELY(rM1[sl] == kb)) {
+                        const int J = cM1[sl];
                         ft_xtz_chain<R>(aM1[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
-                                        [&](int j) { return U1N + (size_t)(j * NB + q1 % NB) * FT_TILE; });
-                    if (q2 < NQ && q2 / NB == kb)
+                                        [&](int j) { return U1N + (size_t)(j * NB + J) * FT_TILE; });
+                    }
+                    if (FT_UNLIKELY(rM2[sl] == kb)) {
+                        const int J = cM2[sl];
                         ft_xtz_chain<R>(aM2[sl], kb, lane, [&](int j) { return sLT + (size_t)ft_lt_index(NB, j, kb) * FT_TILE; },
-                                        [&](int j) { return U2N + (size_t)(j * NB + q2 % NB) * FT_TILE; });
+                                        [&](int j) { return U2N + (size_t)(j * NB + J) * FT_TILE; });
+                    }
                 }
             } else {
 #pragma unroll
@@ -566,11 +580,11 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
             //     the owner of the diagonal tile factors it
 #pragma unroll
             for (int sl = 0; sl < SS; ++sl) {
-                if (sI[sl] == kb && sJ[sl] == cn && c == nl) {
+                if (FT_UNLIKELY(sI[sl] == kb) && sJ[sl] == cn && c == nl) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sYSH[TT::row(g, r)] = aS[sl][r];
                 }
-                if (sI[sl] == kb && sJ[sl] == kb) {
+                if (FT_UNLIKELY(sI[sl] == kb && sJ[sl] == kb)) {
                     v4 Ro, Wo;
                     FT_TICK(14);
                     __builtin_amdgcn_s_setprio(3);             // a chain of dependent steps: issue ahead of the SIMD's other wave
@@ -606,7 +620,7 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
             for (int r = 0; r < 4; ++r) wop[r] = sWT[TT::row(g, r) * FT_WLD + c];
 #pragma unroll
             for (int sl = 0; sl < SS; ++sl) {
-                if (sI[sl] == kb && sJ[sl] > kb) {
+                if (FT_UNLIKELY(sI[sl] == kb && sJ[sl] > kb)) {
                     v4 o = {0, 0, 0, 0};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], aS[sl][r], o);
@@ -627,8 +641,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
 #pragma unroll
             for (int sl = 0; sl < MS; ++sl) {
                 const int q1 = firstM1 + sl * NW, q2 = firstM2 + sl * NW;
-                if (q1 < NQ && q1 / NB == kb) {
-                    const int J = q1 % NB;
+                if (FT_UNLIKELY(rM1[sl] == kb)) {
+                    const int J = cM1[sl];
                     v4 pv = aM1[sl];
                     if (J == cn && c == nl) {
 #pragma unroll
@@ -643,8 +657,8 @@ __device__ __noinline__ bool ft_phase_factor(FtKP Pin) {
                     for (int r = 0; r < 4; ++r) dg[TT::row(g, r) * 16 + c] = o[r];
                     TT::st4(dl, lane, o);
                 }
-                if (q2 < NQ && q2 / NB == kb) {
-                    const int J = q2 % NB;
+                if (FT_UNLIKELY(rM2[sl] == kb)) {
+                    const int J = cM2[sl];
                     v4 pv = aM2[sl];
                     if (J == cn && c == nl) {
 #pragma unroll
