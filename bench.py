@@ -614,6 +614,9 @@ def _main(real_out):
                                                                 "windows, ad_est, b_ref, fastMPC step, first moves", "ms_per_loop_step": dt / 35 * 1e3,
                                                        "value": 35 / dt, "unit": "loop steps/s"}
             phc_ = ph_.transpose(-1, -2).contiguous()                                       # the order MATLAB keeps phase_valid(:,:,k) in
+            for s_ in range(5):                                                             # (warm-up of this form too, as above)
+                ao_.step(phc_[s_], colmajor=True)
+            torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for s_ in range(5, 40):
                 ao_.step(phc_[s_], colmajor=True)
