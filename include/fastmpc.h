@@ -229,7 +229,11 @@ int fmpc_loop_step_device(fmpc_handle h, int batch, const double* a_k, const dou
  * at (27, 144, 30)); a step whose step-length decision is not clear-cut ends that walk, the exact path redoes the step and the
  * walk goes on behind it -- same results as one call per step (bit for bit up to 64 realisations, where the one-step call
  * uses the same form; to rounding, 1e-13, beyond).  In that case the call SYNCHRONISES the stream
- * (the host has to see where the walks stopped): the results are complete when it returns.
+ * (the host has to see where the walks stopped): the results are complete when it returns.  The number of walks of a call is
+ * capped: after 8 of them (FMPC_WALK_MAX_RESTARTS), or when more than a tenth of the realisations stop in one walk, the rest of
+ * the stretch is done stepwise -- the realisations furthest behind take one step through the one-step call until all have
+ * arrived: at most `steps` such calls, none synchronises -- so a stretch where most steps are not clear-cut costs about what
+ * one call per step does, not a batch-wide launch per stop.
  */
 int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, const double* nu0,
                          const double* u_before1, const double* u_before2, int have_x0_last,

@@ -1654,8 +1654,27 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
                               double* x0, double* x0_pre, double* w, double* U0, double* X0, int* status, int* iters, hipStream_t stream) {
     const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
     std::vector<int> start(batch, 0), stop(batch, 0), idx, stp;      // (host sides of asynchronous copies: alive until the function returns)
+    std::vector<std::vector<int>> keep;                              // index lists of the stepwise mode (no synchronisation between its copies)
+    // Every walk costs a synchronisation, and every stop a gather + one-step call + scatter + a new batch-wide launch: on a stretch
+    // where many steps are not clear-cut that is slower than one call per step.  After `max_restarts` walks, or when more than a
+    // tenth of the realisations stop in one walk, the rest of the stretch is done STEPWISE: the realisations that are furthest
+    // behind take one step through the one-step call (a compact batch, as for a stopped step) until all have arrived -- at most
+    // `upto` such calls, none of them synchronises.
+    int max_restarts = 8, restarts = 0;
+    { const char* e = getenv("FMPC_WALK_MAX_RESTARTS"); if (e && e[0] >= '0' && e[0] <= '9') max_restarts = atoi(e); }
+    bool stepwise = false;
     for (;;) {
-        {
+        if (stepwise) {
+            int smin = upto;
+            for (int p = 0; p < batch; ++p) smin = start[p] < smin ? start[p] : smin;
+            if (smin >= upto) return FMPC_OK;
+            keep.emplace_back(); keep.emplace_back();
+            std::vector<int>& ki = keep[keep.size() - 2];
+            std::vector<int>& ks = keep[keep.size() - 1];
+            for (int p = 0; p < batch; ++p)
+                if (start[p] == smin) { ki.push_back(p); ks.push_back(smin); start[p] = smin + 1; }
+            idx = ki; stp = ks;
+        } else {
             if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
             std::lock_guard<std::mutex> lk(h->mu);
             int rc = fmpc_guard_begin(h, stream);
@@ -1691,15 +1710,19 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
         }
         // the stopped realisations, each at its own step, as ONE compact batch through the one-step call (its exact path redoes
         // them), results scattered back; then the walks go on behind those steps
-        idx.clear(); stp.clear();
-        for (int p = 0; p < batch; ++p) {
-            if (stop[p] >= upto) { start[p] = upto; continue; }
-            idx.push_back(p); stp.push_back(stop[p]);
-            start[p] = stop[p] + 1;
+        if (!stepwise) {
+            idx.clear(); stp.clear();
+            for (int p = 0; p < batch; ++p) {
+                if (stop[p] >= upto) { start[p] = upto; continue; }
+                idx.push_back(p); stp.push_back(stop[p]);
+                start[p] = stop[p] + 1;
+            }
         }
         const bool done = idx.empty();
         if (!done) {
             const int cnt = (int)idx.size();
+            const int* hidx = stepwise ? keep[keep.size() - 2].data() : idx.data();
+            const int* hstp = stepwise ? keep[keep.size() - 1].data() : stp.data();
             FmCompact C;
             C.cnt = cnt; C.n = h->n; C.m = h->m; C.T = h->T; C.nb = h->nb; C.batch = batch; C.have_x0_last = have_x0_last;
             C.a = a; C.nu0 = nu0; C.U0 = U0; C.X0 = X0; C.ub1 = ub1; C.ub2 = ub2;
@@ -1710,8 +1733,8 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
                 int* d_stp = h->fm_walk_i + h->fm_walk_cap;
                 fmpc_compact_carve(C, h->fm_compact, (int)h->fm_walk_cap);
                 C.idx = d_idx; C.stp = d_stp;
-                if (hipMemcpyAsync(d_idx, idx.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
-                    hipMemcpyAsync(d_stp, stp.data(), cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                if (hipMemcpyAsync(d_idx, hidx, cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(d_stp, hstp, cnt * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
                     fmpc_launch_walk_gather(C, stream) != hipSuccess) return FMPC_E_HIP;
             }
             const int rc = fmpc_loop_step_device(h, cnt, C.ca, C.cx0, C.cu1, C.cu2, C.cx0, C.cx0p, C.cw, nu0 ? C.cnu : nullptr, 1, k,
@@ -1720,11 +1743,15 @@ static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, con
             if (fmpc_launch_walk_scatter(C, stream) != hipSuccess) return FMPC_E_HIP;
         }
         if (getenv("FMPC_DEBUG_WALK")) {
-            int nstop = 0;
-            for (int p = 0; p < batch; ++p) nstop += stop[p] < upto ? 1 : 0;
-            fprintf(stderr, "[fastmpc] walk over %d realisations up to step %d: %d stopped\n", batch, upto, nstop);
+            if (stepwise) fprintf(stderr, "[fastmpc] stepwise: %d realisations take step %d\n", (int)idx.size(), stp.empty() ? -1 : stp[0]);
+            else {
+                int nstop = 0;
+                for (int p = 0; p < batch; ++p) nstop += stop[p] < upto ? 1 : 0;
+                fprintf(stderr, "[fastmpc] walk over %d realisations up to step %d: %d stopped\n", batch, upto, nstop);
+            }
         }
         if (done) return FMPC_OK;                    // (a restarted walk begins at a step >= 1 of the stretch: x0 holds its predecessor's residual)
+        if (!stepwise && (++restarts >= max_restarts || idx.size() * 10 > (size_t)batch)) stepwise = true;
     }
 }
 

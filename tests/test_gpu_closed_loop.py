@@ -300,11 +300,16 @@ def test_recorded_stretch_in_one_call(pkg, gpu, R):
     h1.close(); h2.close()
 
 
-def test_recorded_stretch_with_steps_the_exact_path_redoes(pkg, gpu):
+@pytest.mark.parametrize("max_restarts", [None, "1", "0"])
+def test_recorded_stretch_with_steps_the_exact_path_redoes(pkg, gpu, monkeypatch, max_restarts):
     """Tight bounds (see test_first_move_form_hands_unclear_realisations_to_the_exact_path): the one-launch walk of
     fmpc_loop_run_device stops at the steps that are not clear-cut, the exact path redoes them and the walk goes on behind
-    them -- same results as one call per step, bit for bit, and the oracle loop to 1e-8."""
+    them -- same results as one call per step, bit for bit, and the oracle loop to 1e-8.  With a cap on the number of walks
+    (FMPC_WALK_MAX_RESTARTS, read per call; default 8, or a tenth of the realisations stopping in one walk) the rest of the
+    stretch is done stepwise, the realisations furthest behind first: same results again."""
     import torch
+    if max_restarts is not None:
+        monkeypatch.setenv("FMPC_WALK_MAX_RESTARTS", max_restarts)
     md = pkg.synthetic.make_model(27, 144, 10)
     # bounds at the width where the decision tips (+-0.22: every step of every realisation is handed over, +-0.25: none) and
     # realisations of different strength: single realisations stop at single steps
