@@ -282,11 +282,15 @@ def _main(real_out):
 
     class Replay:
         """One handle + output buffers for a replay batch; step() = solve + first moves (README.md:589) on torch's stream."""
-        def __init__(self, h, tx0, tx0p, tnu0, n_newton, z_init=None, want_z=True):
+        def __init__(self, h, tx0, tx0p, tnu0, n_newton, z_init=None, want_z=True, pad_z=False):
             self.h, self.a = h, (tx0, tx0p, tnu0, z_init)
             Bn = tx0.shape[0]
             self.nw = n_newton
-            self.z = torch.empty((Bn, h.nz), dtype=torch.float64, device=dev) if want_z else None
+            # pad_z: the z rows of consecutive problems a multiple of 128 bytes apart (a view of a wider array, fmpc_set_z_ld): the
+            # cold-start step then writes whole cache lines with non-temporal stores
+            self.ldz = (h.nz + 15) // 16 * 16 if (pad_z and want_z) else h.nz
+            self.zbuf = torch.empty((Bn, self.ldz), dtype=torch.float64, device=dev) if want_z else None
+            self.z = (self.zbuf[:, :h.nz] if self.ldz != h.nz else self.zbuf) if want_z else None
             self.u0 = torch.empty((Bn, h.m), dtype=torch.float64, device=dev)
             self.st = torch.zeros(Bn, dtype=torch.int32, device=dev)
             self.it = torch.zeros(Bn, dtype=torch.int32, device=dev)
@@ -308,11 +312,11 @@ def _main(real_out):
         """HEAD_SETS replay batches (different stretches of the realisation, own inputs AND outputs) solved in turn by one
         handle: consecutive steps neither re-read the same inputs nor overwrite the same 82 MB of z, so the output stream of a
         step really goes to HBM (4 x 82 MB exceed the 256 MB Infinity Cache; round 2 wrote one buffer over and over)."""
-        def __init__(self, h_, n_newton, want_z=True):
+        def __init__(self, h_, n_newton, want_z=True, pad_z=False):
             self.sets = []
             for i_ in range(HEAD_SETS):
                 d_ = data if i_ == 0 else pkg.synthetic.make_replay_batch(model, r=rank + 1000 * i_, steps=B)
-                self.sets.append(Replay(h_, to_dev(d_["x0"]), to_dev(d_["x0_pre"]), to_dev(d_["nu0"]), n_newton, want_z=want_z))
+                self.sets.append(Replay(h_, to_dev(d_["x0"]), to_dev(d_["x0_pre"]), to_dev(d_["nu0"]), n_newton, want_z=want_z, pad_z=pad_z))
             self.i = 0
 
         def step(self, u0_out=None):
@@ -322,7 +326,9 @@ def _main(real_out):
         def check(self):
             return sum(s_.check() for s_ in self.sets) / len(self.sets)
 
-    head = Ring(h, args.n_newton)
+    PAD_Z = args.n_newton == 1 and os.environ.get("FMPC_BENCH_CONTIGUOUS_Z", "0") != "1"   # (padded rows: the cold-start step with a budget of 1 only)
+    head = Ring(h, args.n_newton, pad_z=PAD_Z)
+    LDZ = head.sets[0].ldz
     # Multi-GPU: the first moves of every step are gathered (the one collective of the job, RCCL all-gather).  A collective
     # costs ~30 us of host time to submit, more than half a step: the first moves of GROUP consecutive steps share one buffer
     # and one all-gather ("fewer, larger collectives"), two buffers in turn so that a gather in flight never holds up a solve;
@@ -459,6 +465,14 @@ def _main(real_out):
         eL, sL, _ = timed(head_step, args.steps, 2)
         extra["headline_min_50ms"] = {"what": "the headline leg again over a timed region of at least %.0f ms" % MIN_LEG_MS,
                                       "value": B * sL / eL, "unit": "MPC steps/s", "steps": sL, "ms_per_step": eL / sL * 1e3}
+        if PAD_Z:
+            hc = Ring(h, args.n_newton)
+            eC, sC, kC = timed(hc.step, args.steps, args.warmup)
+            hc.check()
+            extra["headline_contiguous_z"] = {"what": "the headline leg with the z rows of consecutive problems contiguous (N_z = %d doubles apart: a row starts "
+                                                      "%d bytes off a cache line, the stores go through the L2)" % (h.nz, (h.nz * 8) % 128),
+                                              "value": B * sC / eC, "unit": "MPC steps/s", "ms_per_step": eC / sC * 1e3, "kernel_ms": kC}
+            del hc
         # ------------------------------------------------------------------ output options: first moves only (README.md:589)
         hu = Ring(h, args.n_newton, want_z=False)
         eU, sU, kU = timed(hu.step, args.steps, args.warmup)
@@ -793,6 +807,9 @@ def _main(real_out):
                                  "regions (ms): min %.3f, median %.3f, max %.3f" % (len(head_regions) or 1, steps_done,
                                                                                    1e3 * min(head_regions or [elapsed]), 1e3 * elapsed, 1e3 * max(head_regions or [elapsed])),
                        "buffers": "%d input/output sets solved in turn (%.0f MB of z in rotation: larger than the 256 MB Infinity Cache)" % (HEAD_SETS, HEAD_SETS * B * T * (n + m) * 8 / 1e6),
+                       "z_layout": ("rows of consecutive problems %d doubles apart (N_z = %d padded to a multiple of 128 bytes, fmpc_set_z_ld: whole cache lines, "
+                                    "non-temporal stores); `extra.headline_contiguous_z` is the same leg with contiguous rows" % (LDZ, T * (n + m))) if PAD_Z
+                                   else "contiguous rows (N_z = %d doubles)" % (T * (n + m)),
                        "ranks": world, "rccl_ranks": dist.get_world_size() if dist_on else 1, "device_ordinal": local_rank},
             "roofline": roof_head,
         }

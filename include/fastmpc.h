@@ -328,6 +328,18 @@ int fmpc_last_tiled_wavefronts(fmpc_handle h);
  *                        switches it off).  4 = the same with the loop inputs in the same launch (see fmpc_loop_step_device). */
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
+/*
+ * Padded output rows for batches on the device: row p of z_out starts at z_out + p * ldz (ldz >= T (n + m); 0 restores the
+ * contiguous rows).  A batch is this library's extension of the reference's one-problem call (Fast_MPC2.m:47-60), so the
+ * distance between its rows is ours to offer: with ldz a multiple of 16 (128 bytes) and z_out 128-byte aligned every
+ * 128-byte run a tile of the cold-start step writes is one cache line, and the step's 82 MB of output leave with
+ * non-temporal stores (34.6 against 39.1 us per 2000-problem step).  Honoured by the affine form of the cold-start step
+ * (fmpc_solve_device / fmpc_solve_u0_device with w == NULL, z_init == NULL, n_newton == 1, n = 27) including its exact
+ * path for the problems whose step-length decision is not clear-cut; any other solve on a handle with padded rows returns
+ * FMPC_E_UNSUPPORTED before anything is enqueued.  z_init, nu, u0, status are not affected.
+ */
+int fmpc_set_z_ld(fmpc_handle h, int ldz);
+
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)
  * run on the tiled kernel with TWO wavefronts per problem (tiled = 1, default: lowest latency of ONE call) or on the
  * one-wavefront kernel (tiled = 0: its single wavefronts share the chip better when many handles have solves in flight at the

@@ -6,6 +6,7 @@
 struct FaParams {
     int n, m, T, nb, has_xf, batch, rows, tiles, step_ld;
     int nu_rows, nu_tiles;              // nu+ as further tiles behind those of z (written when nuout != NULL)
+    int ldz;                            // doubles between the z rows of consecutive problems (>= rows; launcher: rows unless set)
     int tiles_used, wgs_per_group;    // set by the launcher (flags: knock-out experiments, FMPC_AFFINE_FLAGS)
     const double* img;                  // [tiles][FA_KS][64]: A-operand images of [Kz | zc | 0]
     const double* imgE; const double* imgEp;               // [4][FA_KS][64]: the (x0, x0_pre) blocks of E, Ep (64 rows, zero padded)

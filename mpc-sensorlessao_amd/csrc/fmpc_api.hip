@@ -61,7 +61,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
                             const double* nuws = nullptr, double* u0out = nullptr,
                             int pphase = 0, const double* rnp = nullptr, int* list = nullptr, int u0_done = 0,
-                            const int* nflag = nullptr, int* nflag_zero = nullptr);
+                            const int* nflag = nullptr, int* nflag_zero = nullptr, int zld = 0);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -139,6 +139,7 @@ struct fmpc_handle_s {
     struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // bm: padded fp64 images   // [0] fp64, [1] fp32
     double* tl_ws; size_t tl_ws_doubles; int tl_prepared;         // (bit NW: that wavefront count of the fp64 instance is prepared)
     int tl_last_nw;                       // wavefronts per problem of the last tiled launch (diagnostic)
+    int z_ld;                             // fmpc_set_z_ld: doubles between the z rows of consecutive problems (0: T (n + m))
     int small_tiled;                      // per-problem-factor solves of few problems go to the tiled kernel (FMPC_NO_SMALL_TILED=1: off)
     int small_nw;                         // ... with this many wavefronts per problem: 2 (default) or 4 (FMPC_SMALL_TILED_NW=4 /
                                           // fmpc_set_small_batch_kernel(h, 4): opt-in, see the note at FT_DISPATCH in fmpc_kernel_tiled.hip)
@@ -312,6 +313,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
     { const char* ns = getenv("FMPC_NO_SMALL_TILED"); h->small_tiled = (ns && ns[0] == '1') ? 0 : 1; }
+    h->z_ld = 0;
     { const char* nw = getenv("FMPC_SMALL_TILED_NW"); h->small_nw = (nw && nw[0] == '4') ? 4 : 2; }
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
@@ -1170,6 +1172,10 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         }
         z_out = h->zs;
     }
+    // Padded z rows (fmpc_set_z_ld): the affine form of the cold-start step and its exact path honour them, nothing else does
+    const int zld = (!z_null && h->z_ld > h->T * (h->n + h->m)) ? h->z_ld : 0;
+    if (zld && (w != nullptr || z_init != nullptr || max_iter != 1 || h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ ||
+                h->denseR || !h->use_wave || !h->sh_enabled || !h->pn_enabled)) return FMPC_E_UNSUPPORTED;
     if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
@@ -1255,19 +1261,21 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     h->fa_parity ^= 1;
                     static const bool no_nflag = [] { const char* e = getenv("FMPC_NO_NFLAG"); return e && e[0] == '1'; }();   // A/B switch
                     A.nflag = no_nflag ? nullptr : nf;
+                    A.ldz = zld;                                          // (0: contiguous rows)
                     // the two-stage form (22 % fewer matrix instructions, one task per wavefront): opt-in, FMPC_AFFINE2=1 -- the step is
                     // bound by the HBM write path, not by the matrix pipes, and the form measured 3 us slower (fmpc_kernel_affine2.hip)
                     const char* a2e = getenv("FMPC_AFFINE2_MIN_BATCH");
-                    const bool two_stage = batch >= (a2e && a2e[0] ? atoi(a2e) : 1024) && fmpc_affine2_applies(A);
+                    const bool two_stage = !zld && batch >= (a2e && a2e[0] ? atoi(a2e) : 1024) && fmpc_affine2_applies(A);
                     if ((two_stage ? fmpc_launch_affine2(A, (hipStream_t)stream) : fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream)) != hipSuccess) return FMPC_E_HIP;
                     int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
                     e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nu_out, status, iters, step,
                                          fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,
-                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need, 0, no_nflag ? nullptr : nf, nfz);
+                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need, 0, no_nflag ? nullptr : nf, nfz, zld);
                     h->last_path = FMPC_PATH_PANEL; h->inv_last = 2;
                     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
                 }
             }
+            if (zld) return FMPC_E_UNSUPPORTED;                       // (nothing of this solve is enqueued yet)
             const int split = max_iter > 1;                           // budgets > 1: decide, compact, continue (two launches)
             const int pgrid = npanels < h->num_cu ? npanels : h->num_cu;
             // (a small LDS footprint lets a d_z workgroup of another stream share the CU)
@@ -1333,6 +1341,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
             h->last_path = FMPC_PATH_PANEL;
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
         }
+        if (zld) return FMPC_E_UNSUPPORTED;
         if (mode == 0 && h->small_tiled && batch <= 1024) {
             // Every problem factors its own Schur complement and there are at most 4 problems per CU: the tiled kernel's
             // 2 (4) wavefronts per problem finish a problem in 0.5 (0.4) ms where the one-wavefront kernel needs 1.0 ms;
@@ -1790,6 +1799,14 @@ extern "C" int fmpc_debug_first_move_forms(fmpc_handle h, double* dev_forms) {
     if (!h) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(h->mu);
     h->fm_forms = dev_forms;
+    return FMPC_OK;
+}
+
+extern "C" int fmpc_set_z_ld(fmpc_handle h, int ldz) {
+    if (!h) return FMPC_E_NULL;
+    if (ldz != 0 && ldz < h->T * (h->n + h->m)) return FMPC_E_DIM;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->z_ld = ldz;
     return FMPC_OK;
 }
 

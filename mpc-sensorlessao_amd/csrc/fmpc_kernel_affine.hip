@@ -120,7 +120,11 @@ __device__ __forceinline__ bool fa_decide(const FaParams& P, double qe, double q
 // 16 t .. 16 t + 15 of E and Ep, 28 matrix instructions), from the same LDS copy of the data.
 // Measured (timing build, scripts/affine_trace.py): a tile of 56 matrix instructions takes 2.05 us of a SIMD's matrix pipe
 // (64 cycles each at 1.75 GHz), two wavefronts per SIMD keep it busy; the kernel is bound by that pipe.
-template <bool ZOUT>
+// NT: the z stores of the full rounds bypass the L2 (non-temporal).  Only with the z rows of consecutive problems a multiple of
+// 128 bytes apart from a 128-byte aligned base (fmpc_set_z_ld): every 128-byte run of a tile is then exactly one cache line
+// and nothing is left for the L2 to merge or to write back when the kernel ends (34.6 against 39.1 us per 2000-problem step,
+// same box; with rows that straddle lines the same stores take 60 us).
+template <bool ZOUT, bool NT = false>
 __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
     // the group's data in OPERAND order: entry (problem 16 ct + c, k = 4 q + g) at ((q FA_CT + ct) 4 + g) 16 + c, so that a
     // wavefront's read of an operand register is 64 consecutive doubles (row-major [problem][k] with an odd stride had 2-4
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pp = (gi * FA_CT + ct) * 16 + 4 * r + g;
-                if (ZOUT && lt < P.tiles && row < rows && pp < P.batch) P.zout[(size_t)pp * rows + row] = acc[r];
+                if (ZOUT && lt < P.tiles && row < rows && pp < P.batch) P.zout[(size_t)pp * P.ldz + row] = acc[r];
                 if (ZOUT && lt >= P.tiles && row - 16 * P.tiles < P.nu_rows && pp < P.batch) P.nuout[(size_t)pp * P.nu_rows + (row - 16 * P.tiles)] = acc[r];
                 if (P.u0out != nullptr && row < m && pp < P.batch) P.u0out[(size_t)pp * m + row] = acc[r];
             }
@@ -292,18 +296,19 @@ __global__ void __launch_bounds__(FA_THREADS, 2) fmpc_cold_affine(FaParams P) {
         if (ZOUT) {
             // (tiles beyond those of z are rows of nu+: another base and row count, the same 16 stores)
             const bool isnu = tile >= P.tiles;
-            const int rloc = isnu ? row - 16 * P.tiles : row, rcnt = isnu ? P.nu_rows : rows;
+            const int rloc = isnu ? row - 16 * P.tiles : row, rcnt = isnu ? P.nu_rows : rows, ld = isnu ? P.nu_rows : P.ldz;
             double* obase = isnu ? P.nuout : P.zout;
-            const unsigned voz = (unsigned)(g * rcnt + rloc);
+            const unsigned voz = (unsigned)(g * ld + rloc);
             const bool rok = rloc < rcnt;
 #pragma unroll
             for (int ct = 0; ct < FA_CT; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pb = (gi * FA_CT + ct) * 16 + 4 * r;       // uniform
-                    double* zb = obase + (size_t)pb * rcnt + voz;
+                    double* zb = obase + (size_t)pb * ld + voz;
                     double* dst = (rok && pb + g < P.batch) ? zb : dump;
-                    *dst = acc[ct][r];
+                    if (NT) __builtin_nontemporal_store(acc[ct][r], dst);
+                    else *dst = acc[ct][r];
                 }
         }
         // Without z (ZOUT = false) the first moves are the ONLY stores behind the request above: they must not sit under a
@@ -341,6 +346,9 @@ hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream) {
     if (!P.zout && !P.u0out) return hipErrorInvalidValue;         // (fmpc_cold_affine<false> stores the first moves unconditionally)
     const int ncol = (P.batch + 15) / 16, ngroups = (ncol + FA_CT - 1) / FA_CT;
     P.tiles_used = P.zout ? P.tiles + (P.nuout ? P.nu_tiles : 0) : (P.m + 15) / 16;
+    if (P.ldz < P.rows) P.ldz = P.rows;
+    static const bool no_nt = [] { const char* e = getenv("FMPC_AFFINE_NO_NT"); return e && e[0] == '1'; }();       // A/B switch
+    const bool nt = P.zout && !no_nt && P.ldz % 16 == 0 && ((size_t)P.zout & 127) == 0;
     // two workgroups of four wavefronts per CU are resident: that many workgroups share the groups of 64 problems (a workgroup
     // beyond the resident set would start when another ends)
     int wpg = (2 * num_cu) / ngroups;                            // workgroups per group
@@ -349,7 +357,8 @@ hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream) {
     if (wpg > wpg_max) wpg = wpg_max;
     P.wgs_per_group = wpg;
     const int grid = ngroups * wpg;
-    if (P.zout) hipLaunchKernelGGL(fmpc_cold_affine<true>, dim3(grid), dim3(FA_THREADS), 0, stream, P);
-    else hipLaunchKernelGGL(fmpc_cold_affine<false>, dim3(grid), dim3(FA_THREADS), 0, stream, P);
+    if (P.zout && nt) hipLaunchKernelGGL((fmpc_cold_affine<true, true>), dim3(grid), dim3(FA_THREADS), 0, stream, P);
+    else if (P.zout) hipLaunchKernelGGL((fmpc_cold_affine<true, false>), dim3(grid), dim3(FA_THREADS), 0, stream, P);
+    else hipLaunchKernelGGL((fmpc_cold_affine<false, false>), dim3(grid), dim3(FA_THREADS), 0, stream, P);
     return hipGetLastError();
 }

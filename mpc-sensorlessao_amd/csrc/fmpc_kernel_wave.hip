@@ -157,6 +157,7 @@ struct FwParams {
     double kbar;
     const double* x0; const double* x0p; const double* w; const double* zinit; const double* nu0;
     double* zout; double* nuout; int* status; int* iters; double* step;
+    int zld;                        // doubles between the z rows of consecutive problems (T (n + m) unless fmpc_set_z_ld: flag mode only)
     double* ws; size_t ws_stride;
     double* sh_fac; double* sh_rs; int* sh_ok;     // shared (cold-start) factor owned by the handle
     const double* cold;                             // cold-start constants (FwCold layout), k-dependent
@@ -250,7 +251,7 @@ struct FwView {
         const FwWs L = fw_ws_layout(N, m, mp, T, nb, FwCfg<N>::LDG, FwCfg<N>::FST);
         const int wave_g = blockIdx.x * FW_WAVES + (threadIdx.x >> 6);
         double* wsp = P->ws + (size_t)wave_g * P->ws_stride;
-        zp = P->zout + (size_t)p * T * s;
+        zp = P->zout + (size_t)p * P->zld;
         zs = (first && P->zinit) ? P->zinit + (size_t)p * T * s : zp;
         b = wsp + L.b; nu = wsp + L.nu; rdu = wsp + L.rdu;
         rdx = wsp + L.rdx; rp = wsp + L.rp; rhs = wsp + L.rhs; yv = wsp + L.y; dnu = wsp + L.dnu;
@@ -2105,7 +2106,7 @@ __device__ __forceinline__ bool fw_panel_decide(FwKP P, int p, bool write) {
     }
     if (clear && write && P->u0out && !P->u0_done) {     // z is what the d_z kernel wrote (an earlier launch)
         const int m = P->M.m;
-        const double* zp = P->zout + (size_t)p * T * (P->M.n + m);
+        const double* zp = P->zout + (size_t)p * P->zld;
         for (int idx = lane; idx < m; idx += 64) P->u0out[(size_t)p * m + idx] = zp[idx];
     }
     return clear;
@@ -2343,7 +2344,7 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         if (P->u0out) {                              // z of this problem was written by this wave's own lanes
             fw_mem_fence();
             const int m = P->M.m;
-            const double* zp = P->zout + (size_t)p * P->M.T * (N + m);
+            const double* zp = P->zout + (size_t)p * P->zld;
             for (int idx = lane; idx < m; idx += 64) P->u0out[(size_t)p * m + idx] = zp[idx];
         }
     }
@@ -2412,9 +2413,10 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out,
-                            int pphase, const double* rnp, int* list, int u0_done, const int* nflag, int* nflag_zero) {
+                            int pphase, const double* rnp, int* list, int u0_done, const int* nflag, int* nflag_zero, int zld) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
+    P.zld = zld > 0 ? zld : M.T * (M.n + M.m);
     P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
     P.pphase = pphase; P.rnp = rnp; P.list = list; P.u0_done = u0_done; P.nflag = nflag; P.nflag_zero = nflag_zero;
     static const int env_flags = [] { const char* e = getenv("FMPC_WAVE_FLAGS"); return e && e[0] ? atoi(e) : 0; }();

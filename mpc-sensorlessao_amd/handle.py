@@ -198,7 +198,10 @@ class FastMPCHandle:
         u_prev (batch, m): solve WITH the ramp-rate rows (after `set_ramp`).
         u0_out (batch, m): also receives the first moves z[:, :m] (fmpc_solve_u0_device: no separate unpack).
         want_z=False (with u0_out): first moves only -- z_out = NULL at the C ABI, the returned z is None (README.md:589
-        uses nothing but U(1:nu))."""
+        uses nothing but U(1:nu)).
+        z_out may be a view with padded rows, e.g. torch.empty((batch, ldz))[:, :N_z] (fmpc_set_z_ld for this call): with ldz
+        a multiple of 16 the cold-start step writes whole cache lines with non-temporal stores; only the cold-start step
+        without w, z_init and budget > 1 takes such rows (FMPC_E_UNSUPPORTED otherwise)."""
         import torch
 
         def chk(t, cols, name, dtype=torch.float64):
@@ -225,12 +228,37 @@ class FastMPCHandle:
             status = torch.empty(batch, dtype=torch.int32, device=dev)
         if iters is None:
             iters = torch.empty(batch, dtype=torch.int32, device=dev)
-        chk(z_out, self.nz, "z_out"); chk(nu_out, self.nu_len, "nu_out"); chk(u0_out, self.m, "u0_out")
+        zld = 0
+        if (z_out is not None and z_out.dim() == 2 and tuple(z_out.shape) == (batch, self.nz) and z_out.is_cuda
+                and z_out.dtype == torch.float64 and z_out.stride(1) == 1 and z_out.stride(0) > self.nz):
+            zld = int(z_out.stride(0))                             # padded rows: a view of a wider array
+        else:
+            chk(z_out, self.nz, "z_out")
+        chk(nu_out, self.nu_len, "nu_out"); chk(u0_out, self.m, "u0_out")
         chk(status, 1, "status", torch.int32); chk(iters, 1, "iters", torch.int32)
         if step is not None:
             chk(step, self._lib.fmpc_step_ld(n_newton), "step")
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        per_call = zld and zld != getattr(self, "_z_ld", 0)       # (a stride set with set_z_ld stays; otherwise for this call only)
+        if zld and u_prev is not None:
+            raise FastMPCError(_lib.FMPC_E_UNSUPPORTED, "padded z rows: not with the ramp-rate rows")
+        if per_call:
+            rcz = self._lib.fmpc_set_z_ld(self._h, zld)
+            if rcz != _lib.FMPC_OK:
+                raise FastMPCError(rcz, "fmpc_set_z_ld")
+        try:
+            rc = self._solve_device_call(batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                         u_prev, u0_out, stream)
+        finally:
+            if per_call:
+                self._lib.fmpc_set_z_ld(self._h, getattr(self, "_z_ld", 0))
+        if rc != _lib.FMPC_OK:
+            raise FastMPCError(rc, "fmpc_solve_ramp_device" if u_prev is not None else "fmpc_solve_device")
+        return z_out, status, iters
+
+    def _solve_device_call(self, batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step, u_prev, u0_out,
+                           stream):
         if u_prev is not None:
             rc = self._lib.fmpc_solve_ramp_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
                                                   p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
@@ -245,9 +273,14 @@ class FastMPCHandle:
             rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
                                              n_newton, float(k), p(z_out), p(nu_out), p(status),
                                              p(iters), p(step), stream)
+        return rc
+
+    def set_z_ld(self, ldz):
+        """fmpc_set_z_ld: rows of z_out of the device-pointer solves ldz doubles apart (0: contiguous)."""
+        rc = self._lib.fmpc_set_z_ld(self._h, int(ldz))
         if rc != _lib.FMPC_OK:
-            raise FastMPCError(rc, "fmpc_solve_ramp_device" if u_prev is not None else "fmpc_solve_device")
-        return z_out, status, iters
+            raise FastMPCError(rc, "fmpc_set_z_ld")
+        self._z_ld = int(ldz)
 
     def loop_inputs_device(self, a_k, x0_last, u1, u2, x0, x0_pre, w):
         """fmpc_loop_inputs_device: x0 = a_k + B u1, x0_pre = x0_last (None: zeros), w = -M1 B u1 - M2 B u2 (torch

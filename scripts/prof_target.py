@@ -1,5 +1,6 @@
 """One workload, a few launches, for rocprofv3 (scripts/prof_round2.sh):  python3 scripts/prof_target.py <target> [reps]
-  headline        configs[1]: 2000 problems, cold start, n_newton 1 (panel path)
+  headline        configs[1]: 2000 problems, cold start, n_newton 1: the affine form, z rows padded to 128 bytes as bench.py hands them over
+  headline_contig the same with contiguous z rows (stores through the L2)
   general_wave    2000 problems from an explicit start, n_newton 1: fmpc_newton_wave<27>
   general_budget5 the same with the Newton budget of the reference's test (5): first step by fmpc_newton_wave<27> (pphase 4), the ~9 % of
                   problems that go on by fmpc_newton_tiled over the compacted list
@@ -63,6 +64,8 @@ if target in ("general_wave", "general_budget5", "general_tiled", "tiled_f32"):
     zc = np.tile(np.concatenate([(model["u_min"] + model["u_max"]) / 2, (model["x_min"] + model["x_max"]) / 2]), T)
     zi = torch.from_numpy(np.tile(zc, (B, 1))).to(dev)
 z = torch.empty((B, h.nz), dtype=torch.float64, device=dev)
+if target == "headline":
+    z = torch.empty((B, (h.nz + 15) // 16 * 16), dtype=torch.float64, device=dev)[:, :h.nz]
 st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev)
 u0 = torch.empty((B, m), dtype=torch.float64, device=dev)
 if target in ("closed512", "closed512u0"):

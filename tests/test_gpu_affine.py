@@ -189,3 +189,63 @@ def test_two_stage_affine_form_opt_in(pkg, gpu, T, batch, xf, var_order, tight):
     assert np.array_equal(i2[:nchk], ito) and np.array_equal(s2[:nchk], sto)
     assert max(rel_err(z2[p], zo[p]) for p in range(nchk)) <= 1e-9
     h.close()
+
+
+@pytest.mark.parametrize("ldz_extra,batch,tight", [(6, 2000, None), (6, 37, None), (1, 70, None), (6, 70, 0.05), (70, 70, 0.05), (22, 200, 0.15), (1, 200, 0.1)])
+def test_padded_z_rows(pkg, gpu, ldz_extra, batch, tight):
+    """fmpc_set_z_ld: row p of z_out at z_out + p ldz.  N_z = 5130 at (27, 144, 30): ldz = 5136 / 5200 are multiples of 16 (128 bytes:
+    the kernel instance with non-temporal stores), 5131 is not (ordinary stores).  Same numbers as with contiguous rows, bit for bit
+    -- also for the problems the exact path redoes (tight bounds) --, nothing written between the rows; solves the affine form does
+    not take refuse padded rows before anything is enqueued."""
+    import torch
+    dev = torch.device("cuda:0")
+    md = pkg.synthetic.make_model(27, 144, 30)
+    if tight:
+        md["u_min"] = -tight * np.ones(144); md["u_max"] = tight * np.ones(144)
+    data = pkg.synthetic.make_replay_batch(md, r=5, steps=batch)
+    if tight:
+        data["x0"] = data["x0"] * np.linspace(0.05, 5.0, batch)[:, None]
+        data["x0_pre"] = data["x0_pre"] * np.linspace(0.05, 5.0, batch)[:, None]
+    h = handle_from_model(pkg, md)
+    t = {k: (None if v is None else torch.from_numpy(np.ascontiguousarray(v)).to(dev)) for k, v in data.items()}
+    ldz = h.nz + ldz_extra
+    zc = torch.full((batch, h.nz), float("nan"), dtype=torch.float64, device=dev)
+    big = torch.full((batch, ldz), -7.0, dtype=torch.float64, device=dev)
+    nuc = torch.empty((batch, h.nu_len), dtype=torch.float64, device=dev); nup = torch.empty_like(nuc)
+    uc = torch.empty((batch, h.m), dtype=torch.float64, device=dev); up = torch.empty_like(uc)
+    _, sc, ic = h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=zc, nu_out=nuc, u0_out=uc)
+    handed = h.last_dispatch()[1]
+    assert h.last_dual_form() == 2
+    if tight and tight <= 0.05:
+        assert 0 < handed, "no problem was handed to the exact path: the case does not test it"
+    _, sp, ip = h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=big[:, :h.nz], nu_out=nup, u0_out=up)
+    torch.cuda.synchronize()
+    assert h.last_dual_form() == 2 and h.last_dispatch()[1] == handed
+    assert torch.equal(big[:, :h.nz], zc) and torch.equal(nup, nuc) and torch.equal(up, uc) and torch.equal(sp, sc) and torch.equal(ip, ic)
+    assert bool((big[:, h.nz:] == -7.0).all()), "something was written between the rows"
+    # without nu, and z alone
+    big.fill_(-7.0)
+    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=big[:, :h.nz])
+    torch.cuda.synchronize()
+    assert torch.equal(big[:, :h.nz], zc) and bool((big[:, h.nz:] == -7.0).all())
+    # the handle is back to contiguous rows after a call with a view
+    z2 = torch.empty_like(zc)
+    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=z2)
+    torch.cuda.synchronize()
+    assert torch.equal(z2, zc)
+    # a stride that stays (set_z_ld), and the solves that do not take padded rows
+    h.set_z_ld(ldz)
+    big.fill_(-7.0)
+    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=big[:, :h.nz])
+    torch.cuda.synchronize()
+    assert torch.equal(big[:, :h.nz], zc)
+    w = torch.zeros((batch, h.T * h.n), dtype=torch.float64, device=dev)
+    for kw in (dict(w=w), dict(n_newton=5), dict(z_init=zc.clone())):
+        args = dict(w=None, z_init=None, n_newton=1); args.update(kw)
+        with pytest.raises(pkg.FastMPCError) as ei:
+            h.solve_device(t["x0"], t["x0_pre"], args["w"], args["z_init"], t["nu0"], args["n_newton"], 1e-2, z_out=big[:, :h.nz])
+        assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    h.set_z_ld(0)
+    with pytest.raises(pkg.FastMPCError):
+        h.set_z_ld(h.nz - 1)
+    h.close()
