@@ -1146,6 +1146,9 @@ static int fmpc_ensure_cold(fmpc_handle h, double k, size_t stride, hipStream_t 
     return FMPC_OK;
 }
 
+// set by the host-pointer entry around its device solve: its staging block has contiguous rows whatever fmpc_set_z_ld says
+static thread_local int fmpc_tl_contiguous_z = 0;
+
 // fmpc_solve_device (u0_out == NULL) / fmpc_solve_u0_device: the first moves are written by the solve's last kernel
 // where that kernel visits every problem anyway (the wave kernel), by the unpack kernel otherwise
 static int fmpc_solve_device_inner(fmpc_handle h, int batch,
@@ -1173,7 +1176,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         z_out = h->zs;
     }
     // Padded z rows (fmpc_set_z_ld): the affine form of the cold-start step and its exact path honour them, nothing else does
-    const int zld = (!z_null && h->z_ld > h->T * (h->n + h->m)) ? h->z_ld : 0;
+    const int zld = (!z_null && !fmpc_tl_contiguous_z && h->z_ld > h->T * (h->n + h->m)) ? h->z_ld : 0;
     if (zld && (w != nullptr || z_init != nullptr || max_iter != 1 || h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ ||
                 h->denseR || !h->use_wave || !h->sh_enabled || !h->pn_enabled)) return FMPC_E_UNSUPPORTED;
     if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
@@ -1876,6 +1879,7 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                                       void* stream) {
     if (!h || !x0 || !z_out || !u_prev) return FMPC_E_NULL;
     if (!h->ramp_du) return FMPC_E_UNSUPPORTED;                    // fmpc_set_ramp first
+    if (!fmpc_tl_contiguous_z && h->z_ld > h->T * (h->n + h->m)) return FMPC_E_UNSUPPORTED;   // padded z rows: the cold-start affine step only
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
@@ -1972,10 +1976,12 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     int* d_it = (int*)(base + o_it);
     double* d_nu = nu_out ? (double*)(base + o_nu) : nullptr;
     double* d_step = step ? (double*)(base + o_step) : nullptr;
+    fmpc_tl_contiguous_z = 1;                                   // (the staging block's rows are contiguous: fmpc_set_z_ld is for device batches)
     int rc = u_prev ? fmpc_solve_ramp_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(u_prev, o_up), dptr(z_init, o_zi),
                                              dptr(nu0, o_nu0), n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr)
                     : fmpc_solve_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
                                         n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr);
+    fmpc_tl_contiguous_z = 0;
     if (rc != FMPC_OK) { (void)hipDeviceSynchronize(); return rc; }
     std::vector<int> stv;
     const int* st;

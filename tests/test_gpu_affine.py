@@ -245,6 +245,9 @@ def test_padded_z_rows(pkg, gpu, ldz_extra, batch, tight):
         with pytest.raises(pkg.FastMPCError) as ei:
             h.solve_device(t["x0"], t["x0_pre"], args["w"], args["z_init"], t["nu0"], args["n_newton"], 1e-2, z_out=big[:, :h.nz])
         assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    # the host-pointer entry stages contiguous rows whatever the handle's stride says
+    zh = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=1, k=1e-2)
+    assert np.array_equal(zh, zc.cpu().numpy())
     h.set_z_ld(0)
     with pytest.raises(pkg.FastMPCError):
         h.set_z_ld(h.nz - 1)
