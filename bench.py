@@ -228,12 +228,13 @@ def _main(real_out):
             torch.cuda.synchronize(dev)
 
     def timed(step_fn, steps, warmup, min_ms=MIN_LEG_MS, after=None, exact=False, regions=1, all_regions=None, dev_regions=None,
-              rank_times=None):
+              rank_times=None, region_fn=None):
         """W warm-up steps, then `steps` timed steps between barriers -- exactly `steps` for the headline (exact=True),
         otherwise as many more as it takes for the timed region to last min_ms.  regions > 1 (headline): that many timed
         regions of exactly `steps` steps back to back, each bracketed by barrier + synchronize; the MEDIAN region is
         returned (a single 20-step region lasts 1 ms and spread by 15 % from run to run in round 2), all of them in
-        `all_regions`.
+        `all_regions`.  region_fn (headline, one GPU): the `steps` steps of a region as ONE host call -- a HIP graph of exactly
+        that many solves recorded beforehand (RecordedSolves) -- instead of `steps` calls of step_fn.
         Returns (elapsed_s, steps_done, kernel_ms): kernel_ms = median device time of ONE step run alone, from HIP
         events on the stream the step is enqueued on, measured outside the timed region."""
         for _ in range(warmup):
@@ -256,8 +257,11 @@ def _main(real_out):
             ra, rb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             ra.record()                                                 # HIP events on the stream the steps are enqueued on
-            for _ in range(steps):
-                step_fn()
+            if region_fn is not None:
+                region_fn()                                             # (exactly `steps` steps, recorded once: one host call)
+            else:
+                for _ in range(steps):
+                    step_fn()
             rb.record()
             if after:
                 after()
@@ -370,10 +374,21 @@ def _main(real_out):
                 gather_state["pending"][s_].wait(); gather_state["pending"][s_] = None
 
     head_regions, head_dev_regions, head_rank_times = [], [], []
+    # One GPU: the K steps of a timed region are recorded once into a HIP graph (the inputs of a replay batch are known in advance)
+    # and a region is one replay -- inside a graph the launches follow each other more closely than the host can submit them.
+    # With ranks the first moves are gathered every GROUP steps by the host (RCCL): submitted step by step as before.
+    GRAPH = depth == 1 and not dist_on and os.environ.get("FMPC_BENCH_EAGER", "0") != "1"
+    head_rec = None
+    if GRAPH:
+        try:
+            head_rec = pkg.RecordedSolves(lambda: [head.step() for _ in range(args.steps)])
+        except Exception as ex_:                                           # (a runtime without stream capture: eager submission)
+            print("[bench] HIP graph capture of the headline failed (%s): eager submission" % repr(ex_)[:200], file=sys.stderr)
+            head_rec, GRAPH = None, False
     if depth == 1:
         elapsed, steps_done, kern_ms = timed(head_step, args.steps, args.warmup, after=head_after, exact=True,
                                              regions=HEAD_REGIONS, all_regions=head_regions, dev_regions=head_dev_regions,
-                                             rank_times=head_rank_times)
+                                             rank_times=head_rank_times, region_fn=head_rec.replay if head_rec is not None else None)
     else:
         lanes = pkg.SolveLanes(make_handle, B, depth=depth, device=dev)
         lane_step = lambda: lanes.submit(x0, x0p, None, None, nu0, args.n_newton, K_BAR, after_current=False)
@@ -465,6 +480,10 @@ def _main(real_out):
         eL, sL, _ = timed(head_step, args.steps, 2)
         extra["headline_min_50ms"] = {"what": "the headline leg again over a timed region of at least %.0f ms" % MIN_LEG_MS,
                                       "value": B * sL / eL, "unit": "MPC steps/s", "steps": sL, "ms_per_step": eL / sL * 1e3}
+        if GRAPH:
+            eE, sE, _ = timed(head_step, args.steps, args.warmup, exact=True, regions=HEAD_REGIONS)
+            extra["headline_eager_submission"] = {"what": "the headline leg with the %d steps of a region submitted one host call at a time (no HIP graph)" % sE,
+                                                  "value": B * sE / eE, "unit": "MPC steps/s", "ms_per_step": eE / sE * 1e3}
         if PAD_Z:
             hc = Ring(h, args.n_newton)
             eC, sC, kC = timed(hc.step, args.steps, args.warmup)
@@ -807,6 +826,9 @@ def _main(real_out):
                                  "regions (ms): min %.3f, median %.3f, max %.3f" % (len(head_regions) or 1, steps_done,
                                                                                    1e3 * min(head_regions or [elapsed]), 1e3 * elapsed, 1e3 * max(head_regions or [elapsed])),
                        "buffers": "%d input/output sets solved in turn (%.0f MB of z in rotation: larger than the 256 MB Infinity Cache)" % (HEAD_SETS, HEAD_SETS * B * T * (n + m) * 8 / 1e6),
+                       "submission": ("the %d steps of a timed region are recorded once into a HIP graph (RecordedSolves: torch.cuda.CUDAGraph around the "
+                                      "C-ABI calls, capture-safe once the workspaces exist) and a region is one replay; `extra.headline_eager_submission` is "
+                                      "the same leg with one host call per step" % steps_done) if GRAPH else "one host call per step",
                        "z_layout": ("rows of consecutive problems %d doubles apart (N_z = %d padded to a multiple of 128 bytes, fmpc_set_z_ld: whole cache lines, "
                                     "non-temporal stores); `extra.headline_contiguous_z` is the same leg with contiguous rows" % (LDZ, T * (n + m))) if PAD_Z
                                    else "contiguous rows (N_z = %d doubles)" % (T * (n + m)),

@@ -329,6 +329,18 @@ int fmpc_last_tiled_wavefronts(fmpc_handle h);
 int fmpc_set_dense_form(fmpc_handle h, int enabled, int max_batch_with_w);
 
 /*
+ * Recording solves into a HIP graph.  The device-pointer solves do not allocate, synchronise or read back once the handle's
+ * workspaces exist for the batch size and barrier weight of a call (one eager call first), and they leave the handle's
+ * cross-stream event alone while their stream is being captured: a stretch of solves on known inputs -- the reference's
+ * replay of a realisation, README.md:548-556 -- can be captured once (hipStreamBeginCapture / torch.cuda.graph around the
+ * calls; Python: RecordedSolves) and replayed with one host call; inside a graph the launches follow each other more
+ * closely than the host can submit them (31.2 against 33.9 us per 2000-problem step).  A graph holds the addresses of the
+ * handle's workspaces: fmpc_alloc_generation() changes whenever any handle of the process allocates or releases device
+ * memory -- compare it with its value at the recording before every replay, and record again when it has changed.
+ */
+unsigned long long fmpc_alloc_generation(void);
+
+/*
  * Padded output rows for batches on the device: row p of z_out starts at z_out + p * ldz (ldz >= T (n + m); 0 restores the
  * contiguous rows).  A batch is this library's extension of the reference's one-problem call (Fast_MPC2.m:47-60), so the
  * distance between its rows is ours to offer: with ldz a multiple of 16 (128 bytes) and z_out 128-byte aligned every

@@ -11,10 +11,11 @@ from . import synthetic
 from .sharded import ShardedFastMPC, shard_range
 from .closed_loop import ClosedLoop, AOLoop
 from .lanes import SolveLanes
+from .recorded import RecordedSolves
 from .var_identify import identify_var2_device
 from .estimator import PhaseDiversityEstimator
 from . import _lib
 
 __all__ = ["FastMPCHandle", "Fast_MPC2", "Fast_MPC2_VAR1", "deinterleave", "FastMPCError",
-           "ShardedFastMPC", "shard_range", "ClosedLoop", "AOLoop", "SolveLanes", "PhaseDiversityEstimator", "synthetic", "load", "LIB_PATH",
+           "ShardedFastMPC", "shard_range", "ClosedLoop", "AOLoop", "SolveLanes", "RecordedSolves", "PhaseDiversityEstimator", "synthetic", "load", "LIB_PATH",
            "identify_var2_device"]

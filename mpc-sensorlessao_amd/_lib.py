@@ -57,6 +57,7 @@ SIGNATURES = {
     "fmpc_last_tiled_wavefronts": (C.c_int, [_vp]),
     "fmpc_set_small_batch_kernel": (C.c_int, [_vp, C.c_int]),
     "fmpc_set_z_ld": (C.c_int, [_vp, C.c_int]),
+    "fmpc_alloc_generation": (C.c_ulonglong, []),
     "fmpc_loop_inputs_device": (C.c_int, [_vp, C.c_int] + [_vp] * 7 + [_vp]),
     "fmpc_loop_step_device": (C.c_int, [_vp, C.c_int] + [_vp] * 8 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_ao_step_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),

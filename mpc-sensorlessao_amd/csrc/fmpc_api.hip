@@ -18,6 +18,17 @@
 #include "fmpc_loopu0.h"
 #include "fmpc_tiled.h"
 #define FMPC_PRODUCT_MIN_BATCH_DEFAULT 65   // closed-loop steps with first moves only: the product form from this many realisations on
+#include <atomic>
+
+// Every device allocation and release of this file bumps one process-wide counter (fmpc_alloc_generation): a HIP graph
+// recorded over solve calls holds the addresses of the handle's workspaces, and a replay after any of them has been
+// reallocated would use freed memory -- whoever replays compares the counter first (RecordedSolves in handle.py).
+static std::atomic<unsigned long long> fmpc_alloc_gen{0};
+static inline hipError_t fmpc_counted_malloc(void** p, size_t bytes) { fmpc_alloc_gen.fetch_add(1); return hipMalloc(p, bytes); }
+static inline hipError_t fmpc_counted_free(void* p) { fmpc_alloc_gen.fetch_add(1); return hipFree(p); }
+#define hipMalloc(p, bytes) fmpc_counted_malloc((void**)(p), (bytes))
+#define hipFree(p) fmpc_counted_free((void*)(p))
+extern "C" unsigned long long fmpc_alloc_generation(void) { return fmpc_alloc_gen.load(); }
 
 
 // kernels / launchers (fmpc_kernel_generic.hip)
@@ -857,12 +868,21 @@ static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
 
 // Orders the solves of a handle that arrive on different streams (they share the handle's workspaces): called with
 // h->mu held, before the first launch of a solve and after its last one.
+// (Under stream capture -- the solves of a recorded stretch going into a HIP graph, RecordedSolves in handle.py -- the handle's
+// event is left alone: an event recorded inside a capture cannot be waited for by a stream outside it, and the order of a
+// replay against other work is the order of the stream it is replayed on.)
+static bool fmpc_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
 static int fmpc_guard_begin(fmpc_handle h, hipStream_t stream) {
+    if (fmpc_capturing(stream)) return FMPC_OK;
     if (!h->ev && hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) return FMPC_E_HIP;
     if (h->ev_valid && stream != h->last_stream && hipStreamWaitEvent(stream, h->ev, 0) != hipSuccess) return FMPC_E_HIP;
     return FMPC_OK;
 }
 static void fmpc_guard_end(fmpc_handle h, hipStream_t stream) {
+    if (fmpc_capturing(stream)) return;
     if (h->ev && hipEventRecord(h->ev, stream) == hipSuccess) { h->ev_valid = 1; h->last_stream = stream; }
 }
 

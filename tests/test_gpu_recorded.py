@@ -1,0 +1,63 @@
+"""RecordedSolves: device solves captured once into a HIP graph and replayed (include/fastmpc.h, "Recording solves into a HIP
+graph").  Same numbers as the eager calls, bit for bit; eager calls on other streams still work afterwards (the handle's
+cross-stream event is not touched under capture); a replay is refused once device buffers have been reallocated."""
+import numpy as np
+import pytest
+
+from tests.util import handle_from_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("batch,padded", [(2000, True), (70, False)])
+def test_recorded_solves_replay_equals_eager(pkg, gpu, batch, padded):
+    import torch
+    dev = torch.device("cuda:0")
+    md = pkg.synthetic.make_model(27, 144, 30)
+    h = handle_from_model(pkg, md)
+    nsets, reps = 3, 2
+    ldz = (h.nz + 15) // 16 * 16 if padded else h.nz
+    sets = []
+    for i in range(nsets):
+        d = pkg.synthetic.make_replay_batch(md, r=10 + i, steps=batch)
+        big = torch.full((batch, ldz), -3.0, dtype=torch.float64, device=dev)
+        sets.append(dict(x0=torch.from_numpy(d["x0"]).to(dev), x0p=torch.from_numpy(d["x0_pre"]).to(dev), nu0=torch.from_numpy(d["nu0"]).to(dev),
+                         big=big, z=big[:, :h.nz] if padded else big, u0=torch.empty((batch, h.m), dtype=torch.float64, device=dev),
+                         st=torch.zeros(batch, dtype=torch.int32, device=dev), it=torch.zeros(batch, dtype=torch.int32, device=dev)))
+
+    def one(s):
+        h.solve_device(s["x0"], s["x0p"], None, None, s["nu0"], 1, 1e-2, z_out=s["z"], status=s["st"], iters=s["it"], u0_out=s["u0"])
+
+    def stretch():
+        for _ in range(reps):
+            for s in sets:
+                one(s)
+
+    stretch()
+    torch.cuda.synchronize()
+    ref = [(s["big"].clone(), s["u0"].clone(), s["st"].clone(), s["it"].clone()) for s in sets]
+    rec = pkg.RecordedSolves(stretch)
+    assert rec.valid()
+    for _ in range(2):
+        for s in sets:
+            s["big"].fill_(-3.0); s["u0"].fill_(0.0); s["st"].fill_(-9); s["it"].fill_(-9)
+        rec.replay()
+        torch.cuda.synchronize()
+        for s, (zb, u0, st, it) in zip(sets, ref):
+            assert torch.equal(s["big"], zb) and torch.equal(s["u0"], u0) and torch.equal(s["st"], st) and torch.equal(s["it"], it)
+    # eager calls afterwards, on another stream too
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        one(sets[0])
+    one(sets[1])
+    torch.cuda.synchronize()
+    assert torch.equal(sets[0]["big"], ref[0][0]) and torch.equal(sets[1]["big"], ref[1][0])
+    # a larger batch makes the handle allocate: the recording is stale from then on
+    d2 = pkg.synthetic.make_replay_batch(md, r=99, steps=2 * batch + 100)
+    h.solve_device(torch.from_numpy(d2["x0"]).to(dev), torch.from_numpy(d2["x0_pre"]).to(dev), None, None, torch.from_numpy(d2["nu0"]).to(dev), 1, 1e-2)
+    torch.cuda.synchronize()
+    assert not rec.valid()
+    with pytest.raises(pkg.FastMPCError) as ei:
+        rec.replay()
+    assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    h.close()
