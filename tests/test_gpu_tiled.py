@@ -166,6 +166,18 @@ def test_tiled_fp32_tight_bounds_n65(pkg, gpu):
     _compare32(pkg, model, data, 5, 1e-2)
 
 
+@pytest.mark.parametrize("n,m,T,var,xf", [(33, 20, 6, 2, False), (40, 150, 5, 2, True), (47, 60, 4, 1, False),      # 3 blocks of 16 (NB = 3)
+                                          (48, 30, 5, 2, False), (63, 64, 4, 2, True),                                 # NB = 4, last block 0 / 15 rows
+                                          (64, 33, 4, 2, False), (66, 70, 4, 1, True), (79, 150, 3, 2, False)])       # NB = 5: 0, 2, 15 live rows
+def test_tiled_fp32_random_models_over_the_block_sizes(pkg, gpu, n, m, T, var, xf):
+    """The fp32 instances besides the AO sizes (block structure at run time: n = 64 has NO live row in its fifth block, 79 fills
+    it), on random stable models (tests/test_property_random.py: the generator of test_fast_mpc.m:8-37), two Newton steps."""
+    from tests.test_property_random import random_problem
+    model, data = random_problem(7000 + n, n, m, T, var, False, False, xf and m >= n, False, batch=4)
+    err = _compare32(pkg, model, data, 2, 1e-1)
+    print(f"fp32 factor, random model n={n} m={m} T={T}: max rel err on z {err:.2e}")
+
+
 def test_precision_switch_errors(pkg, gpu):
     model = pkg.synthetic.make_model(65, 144, 4)
     h = handle_from_model(pkg, model)
