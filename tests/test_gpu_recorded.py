@@ -61,3 +61,52 @@ def test_recorded_solves_replay_equals_eager(pkg, gpu, batch, padded):
         rec.replay()
     assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
     h.close()
+
+
+def test_recorded_solves_with_flagged_problems_odd_stretch(pkg, gpu):
+    """Tight bounds: some problems of every step are redone by the exact path (flag mode).  The two counters of flagged problems
+    take turns call by call on the host; a recorded stretch of an ODD number of steps, replayed back to back and mixed with eager
+    calls, meets a counter that the step before it has not cleared -- the exact-path launch then scans the flags (a stale count can
+    only be too high): same results as the eager calls every time."""
+    import torch
+    dev = torch.device("cuda:0")
+    md = pkg.synthetic.make_model(27, 144, 30)
+    md["u_min"] = -0.1 * np.ones(144); md["u_max"] = 0.1 * np.ones(144)
+    h = handle_from_model(pkg, md)
+    batch = 90
+    sets = []
+    for i in range(3):
+        d = pkg.synthetic.make_replay_batch(md, r=20 + i, steps=batch)
+        sc = np.linspace(0.05, 5.0, batch)[:, None] if i != 1 else np.full((batch, 1), 0.01)     # (set 1: nothing flagged)
+        sets.append(dict(x0=torch.from_numpy(d["x0"] * sc).to(dev), x0p=torch.from_numpy(d["x0_pre"] * sc).to(dev), nu0=torch.from_numpy(d["nu0"]).to(dev),
+                         z=torch.empty((batch, h.nz), dtype=torch.float64, device=dev), st=torch.zeros(batch, dtype=torch.int32, device=dev),
+                         it=torch.zeros(batch, dtype=torch.int32, device=dev), stp=torch.zeros((batch, 1), dtype=torch.float64, device=dev)))
+
+    def one(s):
+        h.solve_device(s["x0"], s["x0p"], None, None, s["nu0"], 1, 1e-2, z_out=s["z"], status=s["st"], iters=s["it"], step=s["stp"])
+
+    handed = []
+    for s in sets:
+        one(s); torch.cuda.synchronize(); handed.append(h.last_dispatch()[1])
+    assert handed[0] > 0 and handed[2] > 0 and handed[1] == 0, handed
+    ref = [(s["z"].clone(), s["st"].clone(), s["it"].clone(), s["stp"].clone()) for s in sets]
+    rec = pkg.RecordedSolves(lambda: [one(s) for s in sets])                     # three steps: odd
+
+    def check():
+        torch.cuda.synchronize()
+        for s, (z, st, it, stp) in zip(sets, ref):
+            assert torch.equal(s["z"], z) and torch.equal(s["st"], st) and torch.equal(s["it"], it) and torch.equal(s["stp"], stp)
+
+    def wipe():
+        for s in sets:
+            s["z"].fill_(0.0); s["st"].fill_(-9); s["it"].fill_(-9); s["stp"].fill_(0.0)
+
+    for pattern in ("rr", "rer", "err", "reer"):
+        for c_ in pattern:
+            wipe()
+            if c_ == "r":
+                rec.replay()
+            else:
+                one(sets[0]); one(sets[1]); one(sets[2])
+            check()
+    h.close()
