@@ -13,15 +13,26 @@ class RecordedSolves:
     any handle of the process has allocated or released device memory since the recording (the graph holds addresses)."""
 
     def __init__(self, record_fn):
+        import gc
         import torch
         self._lib = _lib.load()
         record_fn()
         torch.cuda.synchronize()
         self._stream = torch.cuda.Stream()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(self._stream):
-            with torch.cuda.graph(self.graph, stream=self._stream):
-                record_fn()
+        # No garbage collection while the stream is capturing: a collection that happens to run inside the capture may destroy
+        # objects whose release is not allowed then -- another graph with its memory pool (hipFree), a stream -- and the
+        # runtime aborts the process (seen in the test suite: the previous test's recording was collected here).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(self._stream):
+                with torch.cuda.graph(self.graph, stream=self._stream):
+                    record_fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
         torch.cuda.synchronize()
         self._gen = int(self._lib.fmpc_alloc_generation())
 
