@@ -148,6 +148,29 @@ int fmpc_solve_u0_device(fmpc_handle h, int batch,
                          double* u0_out, void* stream);
 
 /*
+ * fmpc_solve_u0_device with the distance between the z rows of consecutive problems as an ARGUMENT of the call: ldz doubles
+ * (0 = contiguous rows, else >= N_z; see fmpc_set_z_ld for what padded rows buy and which solves take them).  The handle's
+ * persistent fmpc_set_z_ld value is neither read nor changed, so concurrent solves on one handle may use different layouts.
+ * u0_out may be NULL here (then it is fmpc_solve_device with an explicit ldz).
+ */
+int fmpc_solve_u0_device_ld(fmpc_handle h, int batch,
+                            const double* x0, const double* x0_pre, const double* w,
+                            const double* z_init, const double* nu0, int n_newton, double k,
+                            double* z_out, double* nu_out, int* status, int* iters, double* step,
+                            double* u0_out, int ldz, void* stream);
+
+/*
+ * fmpc_solve (HOST pointers) returning the first moves: u0_out (m x batch) receives u0 = z(1:m) of every problem -- all the
+ * reference's loop applies (u_prev = U(1:nu), README.md:589; de-interleave README.md:558-570).  z_out may be NULL: then
+ * m x batch doubles come back over PCIe instead of N_z x batch (2.3 MB instead of 82 MB per 2000 problems at (27,144,30))
+ * and the cold-start step writes nothing of z on the device either.  status, iters nullable.  Same return value as fmpc_solve.
+ */
+int fmpc_solve_u0(fmpc_handle h, int batch,
+                  const double* x0, const double* x0_pre, const double* w,
+                  const double* z_init, const double* nu0, int n_newton, double k,
+                  double* z_out, double* u0_out, int* status, int* iters);
+
+/*
  * Caller-side unpack of x_opt (README.md:558-570) and u_prev = U(1:nu) (README.md:589):
  * z (N_z x batch) -> U (T*m x batch), X (T*n x batch), u0 (m x batch); any output may be NULL.
  */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "fmpc_ao_step_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_loop_run_device": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.c_int, C.c_int, C.c_double] + [_vp] * 7 + [_vp]),
     "fmpc_solve_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
+    "fmpc_solve_u0_device_ld": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 6 + [C.c_int, _vp]),
+    "fmpc_solve_u0": (C.c_int, [_vp, C.c_int] + [_vp] * 5 + [C.c_int, C.c_double] + [_vp] * 4),
     "fmpc_set_ramp": (C.c_int, [_vp, _vp, _vp]),
     "fmpc_set_precision": (C.c_int, [_vp, C.c_int]),
     "fmpc_var_identify_device": (C.c_int, [C.c_int] * 4 + [_vp] * 5),

@@ -1168,6 +1168,11 @@ static int fmpc_ensure_cold(fmpc_handle h, double k, size_t stride, hipStream_t 
 
 // set by the host-pointer entry around its device solve: its staging block has contiguous rows whatever fmpc_set_z_ld says
 static thread_local int fmpc_tl_contiguous_z = 0;
+// set by fmpc_solve_u0_device_ld around its solve: the row distance of THIS call's z_out (>= 0), whatever the handle's persistent
+// value says (-1: none given, the handle's fmpc_set_z_ld value applies).  Thread-local, so a concurrent solve on the same handle
+// from another thread never inherits it (the set / solve / restore of fmpc_set_z_ld was not atomic).
+static thread_local int fmpc_tl_zld_explicit = -1;
+static inline int fmpc_effective_zld(fmpc_handle h) { return fmpc_tl_zld_explicit >= 0 ? fmpc_tl_zld_explicit : h->z_ld; }
 
 // fmpc_solve_device (u0_out == NULL) / fmpc_solve_u0_device: the first moves are written by the solve's last kernel
 // where that kernel visits every problem anyway (the wave kernel), by the unpack kernel otherwise
@@ -1196,7 +1201,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         z_out = h->zs;
     }
     // Padded z rows (fmpc_set_z_ld): the affine form of the cold-start step and its exact path honour them, nothing else does
-    const int zld = (!z_null && !fmpc_tl_contiguous_z && h->z_ld > h->T * (h->n + h->m)) ? h->z_ld : 0;
+    const int zld = (!z_null && !fmpc_tl_contiguous_z && fmpc_effective_zld(h) > h->T * (h->n + h->m)) ? fmpc_effective_zld(h) : 0;
     if (zld && (w != nullptr || z_init != nullptr || max_iter != 1 || h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ ||
                 h->denseR || !h->use_wave || !h->sh_enabled || !h->pn_enabled)) return FMPC_E_UNSUPPORTED;
     if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
@@ -1468,6 +1473,22 @@ extern "C" int fmpc_solve_u0_device(fmpc_handle h, int batch,
     if (!u0_out) return FMPC_E_NULL;
     return fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                   u0_out, stream);
+}
+
+// fmpc_solve_u0_device with the row distance of z_out as an ARGUMENT of the call (0: contiguous rows) instead of handle state
+extern "C" int fmpc_solve_u0_device_ld(fmpc_handle h, int batch,
+                                       const double* x0, const double* x0_pre, const double* w,
+                                       const double* z_init, const double* nu0,
+                                       int n_newton, double k,
+                                       double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                       double* u0_out, int ldz, void* stream) {
+    if (!h) return FMPC_E_NULL;
+    if (ldz < 0 || (ldz != 0 && ldz < h->T * (h->n + h->m))) return FMPC_E_DIM;
+    fmpc_tl_zld_explicit = ldz;
+    const int rc = fmpc_solve_device_impl(h, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                          u0_out, stream);
+    fmpc_tl_zld_explicit = -1;
+    return rc;
 }
 
 // Closed-loop step of a few realisations in the first-move form (fmpc_kernel_first.hip): ONE launch computes the loop inputs,
@@ -1899,7 +1920,7 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                                       void* stream) {
     if (!h || !x0 || !z_out || !u_prev) return FMPC_E_NULL;
     if (!h->ramp_du) return FMPC_E_UNSUPPORTED;                    // fmpc_set_ramp first
-    if (!fmpc_tl_contiguous_z && h->z_ld > h->T * (h->n + h->m)) return FMPC_E_UNSUPPORTED;   // padded z rows: the cold-start affine step only
+    if (!fmpc_tl_contiguous_z && fmpc_effective_zld(h) > h->T * (h->n + h->m)) return FMPC_E_UNSUPPORTED;   // padded z rows: the cold-start affine step only
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
@@ -1943,8 +1964,9 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
                            const double* x0, const double* x0_pre, const double* w, const double* u_prev,
                            const double* z_init, const double* nu0,
                            int n_newton, double k,
-                           double* z_out, double* nu_out, int* status, int* iters, double* step) {
-    if (!h || !x0 || !z_out) return FMPC_E_NULL;
+                           double* z_out, double* nu_out, int* status, int* iters, double* step, double* u0_out = nullptr) {
+    if (!h || !x0 || (!z_out && !u0_out)) return FMPC_E_NULL;
+    if (u0_out && u_prev) return FMPC_E_UNSUPPORTED;                // (first-move output: not with the ramp-rate rows)
     if (batch < 0) return FMPC_E_DIM;
     if (batch == 0) return FMPC_OK;
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
@@ -1957,7 +1979,9 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     const size_t o_zi = take(z_init != nullptr, Nz * B * 8), o_nu0 = take(nu0 != nullptr, nbn * B * 8);
     const size_t o_up = take(u_prev != nullptr, (size_t)h->m * B * 8);
     const size_t in_bytes = off;
-    const size_t o_z = take(true, Nz * B * 8), o_nu = take(nu_out != nullptr, nbn * B * 8);
+    const size_t o_out = off;                                       // outputs from here on: one copy down
+    const size_t o_z = take(z_out != nullptr, Nz * B * 8), o_nu = take(nu_out != nullptr, nbn * B * 8);
+    const size_t o_u0 = take(u0_out != nullptr, (size_t)h->m * B * 8);
     const size_t o_st = take(true, B * 4), o_it = take(true, B * 4), o_step = take(step != nullptr, sld * B * 8);
     const bool pinned = off <= FMPC_PIN_LIMIT;
     char* base;
@@ -1997,18 +2021,22 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     double* d_nu = nu_out ? (double*)(base + o_nu) : nullptr;
     double* d_step = step ? (double*)(base + o_step) : nullptr;
     fmpc_tl_contiguous_z = 1;                                   // (the staging block's rows are contiguous: fmpc_set_z_ld is for device batches)
+    double* d_z = z_out ? (double*)(base + o_z) : nullptr;
     int rc = u_prev ? fmpc_solve_ramp_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(u_prev, o_up), dptr(z_init, o_zi),
-                                             dptr(nu0, o_nu0), n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr)
+                                             dptr(nu0, o_nu0), n_newton, k, d_z, d_nu, d_st, d_it, d_step, nullptr)
+            : u0_out ? fmpc_solve_u0_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
+                                            n_newton, k, d_z, d_nu, d_st, d_it, d_step, (double*)(base + o_u0), nullptr)
                     : fmpc_solve_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
-                                        n_newton, k, (double*)(base + o_z), d_nu, d_st, d_it, d_step, nullptr);
+                                        n_newton, k, d_z, d_nu, d_st, d_it, d_step, nullptr);
     fmpc_tl_contiguous_z = 0;
     if (rc != FMPC_OK) { (void)hipDeviceSynchronize(); return rc; }
     std::vector<int> stv;
     const int* st;
     if (pin) {
-        if (hipMemcpyAsync(pin + o_z, base + o_z, off - o_z, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return FMPC_E_HIP;
+        if (hipMemcpyAsync(pin + o_out, base + o_out, off - o_out, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return FMPC_E_HIP;
         if (hipStreamSynchronize(nullptr) != hipSuccess) return FMPC_E_HIP;
-        memcpy(z_out, pin + o_z, Nz * B * 8);
+        if (z_out) memcpy(z_out, pin + o_z, Nz * B * 8);
+        if (u0_out) memcpy(u0_out, pin + o_u0, (size_t)h->m * B * 8);
         if (nu_out) memcpy(nu_out, pin + o_nu, nbn * B * 8);
         if (iters) memcpy(iters, pin + o_it, B * 4);
         if (step) memcpy(step, pin + o_step, sld * B * 8);
@@ -2016,7 +2044,8 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     } else {
         if (hipDeviceSynchronize() != hipSuccess) return FMPC_E_HIP;
         stv.resize(B);
-        if (hipMemcpy(z_out, base + o_z, Nz * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (z_out && hipMemcpy(z_out, base + o_z, Nz * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
+        if (u0_out && hipMemcpy(u0_out, base + o_u0, (size_t)h->m * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
         if (nu_out && hipMemcpy(nu_out, base + o_nu, nbn * B * 8, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
         if (hipMemcpy(stv.data(), d_st, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
         if (iters && hipMemcpy(iters, d_it, B * 4, hipMemcpyDeviceToHost) != hipSuccess) return FMPC_E_HIP;
@@ -2038,6 +2067,17 @@ extern "C" int fmpc_solve(fmpc_handle h, int batch,
                           int n_newton, double k,
                           double* z_out, double* nu_out, int* status, int* iters, double* step) {
     return fmpc_solve_host(h, batch, x0, x0_pre, w, nullptr, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step);
+}
+
+// fmpc_solve with HOST pointers that returns the first moves u0 = z(1:m) (README.md:589: the caller applies U(1:nu) only): m x batch
+// doubles come back instead of N_z x batch (2.3 MB instead of 82 MB per 2000 problems at (27,144,30)); z_out may be given as well.
+extern "C" int fmpc_solve_u0(fmpc_handle h, int batch,
+                             const double* x0, const double* x0_pre, const double* w,
+                             const double* z_init, const double* nu0,
+                             int n_newton, double k,
+                             double* z_out, double* u0_out, int* status, int* iters) {
+    if (!u0_out) return FMPC_E_NULL;
+    return fmpc_solve_host(h, batch, x0, x0_pre, w, nullptr, z_init, nu0, n_newton, k, z_out, nullptr, status, iters, nullptr, u0_out);
 }
 
 extern "C" int fmpc_solve_ramp(fmpc_handle h, int batch,

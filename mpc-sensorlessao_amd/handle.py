@@ -221,13 +221,18 @@ class FastMPCHandle:
         if not want_z and (u0_out is None or u_prev is not None):
             raise FastMPCError(_lib.FMPC_E_NULL, "want_z=False needs u0_out (and no ramp rows)")
         if z_out is None and want_z:
-            z_out = torch.empty((batch, self.nz), dtype=torch.float64, device=dev)
+            ld_ = getattr(self, "_z_ld", 0)
+            z_out = (torch.empty((batch, ld_), dtype=torch.float64, device=dev)[:, :self.nz] if ld_ > self.nz
+                     else torch.empty((batch, self.nz), dtype=torch.float64, device=dev))
         if not want_z:
             z_out = None
         if status is None:
             status = torch.empty(batch, dtype=torch.int32, device=dev)
         if iters is None:
             iters = torch.empty(batch, dtype=torch.int32, device=dev)
+        # Row distance of z_out: an ARGUMENT of this call (fmpc_solve_u0_device_ld), never handle state.  A view of a wider array
+        # (stride(0) > N_z) is taken as it is; a stride set with set_z_ld applies to the array this method allocates itself, and a
+        # z_out whose rows do not have that distance is solved with ITS distance (round 4 wrote such rows at the handle's).
         zld = 0
         if (z_out is not None and z_out.dim() == 2 and tuple(z_out.shape) == (batch, self.nz) and z_out.is_cuda
                 and z_out.dtype == torch.float64 and z_out.stride(1) == 1 and z_out.stride(0) > self.nz):
@@ -240,40 +245,53 @@ class FastMPCHandle:
             chk(step, self._lib.fmpc_step_ld(n_newton), "step")
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        per_call = zld and zld != getattr(self, "_z_ld", 0)       # (a stride set with set_z_ld stays; otherwise for this call only)
         if zld and u_prev is not None:
             raise FastMPCError(_lib.FMPC_E_UNSUPPORTED, "padded z rows: not with the ramp-rate rows")
-        if per_call:
-            rcz = self._lib.fmpc_set_z_ld(self._h, zld)
-            if rcz != _lib.FMPC_OK:
-                raise FastMPCError(rcz, "fmpc_set_z_ld")
-        try:
-            rc = self._solve_device_call(batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
-                                         u_prev, u0_out, stream)
-        finally:
-            if per_call:
-                self._lib.fmpc_set_z_ld(self._h, getattr(self, "_z_ld", 0))
+        rc = self._solve_device_call(batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
+                                     u_prev, u0_out, stream, zld)
         if rc != _lib.FMPC_OK:
             raise FastMPCError(rc, "fmpc_solve_ramp_device" if u_prev is not None else "fmpc_solve_device")
         return z_out, status, iters
 
     def _solve_device_call(self, batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step, u_prev, u0_out,
-                           stream):
+                           stream, zld=0):
         if u_prev is not None:
             rc = self._lib.fmpc_solve_ramp_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
                                                   p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
                                                   p(iters), p(step), stream)
             if rc == _lib.FMPC_OK and u0_out is not None:
                 rc = self._lib.fmpc_unpack_device(self._h, batch, p(z_out), None, None, p(u0_out), stream)
-        elif u0_out is not None:
-            rc = self._lib.fmpc_solve_u0_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
-                                                n_newton, float(k), p(z_out), p(nu_out), p(status),
-                                                p(iters), p(step), p(u0_out), stream)
         else:
-            rc = self._lib.fmpc_solve_device(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
-                                             n_newton, float(k), p(z_out), p(nu_out), p(status),
-                                             p(iters), p(step), stream)
+            rc = self._lib.fmpc_solve_u0_device_ld(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
+                                                   n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                                   p(iters), p(step), p(u0_out), int(zld), stream)
         return rc
+
+    def solve_u0(self, x0, x0_pre=None, w=None, z_init=None, nu0=None, n_newton=1, k=1e-2, u0_out=None, return_info=False, check=True):
+        """fmpc_solve_u0 (host arrays): the first moves u0 = U(1:nu) of every problem (README.md:589) and nothing else --
+        m x batch doubles come back from the device instead of N_z x batch.  Returns u0 (batch, m) [, dict status/iters/rc]."""
+        single = np.asarray(x0).ndim == 1
+        x0 = _f64(x0)
+        batch = 1 if single else x0.shape[0]
+        x0 = _f64(x0, (batch, self.n), "x0")
+        x0_pre = _f64(x0_pre, (batch, self.n), "x0_pre")
+        w = _f64(w, (batch, self.T * self.n), "w")
+        z_init = _f64(z_init, (batch, self.nz), "z_init")
+        nu0 = _f64(nu0, (batch, self.nu_len), "nu0")
+        if u0_out is not None:
+            if not (isinstance(u0_out, np.ndarray) and u0_out.dtype == np.float64 and u0_out.flags.c_contiguous and u0_out.shape == (batch, self.m)):
+                raise FastMPCError(_lib.FMPC_E_DIM, "u0_out must be a C-contiguous float64 array of shape (batch, m)")
+            u0 = u0_out
+        else:
+            u0 = np.empty((batch, self.m))
+        status = np.zeros(batch, dtype=np.int32)
+        iters = np.zeros(batch, dtype=np.int32)
+        rc = self._lib.fmpc_solve_u0(self._h, batch, _ptr(x0), _ptr(x0_pre), _ptr(w), _ptr(z_init), _ptr(nu0),
+                                     0 if n_newton is None else int(n_newton), float(k), None, _ptr(u0), _ptr(status), _ptr(iters))
+        if rc < 0 and check:
+            raise FastMPCError(rc, "fmpc_solve_u0")
+        ur = u0[0] if single else u0
+        return (ur, {"status": status, "iters": iters, "rc": rc}) if return_info else ur
 
     def set_z_ld(self, ldz):
         """fmpc_set_z_ld: rows of z_out of the device-pointer solves ldz doubles apart (0: contiguous)."""

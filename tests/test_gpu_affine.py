@@ -239,6 +239,28 @@ def test_padded_z_rows(pkg, gpu, ldz_extra, batch, tight):
     h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=big[:, :h.nz])
     torch.cuda.synchronize()
     assert torch.equal(big[:, :h.nz], zc)
+    # with a stride that stays, a CONTIGUOUS z_out (or none) must not be written at the handle's row distance --
+    # the row distance is an argument of the call (fmpc_solve_u0_device_ld); a guard region behind the array stays untouched
+    guard = torch.full((batch * h.nz + 64 * ldz,), -3.0, dtype=torch.float64, device=dev)
+    zg = guard[:batch * h.nz].view(batch, h.nz)
+    h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2, z_out=zg)
+    z_auto, _, _ = h.solve_device(t["x0"], t["x0_pre"], None, None, t["nu0"], 1, 1e-2)
+    torch.cuda.synchronize()
+    assert torch.equal(zg, zc) and bool((guard[batch * h.nz:] == -3.0).all()), "rows written at the handle's stride"
+    assert z_auto.stride(0) == ldz and torch.equal(z_auto, zc)            # (the array the method allocates takes the stride)
+    # the raw C ABI: the handle's persistent stride serves fmpc_solve_device, an explicit ldz overrides it for one call
+    import ctypes as C
+    lib = pkg.load()
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    big.fill_(-7.0); zg.fill_(-3.0)
+    st_ = torch.empty(batch, dtype=torch.int32, device=dev); it_ = torch.empty_like(st_)
+    assert lib.fmpc_solve_device(h._h, batch, vp(t["x0"]), vp(t["x0_pre"]), None, None, vp(t["nu0"]), 1, 1e-2, vp(big), None, vp(st_), vp(it_), None, None) == 0
+    assert lib.fmpc_solve_u0_device_ld(h._h, batch, vp(t["x0"]), vp(t["x0_pre"]), None, None, vp(t["nu0"]), 1, 1e-2, vp(zg), None, vp(st_), vp(it_), None,
+                                       None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(big[:, :h.nz], zc) and torch.equal(zg, zc) and bool((guard[batch * h.nz:] == -3.0).all())
+    assert lib.fmpc_solve_u0_device_ld(h._h, batch, vp(t["x0"]), vp(t["x0_pre"]), None, None, vp(t["nu0"]), 1, 1e-2, vp(zg), None, vp(st_), vp(it_), None,
+                                       None, h.nz - 1, None) == pkg._lib.FMPC_E_DIM
     w = torch.zeros((batch, h.T * h.n), dtype=torch.float64, device=dev)
     for kw in (dict(w=w), dict(n_newton=5), dict(z_init=zc.clone())):
         args = dict(w=None, z_init=None, n_newton=1); args.update(kw)

@@ -411,3 +411,31 @@ def test_host_pointer_entry_pinned_and_direct_staging_and_output_reuse(pkg, gpu)
     with pytest.raises(pkg.FastMPCError):
         h.solve(d["x0"], d["x0_pre"], None, nu0=d["nu0"], z_out=np.empty((39, h.nz)))
     h.close()
+
+
+def test_host_pointer_first_move_entry(pkg, gpu):
+    """fmpc_solve_u0 (README.md:558-570,589: the caller applies U(1:nu) only): host pointers in, the first moves
+    out -- equal bit for bit to z[:, :m] of fmpc_solve on every path (cold start / affine form, Newton budget, explicit start, w,
+    pinned and direct staging), status / iters as fmpc_solve reports them, z_out optional beside u0_out, raw ctypes with NULLs."""
+    lib = pkg.load()
+    for (T, B) in ((6, 3), (30, 1), (30, 300)):
+        md = pkg.synthetic.make_model(27, 144, T)
+        h = handle_from_model(pkg, md)
+        d = pkg.synthetic.make_replay_batch(md, r=11, steps=B)
+        rng = np.random.default_rng(T)
+        w = 0.01 * rng.standard_normal((B, T * 27))
+        zi = 0.1 * rng.standard_normal((B, T * 171))
+        for kw in (dict(n_newton=1), dict(n_newton=3), dict(n_newton=1, w=w), dict(n_newton=2, z_init=zi), dict(n_newton=1, nu0=None)):
+            nu0 = kw.get("nu0", d["nu0"])
+            z, info = h.solve(d["x0"], d["x0_pre"], kw.get("w"), z_init=kw.get("z_init"), nu0=nu0, n_newton=kw["n_newton"], k=1e-2, return_info=True)
+            u0, iu = h.solve_u0(d["x0"], d["x0_pre"], kw.get("w"), z_init=kw.get("z_init"), nu0=nu0, n_newton=kw["n_newton"], k=1e-2, return_info=True)
+            assert u0.shape == (B, 144) and np.array_equal(u0, z[:, :144]), kw.keys()
+            assert np.array_equal(iu["iters"], info["iters"]) and np.array_equal(iu["status"], info["status"]) and iu["rc"] == info["rc"]
+        # raw C ABI: z_out beside u0_out, NULL status / iters, NULL u0_out refused
+        zr = np.empty((B, T * 171)); ur = np.full((B, 144), np.nan)
+        assert lib.fmpc_solve_u0(h._h, B, _p(d["x0"]), _p(d["x0_pre"]), None, None, _p(d["nu0"]), 1, 1e-2, _p(zr), _p(ur), None, None) == 0
+        z1 = h.solve(d["x0"], d["x0_pre"], None, nu0=d["nu0"], n_newton=1, k=1e-2)
+        assert np.array_equal(zr, z1) and np.array_equal(ur, z1[:, :144])
+        assert lib.fmpc_solve_u0(h._h, B, _p(d["x0"]), _p(d["x0_pre"]), None, None, None, 1, 1e-2, _p(zr), None, None, None) == pkg.FMPC_E_NULL
+        assert lib.fmpc_solve_u0(h._h, -1, _p(d["x0"]), None, None, None, None, 1, 1e-2, None, _p(ur), None, None) == pkg.FMPC_E_DIM
+        h.close()

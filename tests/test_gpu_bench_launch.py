@@ -35,7 +35,7 @@ def test_bench_gpus2_self_launch_rehearsal(gpu):
     # whole-job value = the units all ranks processed / the slowest rank's time
     assert abs(out["value"] - 2 * out["config"]["batch_per_gpu"] / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
     r = out["roofline"]
-    assert r["bound"] == "hbm" and r["bytes_per_unit"] == 8 * (2 * 27 + 30 * 27 + 30 * (27 + 144))
+    assert r["bound"] == "hbm" and r["bytes_per_unit"] == 8 * (2 * 27 + 30 * (27 + 144))      # w = NULL: no T*n doubles of w
 
 
 @pytest.mark.gpu
@@ -46,5 +46,14 @@ def test_bench_single_gpu_line_has_both_rooflines(gpu):
     # the headline's roofline describes the timed region: bytes per unit x units / device time per step
     assert abs(r["achieved"] - r["bytes_per_unit"] * r["units_per_launch"] / (r["ms_per_step_device"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
     assert r["ms_per_step_device"] <= out["ms_per_step"] * 1.05
+    # the w-less headline moves 8 (2n + T(n+m)) = 41 472 B per problem, the measured traffic is reported with its
+    # ratio to that model (never dropped), and the contiguous-rows figure (the reference's layout) sits beside the padded one
+    assert r["bytes_per_unit"] == 8 * (2 * 27 + 30 * 171) == 41472
+    assert r["traffic"] is not None and abs(r["traffic_over_compulsory"] - r["traffic"] / (41472 * 2000)) < 1e-12
+    c = r["contiguous_rows"]
+    assert abs(r["frac_contiguous_rows"] - c["frac"]) < 1e-15 and abs(c["achieved"] - 41472 * 2000 / (c["ms_per_step_device"] * 1e-3) / 1e9) <= 1e-9 * c["achieved"]
+    assert out["z_layout"] == "padded_5136" and out["submission"] in ("hip_graph", "eager")
+    assert abs(out["value_contiguous_rows"] - c["value"]) <= 1e-9 * c["value"] and c["value"] < 1.2 * out["value"]
+    assert rp["hbm_streamed_factor_model"]["bytes_per_unit"] == 41472 + 8 * 2 * 30 * 3 * 27 * 27
     assert rp["bound"] == "mfma" and "n_newton_5" in rp and rp["n_newton_5"]["frac"] > 0
     assert abs(rp["achieved"] - rp["flops_per_unit"] * rp["units_per_launch"] / (rp["ms_per_step"] * 1e-3) / 1e12) <= 1e-9 * rp["achieved"]
