@@ -342,7 +342,7 @@ def _main(real_out):
     # and one all-gather ("fewer, larger collectives"), two buffers in turn so that a gather in flight never holds up a solve;
     # the last, partial group is gathered when the timed region ends (head_after runs inside it).
     GROUP = int(os.environ.get("FMPC_BENCH_GATHER_GROUP", "8"))
-    gather_state = {"pending": [None, None], "bufs": None, "slot": 0, "fill": 0}
+    gather_state = {"pending": [None, None], "bufs": None, "slot": 0, "fill": 0, "issued": 0, "async": 0}
     if dist_on:
         gather_state["bufs"] = [torch.empty((GROUP, B, m), dtype=torch.float64, device=dev) for _ in range(2)]
         gather_state["all"] = [torch.empty((world, GROUP, B, m), dtype=torch.float64, device=dev) for _ in range(2)]
@@ -356,6 +356,8 @@ def _main(real_out):
             dist.all_gather(parts, gather_state["bufs"][s_].cpu())
         else:
             gather_state["pending"][s_] = dist.all_gather_into_tensor(gather_state["all"][s_], gather_state["bufs"][s_], async_op=True)
+            gather_state["async"] += 1
+        gather_state["issued"] += 1
         gather_state["slot"] = 1 - s_
         gather_state["fill"] = 0
 
@@ -400,6 +402,13 @@ def _main(real_out):
         _, _, kern_ms = timed(head_step, 5, 2)
         lanes.close()
     iters_head = head.check()
+    gather_ok = None
+    if dist_on and not rehearse:
+        # what the all-gathers delivered: this rank's slice of every gathered buffer is, bit for bit, the buffer the solves wrote
+        # (a full group fills a buffer completely; both buffers have been gathered at least once after the warm-up + regions)
+        torch.cuda.synchronize(dev)
+        gather_ok = bool(gather_state["issued"] >= 2 and all(torch.equal(gather_state["all"][s_][rank], gather_state["bufs"][s_]) for s_ in (0, 1)))
+        assert gather_ok, "the gathered first moves differ from the local ones"
     # The same leg with the z rows of consecutive problems CONTIGUOUS (N_z doubles apart: the layout a caller of the reference's
     # N_z x batch column-major array has), same submission, same regions: reported inside `roofline` beside the padded figure.
     contig = None
@@ -897,6 +906,8 @@ def _main(real_out):
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = dist.get_backend()
             out["ms_per_step_by_rank"] = [t_ / steps_done * 1e3 for t_ in head_rank_times]
+            out["gather"] = {"collectives_issued": gather_state["issued"], "async_all_gather_into_tensor": gather_state["async"],
+                             "steps_per_collective": GROUP, "gathered_equals_local_bitwise": gather_ok}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

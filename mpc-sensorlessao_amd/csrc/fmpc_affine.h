@@ -16,14 +16,11 @@ struct FaParams {
     const double* x0; const double* x0p; const double* nu0;
     double* zout; double* nuout; double* u0out; int* status; int* iters; double* step;
     int* need; int* handed;
-    int* nflag;                         // += 1 per problem flagged in `need` (device counter, zero at entry: the exact-path launch behind this
-                                        // kernel reads it first and leaves at once when nothing was flagged, without scanning `need`)
+    int* nflag;                         // += 1 per problem flagged in `need` (a running device counter, never reset: the exact-path launch behind
+                                        // this kernel compares it with the count it has dealt with and leaves at once when they agree)
     double* dump;                       // 4096 doubles nobody reads: where lanes without a valid target store (no branch around a store)
-    const double* imgJ; const double* imgX; const double* imgBw;   // two-stage form (fmpc_kernel_affine2.hip), NULL: not built
 };
 
 hipError_t fmpc_launch_affine(FaParams P, int num_cu, hipStream_t stream);
 // The same step as TWO chained products per stage (nu+_s = J_s d, u_s = Bw nu+_s; the x rows directly): 20 % fewer matrix
 // instructions and one task per wavefront.  z_out required, nu_out not served (the caller takes fmpc_launch_affine then).
-bool fmpc_affine2_applies(const FaParams& P);
-hipError_t fmpc_launch_affine2(FaParams P, hipStream_t stream);

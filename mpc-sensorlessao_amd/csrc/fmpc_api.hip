@@ -18,16 +18,9 @@
 #include "fmpc_loopu0.h"
 #include "fmpc_tiled.h"
 #define FMPC_PRODUCT_MIN_BATCH_DEFAULT 65   // closed-loop steps with first moves only: the product form from this many realisations on
-#include <atomic>
+#include "fmpc_alloc.h"                    // counted hipMalloc / hipFree (fmpc_alloc_generation), shared with fmpc_est_api.hip
 
-// Every device allocation and release of this file bumps one process-wide counter (fmpc_alloc_generation): a HIP graph
-// recorded over solve calls holds the addresses of the handle's workspaces, and a replay after any of them has been
-// reallocated would use freed memory -- whoever replays compares the counter first (RecordedSolves in handle.py).
-static std::atomic<unsigned long long> fmpc_alloc_gen{0};
-static inline hipError_t fmpc_counted_malloc(void** p, size_t bytes) { fmpc_alloc_gen.fetch_add(1); return hipMalloc(p, bytes); }
-static inline hipError_t fmpc_counted_free(void* p) { fmpc_alloc_gen.fetch_add(1); return hipFree(p); }
-#define hipMalloc(p, bytes) fmpc_counted_malloc((void**)(p), (bytes))
-#define hipFree(p) fmpc_counted_free((void*)(p))
+std::atomic<unsigned long long> fmpc_alloc_gen{0};
 extern "C" unsigned long long fmpc_alloc_generation(void) { return fmpc_alloc_gen.load(); }
 
 
@@ -72,7 +65,7 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             const double* gate = nullptr, const double* epsp = nullptr, int* handed = nullptr,
                             const double* nuws = nullptr, double* u0out = nullptr,
                             int pphase = 0, const double* rnp = nullptr, int* list = nullptr, int u0_done = 0,
-                            const int* nflag = nullptr, int* nflag_zero = nullptr, int zld = 0);
+                            int* nflag = nullptr, int zld = 0);
 size_t fmpc_wave_shared_fac_doubles(int n, int nb);
 void fmpc_wave_cold_layout(int n, int mp, int* off9);
 
@@ -118,8 +111,8 @@ struct fmpc_handle_s {
     size_t pn_o_simg, pn_o_limg, pn_o_bt, pn_o_aimg, pn_o_vec, pn_o_ucon, pn_o_dump, pn_doubles;
     int* pn_cnt;                         // problems the exact path had to solve in the last call (diagnostic)
     int* gn_list; double* gn_nu; int* gn_cnt; int* gn_cnt_host; size_t gn_cap; int gn_split;   // explicit-start batches with a budget > 1: first step / continuation split (FMPC_NO_GENERAL_SPLIT=1: one launch)
-    int* fa_nflag; int fa_parity;        // affine form: two counters of flagged problems used in turn (the exact-path launch of a call
-                                         // reads the one its affine kernel added to and zeroes the other for the next call)
+    int* fa_nflag;                       // affine form: [running count of flagged problems | the count the last exact-path launch dealt with | its
+                                         // ticket]: the exact-path launch leaves at once while the two counts agree (FwParams::nflag)
     size_t pn_cap;                       // per-batch buffers of the panel path, grown together
     double* pn_gate; double* pn_epsp; double* pn_nuws;
     double* pn_rnp; int* pn_list;        // budgets > 1: next-exit-test partials, compacted list of the problems that go on
@@ -338,7 +331,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     { const char* na = getenv("FMPC_PRODUCT_MIN_BATCH"); h->fs_min_batch = (na && atoi(na) >= 1) ? atoi(na) : FMPC_PRODUCT_MIN_BATCH_DEFAULT; }
     { const char* nf = getenv("FMPC_NO_FIRST_MOVE"); h->fm_disabled = (nf && nf[0] == '1') ? 1 : 0; }
     h->inv_failed = 0; h->inv_failed_k = 0.0; h->inv_enabled = 0; h->inv_last = 0; h->inv_valid = 0; h->inv_jks = 0; h->inv_max_batch = 768; h->inv_k = 0.0; h->inv_jimg = nullptr; h->inv_nuc = nullptr; h->inv_eimg = nullptr; h->inv_jst = nullptr; h->inv_nucst = nullptr; h->inv_fuse = 0; h->inv_jimg2 = nullptr; h->inv_jks2 = 0; h->lp_v = nullptr; h->lp_cap = 0; h->lp_hint = 0;
-    h->fa_nflag = nullptr; h->fa_parity = 0;
+    h->fa_nflag = nullptr;
     h->gn_list = nullptr; h->gn_nu = nullptr; h->gn_cnt = nullptr; h->gn_cnt_host = nullptr; h->gn_cap = 0;
     { const char* gs = getenv("FMPC_NO_GENERAL_SPLIT"); h->gn_split = (gs && gs[0] == '1') ? 0 : 1; }
     h->pn_cnt = nullptr; h->pn_cap = 0; h->pn_gate = nullptr; h->pn_epsp = nullptr; h->pn_nuws = nullptr; h->pn_rnp = nullptr; h->pn_list = nullptr; h->pn_cnt_host = nullptr; h->pn_dz_lds = 0; h->pn_rd2_0 = 0.0; h->pn_rp2c = 0.0;
@@ -539,10 +532,10 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
                 h->pn_o_aimg = PL.o_aimg; h->pn_o_vec = PL.o_vec; h->pn_o_ucon = PL.o_ucon; h->pn_o_dz = PL.o_dz;
                 h->pn_doubles = PL.pool_doubles;
                 if (hipMalloc((void**)&h->pn_pool, o * sizeof(double)) != hipSuccess ||
-                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->fa_nflag, 2 * sizeof(int)) != hipSuccess ||
+                    hipMalloc((void**)&h->pn_cnt, 2 * sizeof(int)) != hipSuccess || hipMalloc((void**)&h->fa_nflag, 4 * sizeof(int)) != hipSuccess ||
                     hipMalloc((void**)&h->pn_sched, (size_t)2 * FP_MAX_STEPS(h->nb) * FP_STEP_INTS * sizeof(int)) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 (void)hipMemset(h->pn_cnt, 0, 2 * sizeof(int));     // [handed over, length of the continuation list]
-                (void)hipMemset(h->fa_nflag, 0, 2 * sizeof(int));
+                (void)hipMemset(h->fa_nflag, 0, 4 * sizeof(int));
                 if (hipHostMalloc((void**)&h->pn_cnt_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { fmpc_destroy(h); return FMPC_E_ALLOC; }
                 h->pn_cnt_host[0] = -1; h->pn_cnt_host[1] = -1;   // nothing known yet
                 h->pn_dz_lds = fmpc_dz_lds_bytes(pmp, 1);
@@ -785,11 +778,14 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
 // launches the tiled kernel; caller holds h->mu
 // nw_override: wavefronts per problem other than the handle's default (2 or 4, fp64 without dense R): few problems per CU
 // are solved faster by more wavefronts each (the latency of a problem is what counts then)
-static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, const double* x0_pre, const double* w,
-                            const double* z_init, const double* nu0, int n_newton, double k, double* z_out,
-                            double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream,
-                            int nw_override = 0, const int* list = nullptr, const int* nlist = nullptr, const double* nuws = nullptr,
-                            int grid_hint = 0) {
+static bool fmpc_capturing(hipStream_t stream);
+struct FmpcTiledPlan { int NWu; size_t ldsu; int grid; size_t slot; };
+// Everything a tiled launch needs BEFORE anything is enqueued: the instance is built and prepared, the launch is sized and its
+// workspace exists.  A caller that enqueues another launch first (the first-step / continuation split) plans first and falls
+// back when this fails, so a failure never leaves a half-finished solve.  While `stream` is being captured into a
+// graph nothing is allocated or released (that would end the capture): grid_hint is ignored and the launch is clamped to the
+// slots the workspace already has -- the kernel walks its problems with a workgroup stride, any grid is correct.
+static int fmpc_tiled_plan(fmpc_handle h, int t, int batch, hipStream_t stream, int nw_override, int grid_hint, FmpcTiledPlan* out) {
     fmpc_handle_s::Tiled& X = h->tl[t];
     if (!X.ready) {
         const int rc = t ? fmpc_tiled_build<float>(h, 1) : fmpc_tiled_build<double>(h, 0);
@@ -808,34 +804,54 @@ static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, c
     if (wgs < 1) wgs = 1;
     if (wgs * NWu > 8) wgs = 8 / NWu > 0 ? 8 / NWu : 1;                // two waves per SIMD (the kernel's launch bound)
     const int cap = h->num_cu * wgs;
+    const bool capturing = fmpc_capturing(stream);
     int grid = batch < cap ? batch : cap;
-    if (grid_hint > 0 && grid_hint < grid) grid = grid_hint;           // (a list: as many workgroups as it is expected to be long)
+    if (!capturing && grid_hint > 0 && grid_hint < grid) grid = grid_hint;   // (a list: as many workgroups as it is expected to be long)
     const FtWs L = ft_ws_layout(h->n, h->m, h->T, h->nb, X.NB, t ? 4 : 8, h->denseR);
     // one workspace slot per LAUNCHED workgroup (not per workgroup the chip could hold: a warm start of one problem or a
     // continuation list of 200 would otherwise allocate 0.5-1.4 GB per handle); grown geometrically up to the full grid,
     // so that a growing sequence of batch sizes reallocates (and synchronises) a logarithmic number of times
     const size_t need = L.total * (size_t)grid, full = L.total * (size_t)cap;
     if (need > h->tl_ws_doubles) {
-        size_t want = 2 * h->tl_ws_doubles;
-        if (want < need) want = need;
-        if (want > full) want = full;
-        if (h->tl_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->tl_ws); h->tl_ws = nullptr; h->tl_ws_doubles = 0; }
-        if (hipMalloc((void**)&h->tl_ws, want * sizeof(double)) != hipSuccess) {
-            if (want == need || hipMalloc((void**)&h->tl_ws, need * sizeof(double)) != hipSuccess) { h->tl_ws = nullptr; return FMPC_E_ALLOC; }
-            want = need;
+        if (capturing) {
+            const size_t have = h->tl_ws_doubles / L.total;
+            if (have < 1) return FMPC_E_ALLOC;
+            grid = (int)have;
+        } else {
+            size_t want = 2 * h->tl_ws_doubles;
+            if (want < need) want = need;
+            if (want > full) want = full;
+            if (h->tl_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->tl_ws); h->tl_ws = nullptr; h->tl_ws_doubles = 0; }
+            if (hipMalloc((void**)&h->tl_ws, want * sizeof(double)) != hipSuccess) {
+                if (want == need || hipMalloc((void**)&h->tl_ws, need * sizeof(double)) != hipSuccess) { h->tl_ws = nullptr; return FMPC_E_ALLOC; }
+                want = need;
+            }
+            h->tl_ws_doubles = want;
         }
-        h->tl_ws_doubles = want;
     }
+    out->NWu = NWu; out->ldsu = ldsu; out->grid = grid; out->slot = L.total;
+    return FMPC_OK;
+}
+
+static int fmpc_solve_tiled(fmpc_handle h, int t, int batch, const double* x0, const double* x0_pre, const double* w,
+                            const double* z_init, const double* nu0, int n_newton, double k, double* z_out,
+                            double* nu_out, int* status, int* iters, double* step, double* u0_out, hipStream_t stream,
+                            int nw_override = 0, const int* list = nullptr, const int* nlist = nullptr, const double* nuws = nullptr,
+                            int grid_hint = 0, const FmpcTiledPlan* planned = nullptr) {
+    FmpcTiledPlan plan;
+    if (planned) plan = *planned;
+    else { const int rc = fmpc_tiled_plan(h, t, batch, stream, nw_override, grid_hint, &plan); if (rc != FMPC_OK) return rc; }
+    fmpc_handle_s::Tiled& X = h->tl[t];
     FtParams P;
     P.M = h->dev; P.V = X.V; P.batch = batch;
     P.x0 = x0; P.x0p = x0_pre; P.w = w; P.zinit = z_init; P.nu0 = nu0;
     P.max_iter = n_newton > 0 ? n_newton : 1000; P.kbar = k;
     P.zout = z_out; P.nuout = nu_out; P.status = status; P.iters = iters; P.step = step; P.step_ld = fmpc_step_ld(n_newton);
-    P.ws = h->tl_ws; P.ws_stride = L.total; P.u0out = u0_out;
+    P.ws = h->tl_ws; P.ws_stride = plan.slot; P.u0out = u0_out;
     P.list = list; P.nlist = nlist; P.nuws = nuws;
-    h->tl_last_nw = NWu;
+    h->tl_last_nw = plan.NWu;
     if (!list) h->last_path = t ? FMPC_PATH_TILED_F32 : FMPC_PATH_TILED;
-    return fmpc_launch_tiled(P, X.NB, NWu, t, grid, ldsu, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+    return fmpc_launch_tiled(P, X.NB, plan.NWu, t, plan.grid, plan.ldsu, stream) == hipSuccess ? FMPC_OK : FMPC_E_HIP;
 }
 
 extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
@@ -871,7 +887,7 @@ static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
 // (Under stream capture -- the solves of a recorded stretch going into a HIP graph, RecordedSolves in handle.py -- the handle's
 // event is left alone: an event recorded inside a capture cannot be waited for by a stream outside it, and the order of a
 // replay against other work is the order of the stream it is replayed on.)
-static bool fmpc_capturing(hipStream_t stream) {
+static bool fmpc_capturing(hipStream_t stream) {            // (declared above fmpc_tiled_plan)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
@@ -1053,8 +1069,7 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
     // affine form of the whole step without w: [Kz | zc] as matrix-core images; the (x0, x0_pre) blocks of E, Ep likewise
     h->fa_valid = 0;
     FmpcAffineOut AO;
-    size_t oA = 0, oAE = 0, oAEp = 0, oAl = 0, oAlp = 0, oAd = 0, oAJ = 0, oAX = 0, oAB = 0;
-    bool fa2_ok = false;
+    size_t oA = 0, oAE = 0, oAEp = 0, oAl = 0, oAlp = 0, oAd = 0;
     bool fa_ok = !h->fa_disabled && 2 * n + 2 <= FA_KC;
     if (fa_ok) {
         FmpcAffineIn AI;
@@ -1076,7 +1091,6 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         fmpc_host_mfma_a_images(Ep64.data(), 64, imgEp);
         oA = push(AO.img); oAE = push(imgE); oAEp = push(imgEp); oAl = push(el); oAlp = push(epl);
         oAd = push(std::vector<double>(4096, 0.0));
-        if (!AO.imgJ.empty()) { oAJ = push(AO.imgJ); oAX = push(AO.imgX); oAB = push(AO.imgBw); fa2_ok = true; }
     }
     // the first-move form as a product over many realisations (fmpc_kernel_loopu0.hip): [K0 | u0c], E, Ep as matrix-core images
     // over d -- in the order [x0; x0_pre; B u1; B u2; 1] behind the loop-input kernel, in blocks of 28 with the constant in
@@ -1111,7 +1125,6 @@ static int fmpc_build_first_move(fmpc_handle h, double k) {
         A.n = n; A.m = m; A.T = T; A.nb = h->nb; A.has_xf = h->has_xf; A.rows = AO.rows; A.tiles = AO.tiles; A.nu_rows = AO.nu_rows; A.nu_tiles = AO.nu_tiles;
         A.img = h->fm_pool + oA; A.imgE = h->fm_pool + oAE; A.imgEp = h->fm_pool + oAEp; A.elin = h->fm_pool + oAl; A.eplin = h->fm_pool + oAlp; A.dump = h->fm_pool + oAd;
         A.dx0T = P.dx0T; A.e0 = O.e0; A.ep0 = O.ep0; A.normE = O.normE; A.norme = O.norme; A.normEp = O.normEp; A.normep = O.normep; A.rd2_0 = h->pn_rd2_0;
-        if (fa2_ok) { A.imgJ = h->fm_pool + oAJ; A.imgX = h->fm_pool + oAX; A.imgBw = h->fm_pool + oAB; }
         h->fa_valid = 1;
     }
     if (fl_ok) {
@@ -1284,21 +1297,16 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                     A.batch = batch; A.step_ld = fmpc_step_ld(n_newton);
                     A.x0 = x0; A.x0p = x0_pre; A.nu0 = nu0; A.zout = z_null ? nullptr : z_out; A.nuout = nu_out; A.u0out = u0_out;
                     A.status = status; A.iters = iters; A.step = step; A.need = h->fa_need; A.handed = h->pn_cnt;
-                    int* const nf = h->fa_nflag + h->fa_parity;           // this call's counter of flagged problems (zero: the previous
-                    int* const nfz = h->fa_nflag + (h->fa_parity ^ 1);    // call's exact-path launch, or the allocation, left it so)
-                    h->fa_parity ^= 1;
+                    int* const nf = h->fa_nflag;                          // [running count of flagged problems | count dealt with | ticket]: device
+                                                                          // state only, the same in an eager call and in a recorded graph
                     static const bool no_nflag = [] { const char* e = getenv("FMPC_NO_NFLAG"); return e && e[0] == '1'; }();   // A/B switch
                     A.nflag = no_nflag ? nullptr : nf;
                     A.ldz = zld;                                          // (0: contiguous rows)
-                    // the two-stage form (22 % fewer matrix instructions, one task per wavefront): opt-in, FMPC_AFFINE2=1 -- the step is
-                    // bound by the HBM write path, not by the matrix pipes, and the form measured 3 us slower (fmpc_kernel_affine2.hip)
-                    const char* a2e = getenv("FMPC_AFFINE2_MIN_BATCH");
-                    const bool two_stage = !zld && batch >= (a2e && a2e[0] ? atoi(a2e) : 1024) && fmpc_affine2_applies(A);
-                    if ((two_stage ? fmpc_launch_affine2(A, (hipStream_t)stream) : fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream)) != hipSuccess) return FMPC_E_HIP;
+                    if (fmpc_launch_affine(A, h->num_cu, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
                     int g3 = grid < 64 ? grid : 64;                    // flag mode: the waves walk over the flags, few are set
                     e = fmpc_launch_wave(h->dev, h->wave, batch, g3, x0, x0_pre, nullptr, nullptr, nu0, 1, k, z_out, nu_out, status, iters, step,
                                          fmpc_step_ld(n_newton), h->ws, stride, h->wave_lds, (hipStream_t)stream, 1, h->sh_fac, h->sh_rs, h->sh_ok,
-                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need, 0, no_nflag ? nullptr : nf, nfz, zld);
+                                         h->cold_d, nullptr, nullptr, h->pn_cnt, nullptr, u0_out, 3, nullptr, h->fa_need, 0, no_nflag ? nullptr : nf, zld);
                     h->last_path = FMPC_PATH_PANEL; h->inv_last = 2;
                     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
                 }
@@ -1378,7 +1386,17 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                                               u0_out, (hipStream_t)stream, batch <= 512 ? h->small_nw : 2);
             if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;
         }
-        if (mode == 0 && max_iter > 1 && h->small_tiled && h->gn_split) {
+        FmpcTiledPlan gplan;
+        int gn_hint = 0;
+        bool gn_go = mode == 0 && max_iter > 1 && h->small_tiled && h->gn_split;
+        if (gn_go) {
+            // the continuation's launch is planned (instance, size, workspace) BEFORE the first-step launch is enqueued: if the tiled
+            // kernel cannot run, the single launch below solves the batch and nothing is left half done
+            const int last = h->gn_cnt_host ? ((volatile int*)h->gn_cnt_host)[1] : -1;   // list length an EARLIER call reported (never waited for)
+            gn_hint = last >= 0 ? last + last / 2 + 16 : 0;
+            if (fmpc_tiled_plan(h, 0, batch, (hipStream_t)stream, h->small_nw, gn_hint, &gplan) != FMPC_OK) gn_go = false;
+        }
+        if (gn_go) {
             // Explicit-start batch too large for the tiled kernel, budget > 1: with one problem per wavefront slot a launch lasts
             // as long as its slowest wavefront, so the few per cent of problems that take a second step double it (round 3:
             // 2.0 ms for 2180 problem-iterations, 1.2 ms for the 2000 first ones).  Two launches instead: the one-wavefront
@@ -1407,10 +1425,8 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                                  nullptr, nullptr, h->gn_cnt, nullptr, u0_out, 4, nullptr, h->gn_list);
             if (e != hipSuccess) return FMPC_E_HIP;
             h->last_path = FMPC_PATH_WAVE;
-            const int last = ((volatile int*)h->gn_cnt_host)[1];       // list length an EARLIER call reported (never waited for)
-            const int hint = last >= 0 ? last + last / 2 + 16 : 0;
             const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_arr, status, iters, step,
-                                              u0_out, (hipStream_t)stream, h->small_nw, h->gn_list, h->gn_cnt + 1, nullptr, hint);
+                                              u0_out, (hipStream_t)stream, h->small_nw, h->gn_list, h->gn_cnt + 1, nullptr, gn_hint, &gplan);
             if (rc_t != FMPC_OK) return rc_t;
             if (hipMemcpyAsync(h->gn_cnt_host, h->gn_cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
             return FMPC_OK;

@@ -8,6 +8,7 @@
 #include "../../include/fastmpc.h"
 #include "fmpc_estimator.h"
 #include "fmpc_host.h"
+#include "fmpc_alloc.h"                    // counted hipMalloc / hipFree: the estimator's buffers move fmpc_alloc_generation too
 
 struct fmpc_est_s {
     int device, len, d, first, ndiv, nx, p, rank;

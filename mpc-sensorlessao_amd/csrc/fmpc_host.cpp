@@ -628,37 +628,6 @@ void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out) {
     }
     fmpc_host_mfma_a_images(Jn.data(), Out.nu_rows, imgn);
     Out.img.insert(Out.img.end(), imgn.begin(), imgn.end());
-    // ---- two-stage form (needs n + 1 <= 32 and n + 1 <= 4 FA2_KB; the launcher checks n = 27)
-    Out.imgJ.clear(); Out.imgX.clear(); Out.imgBw.clear();
-    if (n + 1 <= 4 * FA2_KB && n + 1 <= 32) {
-        std::vector<double> Je((size_t)32 * FA_KC), Xe((size_t)32 * FA_KC), im;
-        for (int st = 0; st < T; ++st) {
-            std::fill(Je.begin(), Je.end(), 0.0); std::fill(Xe.begin(), Xe.end(), 0.0);
-            for (int r = 0; r < n; ++r) {
-                for (int c = 0; c < nd; ++c) Je[(size_t)r * FA_KC + c] = In.J[((size_t)st * n + r) * ncJ + c];
-                Je[(size_t)r * FA_KC + nd] = In.nuc[(size_t)st * n + r];
-                for (int c = 0; c < FA_KC; ++c) Xe[(size_t)r * FA_KC + c] = Out.Kz[((size_t)st * s + m + r) * FA_KC + c];
-            }
-            Je[(size_t)n * FA_KC + nd] = 1.0;                     // nu+[n] = 1: carries the constant column of Bw
-            // (k-steps in PAIRS, [tile][q / 2][lane][q % 2]: one 16-byte load per lane brings two k-steps of its operand)
-            auto pairs = [&](const std::vector<double>& a, std::vector<double>& out) {
-                const size_t base = out.size();
-                out.resize(base + a.size());
-                for (int t = 0; t < 2; ++t)
-                    for (int q = 0; q < FA_KS; ++q)
-                        for (int l = 0; l < 64; ++l)
-                            out[base + (((size_t)t * (FA_KS / 2) + q / 2) * 64 + l) * 2 + (q & 1)] = a[((size_t)t * FA_KS + q) * 64 + l];
-            };
-            fmpc_host_mfma_a_images(Je.data(), 32, im); pairs(im, Out.imgJ);
-            fmpc_host_mfma_a_images(Xe.data(), 32, im); pairs(im, Out.imgX);
-        }
-        std::vector<double> Bw((size_t)m * (n + 1));
-        for (int j = 0; j < m; ++j) {
-            for (int r = 0; r < n; ++r) Bw[(size_t)j * (n + 1) + r] = (double)(wc[j] * (ld)In.bt[(size_t)j * n + r]);
-            Bw[(size_t)j * (n + 1) + n] = (double)((ld)In.umid[j] - wc[j] * cu[j]);
-        }
-        fmpc_host_mfma_images(Bw.data(), m, n + 1, FA2_KB, Out.imgBw);
-    }
 }
 
 int fmpc_host_estimator_gain(const double* A_s, int p, int nx, std::vector<double>& G) {

@@ -120,13 +120,7 @@ struct FmpcAffineOut {
     int nu_rows, nu_tiles;              // nb n rows of nu+ = nuc + J d, as further tiles behind those of z
     std::vector<double> Kz;             // rows x FA_KC row-major (checks)
     std::vector<double> img;            // matrix-core operand images: [tile][k-step][lane = 16 (k mod 4) + (row mod 16)], z tiles then nu tiles
-    // the same map in its TWO-STAGE form (fmpc_kernel_affine2.hip): per stage nu+_s = [J_s | nuc_s] d' (row n of the block: the
-    // constant 1), the x rows of the stage straight from Kz, and u_s = Bw [nu+_s ; 1] with Bw = [diag(wc) B' | umid - wc o cu]
-    std::vector<double> imgJ;           // [T][2 tiles][FA_KS / 2][64][2]  (k-steps in pairs per lane) rows 0 .. n-1: [J_s | nuc_s], row n: e_{2n} (the constant), rest zero
-    std::vector<double> imgX;           // [T][2 tiles][FA_KS / 2][64][2]  rows st s + m .. st s + m + n - 1 of Kz
-    std::vector<double> imgBw;          // [ceil(m / 16)][FA2_KB][64]  Bw (m x (n + 1)), k-steps of 4 columns
 };
-#define FA2_KB 7                        // k-steps of the second stage: n + 1 = 28 columns
 void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out);
 // operand images [tile][k-step][lane = 16 (k mod 4) + (row mod 16)] of a rows x cols row-major matrix, ks k-steps of 4 columns
 // (rows padded to tiles of 16, columns to 4 ks, with zeros)

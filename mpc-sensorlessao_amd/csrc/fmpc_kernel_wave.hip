@@ -175,8 +175,10 @@ struct FwParams {
     const double* rnp;              // per (panel, stage, problem): partial ||r_d||^2 at the new point (fmpc_cold_dz<true>)
     int* list;                      // problem index, bit 30 set = handed over (to be redone from scratch)
     int flags;                      // experiment switches (environment FMPC_WAVE_FLAGS); 0 in production
-    const int* nflag; int* nflag_zero;      // flag mode behind the affine kernel: *nflag = number of flagged problems (0: leave at once);
-                                    // *nflag_zero = 0 for the next call (two counters in turn)
+    int* nflag;                             // flag mode behind the affine kernel: nflag[0] = running count of the problems the affine kernel has
+                                    // flagged since the handle exists, nflag[1] = the count the last flag-mode launch has dealt with,
+                                    // nflag[2] = its ticket.  Equal counts: nothing new is flagged, leave at once (two scalar loads, no store).
+                                    // Nothing depends on the order of host calls, so a recorded graph replays it as it stands
     int u0_done;                    // panel path, first moves only: fmpc_cold_dz has written u0out itself (zout is a scratch
                                     // array that only the problems redone here touch)
 };
@@ -2162,9 +2164,12 @@ __global__ void __launch_bounds__(FW_THREADS, 2) fmpc_newton_wave(FwParams Pv) {
         if (!__syncthreads_or(need)) return;
     }
     if (pphase == 2 && nlist == 0) return;
-    if (pphase == 3 && P->nflag) {                   // behind the affine kernel: its own count of flagged problems, one scalar load
-        if (blockIdx.x == 0 && threadIdx.x == 0) *P->nflag_zero = 0;
-        if (*P->nflag == 0) return;
+    if (pphase == 3 && P->nflag) {                   // behind the affine kernel: has its running count of flagged problems moved?
+        const int cnt = P->nflag[0], seen = P->nflag[1];
+        if (cnt == seen) return;
+        // (rare) the workgroup that draws the last ticket has seen every workgroup read both counts: it brings `seen` up to date
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(P->nflag + 2, 1) == (int)gridDim.x - 1) { P->nflag[1] = cnt; P->nflag[2] = 0; }
     }
     if (pphase == 3) {                               // nothing flagged among this workgroup's problems (the usual case): leave
         int any = 0;
@@ -2413,12 +2418,12 @@ hipError_t fmpc_launch_wave(const FmpcDevModel& M, const FwModel& V, int batch, 
                             size_t ws_stride, size_t lds_bytes, hipStream_t stream,
                             int mode, double* sh_fac, double* sh_rs, int* sh_ok, const double* cold,
                             const double* gate, const double* epsp, int* handed, const double* nuws, double* u0out,
-                            int pphase, const double* rnp, int* list, int u0_done, const int* nflag, int* nflag_zero, int zld) {
+                            int pphase, const double* rnp, int* list, int u0_done, int* nflag, int zld) {
     if (M.n != 27) return hipErrorInvalidValue;
     FwParams P;
     P.zld = zld > 0 ? zld : M.T * (M.n + M.m);
     P.gate = gate; P.epsp = epsp; P.handed = handed; P.nuws = nuws; P.u0out = u0out;
-    P.pphase = pphase; P.rnp = rnp; P.list = list; P.u0_done = u0_done; P.nflag = nflag; P.nflag_zero = nflag_zero;
+    P.pphase = pphase; P.rnp = rnp; P.list = list; P.u0_done = u0_done; P.nflag = nflag;
     static const int env_flags = [] { const char* e = getenv("FMPC_WAVE_FLAGS"); return e && e[0] ? atoi(e) : 0; }();
     P.flags = env_flags;
     if (pphase == 1) lds_bytes = 0;                  // the decide-only launch touches no LDS: cheap to place

@@ -16,6 +16,7 @@ class RecordedSolves:
         import gc
         import torch
         self._lib = _lib.load()
+        self._record_fn = record_fn           # (keeps the tensors the closure refers to alive: the graph holds their addresses)
         record_fn()
         torch.cuda.synchronize()
         self._stream = torch.cuda.Stream()

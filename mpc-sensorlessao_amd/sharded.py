@@ -19,14 +19,17 @@ class ShardedFastMPC:
     device.  On a GPU rank this is `FastMPCHandle.solve_device`; CPU gloo tests inject a checker.
     """
 
-    def __init__(self, solve_fn, nz, m, T, n, group=None, solve_u0_fn=None):
+    def __init__(self, solve_fn, nz, m, T, n, group=None, solve_u0_fn=None, always_collective=False):
+        # always_collective: issue the all-gather also in a group of ONE rank (a 1-rank RCCL group on a one-GPU box runs the very
+        # branch 8 ranks run: tests/test_gpu_nccl_one_rank.py); by default a single rank returns its rows without a collective
+        self.always_collective = bool(always_collective)
         self.solve_fn = solve_fn
         self.solve_u0_fn = solve_u0_fn     # optional: (x0, x0_pre, w, nu0, n_newton, k) -> first moves (local_batch, m) only
         self.nz, self.m, self.T, self.n = nz, m, T, n
         self.group = group
 
     @classmethod
-    def from_handle(cls, handle, group=None):
+    def from_handle(cls, handle, group=None, always_collective=False):
         """The production wiring: every rank solves its block with its own `FastMPCHandle.solve_device` (HIP kernels on
         the rank's GPU, asynchronous on torch's current stream)."""
         def solve_fn(x0, x0_pre, w, nu0, n_newton, k):
@@ -36,7 +39,7 @@ class ShardedFastMPC:
             u0 = x0.new_empty((x0.shape[0], handle.m))
             handle.solve_device(x0, x0_pre, w, None, nu0, n_newton, k, u0_out=u0, want_z=False)
             return u0
-        return cls(solve_fn, handle.nz, handle.m, handle.T, handle.n, group, solve_u0_fn)
+        return cls(solve_fn, handle.nz, handle.m, handle.T, handle.n, group, solve_u0_fn, always_collective)
 
     def _dist(self):
         import torch.distributed as dist
@@ -70,7 +73,7 @@ class ShardedFastMPC:
         elif what == "U":
             local = local.reshape(local.shape[0], self.T, self.n + self.m)[:, :, :self.m] \
                          .reshape(local.shape[0], self.T * self.m).contiguous()
-        if ws == 1:
+        if ws == 1 and not (self.always_collective and dist is not None):
             return local
         per = -(-batch // ws)
         cols = local.shape[1]

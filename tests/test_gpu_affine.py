@@ -50,6 +50,8 @@ def _handles(pkg, md):
     (2, 33, False, True, 2),         # the horizon the README itself runs (README.md:338): 342 rows of z
     (1, 5, True, True, 2),
     (7, 130, False, True, 2),
+    (8, 70, False, False, 2),        # no free slot: the decision forms in workgroups of their own
+    (9, 33, False, True, 2), (11, 17, False, False, 2), (2, 40, False, True, 2),
 ])
 def test_affine_form_matches_oracle_and_the_three_kernel_form(pkg, gpu, T, batch, xf, use_nu, var_order):
     md = pkg.synthetic.make_model(27, 144, T, var_order=var_order)
@@ -142,53 +144,6 @@ def test_affine_form_at_the_headline_size(pkg, gpu):
     zo, *_ = oracle_batch(md, sub, 1, 1e-2)
     assert max(rel_err(za[p], zo[q]) for q, p in enumerate(pick)) <= 1e-9
     h.close(); h3.close()
-
-
-@pytest.mark.parametrize("T,batch,xf,var_order,tight", [
-    (30, 2000, False, 2, False),      # the headline shape: 32 groups x 8 quads, decision forms in the last quad's free wavefronts
-    (30, 1, False, 2, False),
-    (30, 65, True, 2, False),         # terminal row; one problem into the second group
-    (10, 130, False, 1, False),       # VAR(1): x0_pre = NULL; 3 quads, two free slots
-    (8, 70, False, 2, False),         # no free slot: the decision forms in workgroups of their own
-    (9, 33, False, 2, False), (11, 17, False, 2, False), (1, 5, True, 2, False), (2, 40, False, 2, False),
-    (10, 70, False, 2, True),         # tight bounds: problems flagged and redone by the exact path
-])
-def test_two_stage_affine_form_opt_in(pkg, gpu, T, batch, xf, var_order, tight):
-    """fmpc_kernel_affine2.hip (FMPC_AFFINE2=1): the same affine map as nu+_s = J_s d, u_s = Bw nu+_s per stage and the x rows
-    directly -- an independent evaluation of the step on the device.  Against the one-product form (1e-11 on z; identical
-    status, iteration counts, step lengths, first moves = z[:, :m]) and the oracle (1e-9)."""
-    md = pkg.synthetic.make_model(27, 144, T, var_order=var_order)
-    rng = np.random.default_rng(6)
-    if xf:
-        md["xf"] = 0.01 * rng.standard_normal(27)
-    if tight:
-        md["u_min"] = -0.24 * np.ones(144); md["u_max"] = 0.24 * np.ones(144)
-    data = pkg.synthetic.make_replay_batch(md, r=6, steps=batch)
-    if tight:
-        data["x0"] = data["x0"] * np.linspace(0.05, 5.0, batch)[:, None]
-        data["x0_pre"] = data["x0_pre"] * np.linspace(0.05, 5.0, batch)[:, None]
-    data["w"] = None
-    data["nu0"] = rng.standard_normal((batch, (T + (1 if xf else 0)) * 27))
-    if var_order == 1:
-        data["x0_pre"] = None
-    h = handle_from_model(pkg, md)
-    z1, u1, s1, i1, t1 = _solve_dev(pkg, h, data)
-    assert h.last_dual_form() == 2
-    os.environ["FMPC_AFFINE2"] = "1"; os.environ["FMPC_AFFINE2_MIN_BATCH"] = "1"
-    try:
-        z2, u2, s2, i2, t2 = _solve_dev(pkg, h, data)
-    finally:
-        os.environ.pop("FMPC_AFFINE2"); os.environ.pop("FMPC_AFFINE2_MIN_BATCH")
-    assert h.last_dual_form() == 2
-    assert np.array_equal(s1, s2) and np.array_equal(i1, i2) and np.array_equal(t1, t2)
-    assert np.all(np.isfinite(z2)) and np.array_equal(u2, z2[:, :144])
-    assert max(rel_err(z2[p], z1[p]) for p in range(batch)) <= 1e-11
-    nchk = min(batch, 6)
-    sub = {k: (v[:nchk] if v is not None else None) for k, v in data.items()}
-    zo, _, ito, sto, steps = oracle_batch(md, sub, 1, 1e-2)
-    assert np.array_equal(i2[:nchk], ito) and np.array_equal(s2[:nchk], sto)
-    assert max(rel_err(z2[p], zo[p]) for p in range(nchk)) <= 1e-9
-    h.close()
 
 
 @pytest.mark.parametrize("ldz_extra,batch,tight", [(6, 2000, None), (6, 37, None), (1, 70, None), (6, 70, 0.05), (70, 70, 0.05), (22, 200, 0.15), (1, 200, 0.1)])
