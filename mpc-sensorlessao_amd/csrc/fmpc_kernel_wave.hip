@@ -81,24 +81,19 @@ struct FwCfg {
     static constexpr int LPACK = (N * (N + 1) / 2 + 1) & ~1;
     __host__ __device__ static constexpr int LOFF(int j) { return j * N - j * (j - 1) / 2; }
     static constexpr int TILE = 32 * LD;
-    // Factor stream of a stage, round 4: the wave's two LDS tiles -- U1 | y as [row j][column c], then L as [row r][column j],
-    // leading dimension LD -- dumped LINEARLY, 16 bytes per lane per instruction (DUMP doubles each: N rows rounded up to whole
-    // wave instructions of 128 doubles).  7 + 7 instructions of 1 KB per stage where the packed form took 27 + 27 of 216 bytes:
-    // a CU's load / store path takes a wave instruction every 12-17 cycles whatever its width (scripts/probes/vmem_issue_rate.hip).
+    // Factor stream of a stage: the wave's LDS tile U1 | y as [row j][column c], leading dimension LD, and the strict lower triangle
+    // of L FOLDED into (N + 1) / 2 rows of LDF doubles, both dumped LINEARLY, 16 bytes per lane per instruction: 7 + 3 instructions
+    // of 1 KB per stage (10 KB; round 4 dumped the full L tile: 7 + 7; round 3's packed form took 27 + 27 instructions of 216
+    // bytes).  A CU's load / store path takes a wave instruction every 12-17 cycles whatever its width
+    // (scripts/probes/vmem_issue_rate.hip).  DUMP doubles: N rows rounded up to whole wave instructions of 128 doubles.
     static constexpr int DUMP = ((N * LD + 127) / 128) * 128;
-    // L: only its strictly lower triangle is streamed, FOLDED -- rows r and N - 1 - r share a tile row of N - 1 entries (row
-    // min(r, N-1-r) of the folded tile: the shorter of the two first) -- LDF doubles per folded row, (N + 1) / 2 rows
-#ifndef FW_LFOLD                                                    // L as a full [row][column] tile, 14 KB per stage.  (FW_LFOLD: only the strict
-                                                                    // lower triangle, folded, 10 KB: measured SLOWER -- the address selects of
-                                                                    // its LDS writes cost the factor phase more than the bytes save)
-    static constexpr int LDF = LD;
-    static constexpr int LFOLD = DUMP;
-    __host__ __device__ static constexpr int LBASE(int r) { return r * LD; }
-#else
+    // The fold: rows r and N - 1 - r share a folded row of N - 1 entries (row min(r, N-1-r): the shorter of the two first).
+    // Written without selects or per-entry predicates (fw_phase_factor: every lane writes its whole row in DESCENDING order, what
+    // falls on another row's slots is overwritten by their owner afterwards); read back with per-lane bases and compile-time
+    // offsets (LBASE).  -4 % launch time, -0.5 GB of traffic per 2000-problem launch against the full tile (round 5)
     static constexpr int LDF = N;                                   // (odd)
     static constexpr int LFOLD = (((N + 1) / 2 * LDF) + 127) / 128 * 128;
     __host__ __device__ static constexpr int LBASE(int r) { return (r <= (N - 1) / 2 ? r * LDF : (N - 1 - r) * LDF + (N - 1 - r)); }
-#endif
     static constexpr int FST = DUMP + LFOLD;
     static_assert(DUMP <= TILE && LFOLD <= TILE, "the dumps must stay inside a tile");
     static constexpr int PER_WAVE = 2 * TILE;                 // tA, tB
@@ -1363,53 +1358,6 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             if (lane == 0) myrs = rs;
             colb[lane] = lk;
         }
-#ifdef FW_BCAST128
-        // Column k of L from LDS as ALIGNED 16-byte pieces (ds_read_b128, one address for all lanes: 4 LDS cycles per two
-        // entries where ds_read2_b64 takes 8 -- the eight wavefronts of a CU factor in lock-step and the broadcasts of the
-        // column were most of the LDS pipe's time, scripts/probes/dp_valu_rate.hip): the pieces start at the even index
-        // (k + 1) & ~1, an entry in front of column k's first sub-diagonal one is read and not used.
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            fw_wave_fence();
-            const fw_c2lds_t cb2 = (fw_c2lds_t)(colb + (k & 1) * 64);  // L[c][k]: one address for all lanes
-            constexpr int CP = CH / 2;
-            const int clo = (k + 1) & ~1;                              // (compile-time: the loop is unrolled)
-            d2v lc2[CP];
-#pragma unroll
-            for (int q = 0; q < CP; ++q) lc2[q] = cb2[(clo + 2 * q < N ? clo + 2 * q : (N - 1) & ~1) >> 1];
-            double lkn = 0.0, xkn = 0.0;
-            if (k + 1 < N) {
-                const double l1 = fw_readlane(lk, k + 1);
-                row[k + 1] = fma(-lk, l1, row[k + 1]);
-                x[k + 1] = fma(-l1, xk, x[k + 1]);
-                const double d = fw_readlane(row[k + 1], k + 1);
-                if (!(d > 0.0) || isinf(d)) notpd = 1;
-                const double rs = fw_rsqrt(d);
-                lkn = row[k + 1] * rs; xkn = x[k + 1] * rs;
-                row[k + 1] = lkn; x[k + 1] = xkn;
-                if (lane == k + 1) myrs = rs;
-                colb[((k + 1) & 1) * 64 + lane] = lkn;
-            }
-#pragma unroll
-            for (int c0 = clo; c0 < N; c0 += CH) {
-                d2v ln2[CP];
-                if (c0 + CH < N) {
-#pragma unroll
-                    for (int q = 0; q < CP; ++q) ln2[q] = cb2[(c0 + CH + 2 * q < N ? c0 + CH + 2 * q : (N - 1) & ~1) >> 1];
-                }
-#pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int c = c0 + q;
-                    const double lcq = (q & 1) ? lc2[q >> 1].y : lc2[q >> 1].x;
-                    if (c > k + 1 && c < N) { row[c] = fma(-lk, lcq, row[c]); x[c] = fma(-lcq, xk, x[c]); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < CP; ++q) lc2[q] = ln2[q];
-            }
-            lk = lkn; xk = xkn;
-        }
-#else
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             fw_wave_fence();
@@ -1451,7 +1399,6 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             }
             lk = lkn; xk = xkn;
         }
-#endif
         fw_wave_fence();
         FW_TICK(2);
         // ---- results: U1|y -> tB, U2|y -> tA (layout change) and the factor to HBM
@@ -1535,19 +1482,20 @@ FW_IN int fw_phase_factor(FwKP Pin, int p, double* lds_g, int first) {
             {
                 // lane r: L[r][j], j < r, to its half of a folded row; entries on and above the diagonal, and the lanes beyond
                 // N, go to a per-lane parking slot behind the folded rows (an address select: no branch, no store under a condition)
-#ifndef FW_LFOLD
-                if (lane < N) {
-                    const fw_lds_t pr = tA + lane * LD;
+                // No select and no per-entry predicate: every lane 1 .. N-1 writes ALL its N - 1 entries at base + j, j DESCENDING.
+                // What a lane writes beyond its own r entries lands on another row's slots, and always on one whose owner writes
+                // it at a SMALLER j, i.e. later: a small row r (base r LDF) spills over the slots of its partner N-1-r, which writes
+                // slot c at j = c - r < c; a big row rho (base (N-1-rho)(LDF + 1)) spills into column N-1 (nobody's) and the head of
+                // the next folded row, written by small row N-rho at j - rho - 1 < j.  Row 0 has no entries: its lane stays out
+                // (its spill would meet row N-1's slots in the SAME instruction).  A wavefront's LDS writes keep their order.
+                if (lane >= 1 && lane < N) {
+                    // (hand-issued: the compiler would pair the stores into ds_write2_b64 with the LOWER slot first, and is free to
+                    //  reorder stores that cannot alias within a lane -- the order across lanes is what counts here)
+                    const unsigned pr = (unsigned)(size_t)(tA + (lane <= (N - 1) / 2 ? lane * C::LDF : (N - 1 - lane) * C::LDF + (N - 1 - lane)));
 #pragma unroll
-                    for (int j = 0; j < N - 1; ++j) pr[j] = row[j];
+                    for (int j = N - 2; j >= 0; --j)
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(pr), "v"(row[j]), "n"(8 * j) : "memory");
                 }
-#else
-                const int rr = lane < N ? lane : N - 1;
-                const int lbase = rr <= (N - 1) / 2 ? rr * C::LDF : (N - 1 - rr) * C::LDF + (N - 1 - rr);
-                const int park = C::LFOLD + lane;
-#pragma unroll
-                for (int j = 0; j < N - 1; ++j) tA[(j < lane && lane < N) ? lbase + j : park] = row[j];
-#endif
             }
 #pragma unroll
             for (int q = 0; q < C::DUMP / 128; ++q) f2[q * 64] = du[q];
@@ -1593,44 +1541,26 @@ FW_IN void fw_phase_backward_dump(FwKP Pin, int p, double* lds_g) {
     typedef __attribute__((address_space(3))) d2v* fw_2lds_t;
     const fw_2lds_t tA2 = (fw_2lds_t)tA + lane, tB2 = (fw_2lds_t)tB + lane;
     const int lr = lane < N ? lane : N - 1;
-#ifndef FW_LFOLD
-    const int lbase = lr * LD;
-#else
     const int lbase = lr <= (N - 1) / 2 ? lr * C::LDF : (N - 1 - lr) * C::LDF + (N - 1 - lr);       // this lane's row of L in the folded tile
-#endif
     const double* facp = W.fac;
     const double* rsp = W.rsg;
     const double* imgs = P->V.img + C::IMG_D + C::IMG_1;       // [block][row j][col c] copies of the constant blocks
     double x1 = 0.0, x2 = 0.0;        // lane j: d_nu_{i+1}[j], d_nu_{i+2}[j]
-    // FW_BWD2: two stages in flight, (du, dl) = the stage about to be used, (du2, dl2) = the one behind it -- with the full L tile
-    // the second register set spills inside the loop (backward sweep 2 x slower, measured); default: one stage in flight
-#ifdef FW_BWD2
-    constexpr int DEPTH = 2;
-#else
-    constexpr int DEPTH = 1;
-#endif
-    d2v du[NQ], dl[NL], du2[DEPTH == 2 ? NQ : 1], dl2[DEPTH == 2 ? NL : 1];
-    double y2[N], yv_n, rs_n, yv_n2, rs_n2;
+    // one stage in flight: (du, dl) = the dumps of the stage about to be used (two in flight spilled: docs/DESIGN_HISTORY.md)
+    d2v du[NQ], dl[NL];
+    double y2[N], yv_n, rs_n;
     int cur2 = -1;                    // block whose rows are in y2
     {
-        const int i = W.nb - 1, i2 = W.nb >= 2 ? W.nb - 2 : 0;
+        const int i = W.nb - 1;
         const d2v* f2 = (const d2v*)(facp + (size_t)i * W.fstride) + lane;
-        const d2v* g2 = (const d2v*)(facp + (size_t)i2 * W.fstride) + lane;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) du[q] = f2[q * 64];
 #pragma unroll
         for (int q = 0; q < NL; ++q) dl[q] = f2[(NQ + q) * 64];
         yv_n = W.yv[i * N + lr]; rs_n = rsp[i * 32 + lr];
-        if (DEPTH == 2) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) du2[q] = g2[q * 64];
-#pragma unroll
-            for (int q = 0; q < NL; ++q) dl2[q] = g2[(NQ + q) * 64];
-            yv_n2 = W.yv[i2 * N + lr]; rs_n2 = rsp[i2 * 32 + lr];
-        } else { yv_n2 = 0.0; rs_n2 = 0.0; }
     }
     for (int i = W.nb - 1; i >= 0; --i) {
-        const int ip = i >= DEPTH ? i - DEPTH : 0;             // stage to request now: DEPTH ahead (harmless re-reads at the end)
+        const int ip = i >= 1 ? i - 1 : 0;                     // stage to request now (a harmless re-read at the end)
         double v = yv_n;
         const double rsv = rs_n;
         const int b2 = P->V.i2[i];
@@ -1645,25 +1575,15 @@ FW_IN void fw_phase_backward_dump(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int q = 0; q < NL; ++q) tB2[q * 64] = dl[q];
         fw_wave_fence();
-        // [rotate and] request the stage DEPTH ahead into the registers that have just been written out
-        if (DEPTH == 2) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) du[q] = du2[q];
-#pragma unroll
-            for (int q = 0; q < NL; ++q) dl[q] = dl2[q];
-            yv_n = yv_n2; rs_n = rs_n2;
-        }
-#ifndef FW_KO_BWD_LOADS
+        // request the next stage into the registers that have just been written out
         {
             const d2v* f2 = (const d2v*)(facp + (size_t)ip * W.fstride) + lane;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { if (DEPTH == 2) du2[q] = f2[q * 64]; else du[q] = f2[q * 64]; }
+            for (int q = 0; q < NQ; ++q) du[q] = f2[q * 64];
 #pragma unroll
-            for (int q = 0; q < NL; ++q) { if (DEPTH == 2) dl2[q] = f2[(NQ + q) * 64]; else dl[q] = f2[(NQ + q) * 64]; }
+            for (int q = 0; q < NL; ++q) dl[q] = f2[(NQ + q) * 64];
         }
-#endif
-        if (DEPTH == 2) { yv_n2 = W.yv[ip * N + lr]; rs_n2 = rsp[ip * 32 + lr]; }
-        else { yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr]; }
+        yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
         double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
         {
             const fw_clds_t r1 = tA + lr * LD;
@@ -1757,10 +1677,8 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int j = 0; j < N; ++j) tA[j * LD + lc] = g1[j];
         fw_wave_fence();
-#ifndef FW_KO_BWD_LOADS
 #pragma unroll
         for (int j = 0; j < N; ++j) g1[j] = fp[u1o + j * LDG];
-#endif
         yv_n = W.yv[ip * N + lr]; rs_n = rsp[ip * 32 + lr];
         double cc = 0.0;                                       // (Y_{i,i+2} d_nu_{i+2})[lr]
         {
@@ -1775,13 +1693,8 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
         // forward substitution  w = L^-1 cc  (lane r holds row r of L in gl: gl[k] = L[r][k]);  v -= w
         {
             double wres = 0.0;
-#ifdef FW_KO_BWD_CHAIN
-#pragma unroll
-            for (int k = 0; k < 1; ++k) {
-#else
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-#endif
                 const double wk = fw_readlane(cc * rsv, k);
                 if (lane == k) wres = wk;
                 cc = fma(-gl[k], wk, cc);          // meaningful on lanes > k only
@@ -1793,20 +1706,13 @@ FW_IN void fw_phase_backward(FwKP Pin, int p, double* lds_g) {
 #pragma unroll
         for (int j = 0; j < N; ++j) tB[j * LD + lc] = gl[j];
         fw_wave_fence();
-#ifndef FW_KO_BWD_LOADS
 #pragma unroll
         for (int j = 0; j < N; ++j) gl[j] = fp[(ex ? j * LDG : C::LOFF(j) - j) + lo];      // (lanes above the diagonal read the tail of an earlier column: unused)
-#endif
         double res = 0.0;
         {
             const fw_clds_t cl = tB + lr * LD;
-#ifdef FW_KO_BWD_CHAIN
-#pragma unroll
-            for (int r = N - 1; r >= N - 1; --r) {
-#else
 #pragma unroll
             for (int r = N - 1; r >= 0; --r) {
-#endif
                 const double xr = fw_readlane(v * rsv, r);
                 if (lane == r) res = xr;
                 v = fma(-cl[r], xr, v);        // meaningful on lanes < r only
