@@ -270,6 +270,14 @@ int fmpc_loop_run_device(fmpc_handle h, int batch, int steps, const double* a, c
  * fmpc_solve[_device] with the extra per-problem input u_prev (m x batch).  The rows couple consecutive stages, so
  * Y = C Phi^-1 C' is dense across the horizon: this path factors a dense (T n)^2 matrix per problem and Newton
  * step (fmpc_kernel_ramp.hip); it needs diagonal Q, R, Qf like the other device paths.
+ * From the COLD START (z_init == NULL, the reference loop's call: Fast_MPC2(..., x_init = []).mpc_fixed_log_newton(1, k))
+ * only the ramp rows of stage 0 (u_0 - u_prev) depend on the problem -- every other ramp slack u_j - u_{j-1} is zero at the
+ * mid-box start -- so the KKT matrix of the first Newton step is a CONSTANT matrix plus a diagonal term on the m entries of u_0,
+ * and the step costs one m x m Cholesky factorisation per problem and two passes through constant operators built once per
+ * (handle, k, bounds) on the host (Woodbury form, fmpc_ramp_cold; fmpc_last_dual_form = 5): 0.8 instead of 18.7 MFLOP at
+ * (27, 144, 10).  A budget n_newton > 1 continues with the dense factorisation from the iterate that step leaves.  Same
+ * results to rounding (tests/test_gpu_ramp.py: both forms against the dense oracle); FMPC_NO_RAMP_COLD=1 at create time keeps
+ * the general path.
  * FMPC_E_UNSUPPORTED: fmpc_set_ramp has not been called (or n > 64).
  */
 int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* du_max);

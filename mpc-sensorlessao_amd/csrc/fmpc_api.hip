@@ -17,6 +17,7 @@
 #include "fmpc_affine.h"
 #include "fmpc_loopu0.h"
 #include "fmpc_tiled.h"
+#include "fmpc_rampcold.h"
 #define FMPC_PRODUCT_MIN_BATCH_DEFAULT 65   // closed-loop steps with first moves only: the product form from this many realisations on
 #include "fmpc_alloc.h"                    // counted hipMalloc / hipFree (fmpc_alloc_generation), shared with fmpc_est_api.hip
 
@@ -35,7 +36,7 @@ hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const do
                             const double* x0, const double* x0p, const double* w, const double* uprev,
                             const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
                             double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
-                            size_t ws_stride, int threads, hipStream_t stream);
+                            size_t ws_stride, int threads, hipStream_t stream, int it0 = 0);
 hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const double* x0,
                                const double* x0p, const double* w, const double* zinit,
                                const double* nu0, int max_iter, double kbar, double* zout,
@@ -156,6 +157,12 @@ struct fmpc_handle_s {
     // ramp-rate rows (VAR_1): bounds on the device, own workspace (dense Y per workgroup)
     double* ramp_du;             // [du_min | du_max], 2 m doubles; nullptr until fmpc_set_ramp
     double* ramp_ws; size_t ramp_ws_doubles;
+    // cold-start step with the ramp rows in its Woodbury form (fmpc_ramp_cold): constants per (handle, k, ramp bounds)
+    std::vector<double> hm_dumin, hm_dumax;
+    int rc_disabled, rc_valid, rc_failed, rc_last; double rc_k, rc_failed_k;
+    double* rc_pool; FrColdParams rc_P;
+    double* rc_ws; size_t rc_ws_doubles;
+    double* rc_nu; int* rc_si; size_t rc_cap;     // nu / status / iters of the first step when the caller passes none (budgets > 1)
     // A handle's device workspaces serve ONE solve at a time.  Solves enqueued on different streams are ordered on
     // the device: every solve records `ev`, and a solve on another stream than the last one waits for it first.
     hipEvent_t ev; int ev_valid; hipStream_t last_stream;
@@ -311,6 +318,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
     h->pin = nullptr; h->pin_bytes = 0;
     h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
+    { const char* e = getenv("FMPC_NO_RAMP_COLD"); h->rc_disabled = (e && e[0] == '1') ? 1 : 0; }
+    h->rc_valid = 0; h->rc_failed = 0; h->rc_last = 0; h->rc_k = 0.0; h->rc_failed_k = 0.0; h->rc_pool = nullptr;
+    h->rc_ws = nullptr; h->rc_ws_doubles = 0; h->rc_nu = nullptr; h->rc_si = nullptr; h->rc_cap = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
     h->generic_ok = generic_ok ? 1 : 0;
     h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
@@ -458,6 +468,13 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
     h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
     h->hm_a1f = a1; h->hm_a2f = a2;
+    // (always kept: the cold-start form of the ramp path is built from them for any n, fmpc_ensure_ramp_cold)
+    h->hm_R2 = R2; h->hm_rl.assign(m, 0.0); if (r) h->hm_rl.assign(r, r + m);
+    h->hm_umin.assign(u_min, u_min + m); h->hm_umax.assign(u_max, u_max + m); h->hm_umid = umid; h->hm_xmid = xmid;
+    h->hm_Q2 = Q2; h->hm_Qf2 = Qf2;
+    h->hm_ql.assign(n, 0.0); if (q) h->hm_ql.assign(q, q + n);
+    h->hm_qfl.assign(n, 0.0); if (qf) h->hm_qfl.assign(qf, qf + n);
+    h->hm_xf.clear(); if (xf) h->hm_xf.assign(xf, xf + n);
     h->denseR = denseR ? 1 : 0; h->hm_r2full = R2full;
     h->denseQ = denseQ ? 1 : 0; h->hm_q2m = Q2m; h->hm_qf2m = Qf2m; h->hm_xm = X; h->hm_xfm = Xf;
     h->hm_b.resize((size_t)n * m);
@@ -616,6 +633,10 @@ extern "C" int fmpc_destroy(fmpc_handle h) {
     if (h->ev) (void)hipEventDestroy(h->ev);
     if (h->ramp_du) (void)hipFree(h->ramp_du);
     if (h->ramp_ws) (void)hipFree(h->ramp_ws);
+    if (h->rc_pool) (void)hipFree(h->rc_pool);
+    if (h->rc_ws) (void)hipFree(h->rc_ws);
+    if (h->rc_nu) (void)hipFree(h->rc_nu);
+    if (h->rc_si) (void)hipFree(h->rc_si);
     if (h->ws) (void)hipFree(h->ws);
     if (h->zs) (void)hipFree(h->zs);
     if (h->stage) (void)hipFree(h->stage);
@@ -1881,6 +1902,7 @@ extern "C" int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled) {
 extern "C" int fmpc_last_dual_form(fmpc_handle h) {
     if (!h) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->last_path == FMPC_PATH_RAMP) return h->rc_last ? 5 : 0;     // 5: the cold-start step with ramp rows in its Woodbury form
     return h->last_path == FMPC_PATH_PANEL ? h->inv_last : 0;
 }
 
@@ -1926,6 +1948,46 @@ extern "C" int fmpc_set_ramp(fmpc_handle h, const double* du_min, const double* 
     }
     if (hipMemcpy(h->ramp_du, du_min, h->m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->ramp_du + h->m, du_max, h->m * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    h->hm_dumin.assign(du_min, du_min + h->m); h->hm_dumax.assign(du_max, du_max + h->m);
+    h->rc_valid = 0; h->rc_failed = 0;                              // (the constants of the cold-start form depend on the bounds)
+    return FMPC_OK;
+}
+
+// Constants of the cold-start step's Woodbury form for barrier weight k (fmpc_host_build_ramp_cold): built on the host in long
+// double on first use of a k, uploaded as one pool.  FMPC_E_UNSUPPORTED: the general path takes the solve (LDS, a start point
+// at which Phibar or Ybar is not positive definite, FMPC_NO_RAMP_COLD=1).  Caller holds h->mu.
+static int fmpc_ensure_ramp_cold(fmpc_handle h, double k) {
+    if (h->rc_disabled) return FMPC_E_UNSUPPORTED;
+    if (h->rc_valid && h->rc_k == k) return FMPC_OK;
+    if (h->rc_failed && h->rc_failed_k == k) return FMPC_E_UNSUPPORTED;
+    const size_t lds = fmpc_ramp_cold_lds_bytes(h->n, h->m, h->T, h->nb);
+    if (lds > FMPC_LDS_LIMIT || h->n > 64) return FMPC_E_UNSUPPORTED;
+    FmpcRampColdIn In;
+    In.n = h->n; In.m = h->m; In.T = h->T; In.nb = h->nb; In.var2 = h->var_order == 2 ? 1 : 0; In.has_xf = h->has_xf;
+    In.bt = h->hm_bt.data(); In.a1 = h->hm_a1f.data(); In.a2 = h->hm_a2f.data();
+    In.umax = h->hm_umax.data(); In.umin = h->hm_umin.data(); In.umid = h->hm_umid.data(); In.xmid = h->hm_xmid.data();
+    In.R2 = h->hm_R2.data(); In.rl = h->hm_rl.data(); In.Q2 = h->hm_Q2.data(); In.Qf2 = h->hm_Qf2.data(); In.ql = h->hm_ql.data();
+    In.qfl = h->hm_qfl.data(); In.xf = h->hm_xf.data(); In.dumin = h->hm_dumin.data(); In.dumax = h->hm_dumax.data(); In.k = k;
+    FmpcRampColdOut O;
+    fmpc_host_build_ramp_cold(In, O);
+    if (!O.valid) { h->rc_failed = 1; h->rc_failed_k = k; return FMPC_E_UNSUPPORTED; }
+    std::vector<double> pool;
+    auto push = [&](const std::vector<double>& v) { const size_t o = pool.size(); pool.insert(pool.end(), v.begin(), v.end()); if (pool.size() & 1) pool.push_back(0.0); return o; };
+    const size_t o_g0 = push(O.g0), o_Gf = push(O.Gf), o_pu = push(O.phib_u), o_px = push(O.phib_x), o_gu = push(O.gbar_u), o_gx = push(O.gbar_x),
+                 o_hd = push(O.hd), o_er = push(O.erb), o_cp = push(O.cpb), o_bb = push(O.betab), o_Yi = push(O.Yinv), o_G = push(O.G),
+                 o_Xi = push(O.Xiu0t), o_y0 = push(O.y0c);
+    if (h->rc_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->rc_pool); h->rc_pool = nullptr; }
+    h->rc_valid = 0;
+    if (hipMalloc((void**)&h->rc_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+    if (hipMemcpy(h->rc_pool, pool.data(), pool.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FMPC_E_HIP;
+    if (fmpc_ramp_cold_prepare(lds) != hipSuccess) return FMPC_E_HIP;
+    FrColdParams& P = h->rc_P;
+    memset(&P, 0, sizeof(P));
+    P.M = h->dev; P.dumin = h->ramp_du; P.dumax = h->ramp_du + h->m; P.kbar = k;
+    P.g0 = h->rc_pool + o_g0; P.Gf = h->rc_pool + o_Gf; P.phib_u = h->rc_pool + o_pu; P.phib_x = h->rc_pool + o_px; P.gbar_u = h->rc_pool + o_gu;
+    P.gbar_x = h->rc_pool + o_gx; P.hd = h->rc_pool + o_hd; P.erb = h->rc_pool + o_er; P.cpb = h->rc_pool + o_cp; P.betab = h->rc_pool + o_bb;
+    P.Yinv = h->rc_pool + o_Yi; P.G = h->rc_pool + o_G; P.Xiu0t = h->rc_pool + o_Xi; P.y0c = h->rc_pool + o_y0;
+    h->rc_valid = 1; h->rc_k = k;
     return FMPC_OK;
 }
 
@@ -1953,13 +2015,65 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
     if ((size_t)cap * stride > budget) cap = (int)(budget / stride);
     if (cap < 1) return FMPC_E_ALLOC;
     const int grid = batch < cap ? batch : cap;
-    const size_t need = stride * (size_t)grid;
-    if (need > h->ramp_ws_doubles) {
-        if (h->ramp_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ramp_ws); h->ramp_ws = nullptr; h->ramp_ws_doubles = 0; }
-        if (hipMalloc((void**)&h->ramp_ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
-        h->ramp_ws_doubles = need;
-    }
+    auto ensure_general_ws = [&]() -> int {                          // (the cold-start form with a budget of 1 never needs it)
+        const size_t need = stride * (size_t)grid;
+        if (need > h->ramp_ws_doubles) {
+            if (h->ramp_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->ramp_ws); h->ramp_ws = nullptr; h->ramp_ws_doubles = 0; }
+            if (hipMalloc((void**)&h->ramp_ws, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+            h->ramp_ws_doubles = need;
+        }
+        return FMPC_OK;
+    };
     h->last_path = FMPC_PATH_RAMP;
+    h->rc_last = 0;
+    // Cold start: the first Newton step in its Woodbury form (one m x m factorisation per problem, fmpc_ramp_cold); a budget > 1
+    // continues with the general kernel from the iterate that step leaves (it0 = 1).
+    if (z_init == nullptr) {
+        const int rcc = fmpc_ensure_ramp_cold(h, k);
+        if (rcc != FMPC_OK && rcc != FMPC_E_UNSUPPORTED) return rcc;
+        if (rcc == FMPC_OK) {
+            const size_t cstride = fmpc_ramp_cold_ws_doubles(h->m);
+            const int cgrid = batch < h->num_cu ? batch : h->num_cu;
+            if (cstride * (size_t)cgrid > h->rc_ws_doubles) {
+                if (h->rc_ws) { (void)hipDeviceSynchronize(); (void)hipFree(h->rc_ws); h->rc_ws = nullptr; h->rc_ws_doubles = 0; }
+                size_t want = cstride * (size_t)(batch < h->num_cu ? (batch < 16 ? 16 : batch) : h->num_cu);
+                if (want > cstride * (size_t)h->num_cu) want = cstride * (size_t)h->num_cu;
+                if (hipMalloc((void**)&h->rc_ws, want * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                h->rc_ws_doubles = want;
+            }
+            double* nu_first = nu_out;
+            int* st_first = status; int* it_first = iters;
+            if (max_iter > 1 && (!nu_out || !status || !iters)) {
+                if ((size_t)batch > h->rc_cap) {
+                    (void)hipDeviceSynchronize();
+                    if (h->rc_nu) (void)hipFree(h->rc_nu);
+                    if (h->rc_si) (void)hipFree(h->rc_si);
+                    h->rc_nu = nullptr; h->rc_si = nullptr; h->rc_cap = 0;
+                    if (hipMalloc((void**)&h->rc_nu, (size_t)batch * h->nb * h->n * sizeof(double)) != hipSuccess ||
+                        hipMalloc((void**)&h->rc_si, 2 * (size_t)batch * sizeof(int)) != hipSuccess) return FMPC_E_ALLOC;
+                    h->rc_cap = batch;
+                }
+                if (!nu_out) nu_first = h->rc_nu;
+                if (!status) st_first = h->rc_si;
+                if (!iters) it_first = h->rc_si + batch;
+            }
+            if (max_iter > 1) { const int rw = ensure_general_ws(); if (rw != FMPC_OK) return rw; }
+            FrColdParams P = h->rc_P;
+            P.batch = batch; P.x0 = x0; P.x0p = x0_pre; P.w = w; P.uprev = u_prev; P.nu0 = nu0;
+            P.zout = z_out; P.nuout = nu_first; P.u0out = nullptr; P.status = st_first; P.iters = it_first; P.step = step;
+            P.step_ld = fmpc_step_ld(n_newton); P.ws = h->rc_ws; P.ws_stride = cstride;
+            if (fmpc_guard_begin(h, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
+            hipError_t e = fmpc_launch_ramp_cold(P, cgrid, (hipStream_t)stream);
+            h->rc_last = 1;
+            if (e == hipSuccess && max_iter > 1)
+                e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_out,
+                                     nu_first, max_iter, k, z_out, nu_out, st_first, it_first, step, fmpc_step_ld(n_newton),
+                                     h->ramp_ws, stride, threads, (hipStream_t)stream, 1);
+            fmpc_guard_end(h, (hipStream_t)stream);
+            return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+        }
+    }
+    { const int rw = ensure_general_ws(); if (rw != FMPC_OK) return rw; }
     if (fmpc_guard_begin(h, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
     const hipError_t e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_init,
                                           nu0, max_iter, k, z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),

@@ -630,6 +630,182 @@ void fmpc_host_build_affine(const FmpcAffineIn& In, FmpcAffineOut& Out) {
     Out.img.insert(Out.img.end(), imgn.begin(), imgn.end());
 }
 
+// ---- cold-start step with the ramp-rate rows: constants of the Woodbury form (fmpc_host.h)
+void fmpc_host_build_ramp_cold(const FmpcRampColdIn& In, FmpcRampColdOut& Out) {
+    typedef long double ld;
+    const int n = In.n, m = In.m, T = In.T, nb = In.nb, s = n + m, Nz = T * s, nbn = nb * n;
+    const bool var2 = In.var2 != 0, has_xf = In.has_xf != 0;
+    Out.valid = 0;
+    // ---- per actuator: box and ramp terms at the start point, the tridiagonal and its inverse
+    std::vector<ld> hb(m), gb(m), erb(m), grb(m);
+    for (int c = 0; c < m; ++c) {
+        const ld dp = 1.0L / ((ld)In.umax[c] - (ld)In.umid[c]), dm = 1.0L / ((ld)In.umid[c] - (ld)In.umin[c]);
+        hb[c] = (ld)In.k * (dp * dp + dm * dm); gb[c] = (ld)In.k * (dp - dm);
+        const ld rp = 1.0L / (ld)In.dumax[c], rm = 1.0L / (-(ld)In.dumin[c]);       // slacks of u_j - u_{j-1} = 0
+        erb[c] = (ld)In.k * (rp * rp + rm * rm); grb[c] = (ld)In.k * (rp - rm);
+    }
+    Out.g0.assign((size_t)T * m, 0.0); Out.Gf.assign((size_t)T * T * m, 0.0); Out.hd.assign((size_t)T * m, 0.0);
+    Out.erb.resize(m);
+    std::vector<ld> Gl((size_t)T * T * m);                        // Gf in long double, same layout
+    std::vector<ld> dg(T), lo(T);
+    for (int c = 0; c < m; ++c) {
+        Out.erb[c] = (double)erb[c];
+        // diag_j = 2R + hb + [j >= 1] erb + [j + 1 < T] erb ; off_{j,j+1} = -erb    (stage 0's own ramp term is the per-problem delta)
+        for (int j = 0; j < T; ++j) {
+            const ld hdj = hb[c] + (j >= 1 ? erb[c] : 0.0L) + (j + 1 < T ? erb[c] : 0.0L);
+            Out.hd[(size_t)j * m + c] = (double)hdj;
+            ld d = (ld)In.R2[c] + hdj;
+            if (j > 0) d -= lo[j - 1] * lo[j - 1] * dg[j - 1];
+            if (!(d > 0.0L) || !std::isfinite((double)d)) return;
+            dg[j] = d;
+            lo[j] = j + 1 < T ? -erb[c] / d : 0.0L;
+        }
+        // inverse of L D L' (L unit lower bidiagonal with sub-diagonal lo): column by column
+        for (int col = 0; col < T; ++col) {
+            std::vector<ld> x(T, 0.0L);
+            x[col] = 1.0L;
+            for (int j = 1; j < T; ++j) x[j] -= lo[j - 1] * x[j - 1];
+            for (int j = 0; j < T; ++j) x[j] /= dg[j];
+            for (int j = T - 2; j >= 0; --j) x[j] -= lo[j] * x[j + 1];
+            for (int j = 0; j < T; ++j) Gl[((size_t)j * T + col) * m + c] = x[j];
+        }
+        for (int i = 0; i < T; ++i)
+            for (int j = 0; j < T; ++j) {                          // (symmetrised: the two triangles agree to rounding)
+                const ld v = 0.5L * (Gl[((size_t)i * T + j) * m + c] + Gl[((size_t)j * T + i) * m + c]);
+                Out.Gf[((size_t)i * T + j) * m + c] = (double)v;
+            }
+        for (int j = 0; j < T; ++j) Out.g0[(size_t)j * m + c] = Out.Gf[((size_t)j * T + 0) * m + c];
+    }
+    for (size_t i = 0; i < Gl.size(); ++i) Gl[i] = (ld)Out.Gf[i];   // (the device applies the rounded values: keep the algebra consistent)
+    auto qinv = [&](int jx, int r) -> ld { return 1.0L / (jx == T ? (ld)In.Qf2[r] : (ld)In.Q2[r]); };   // x_jx, jx = 1..T
+    // ---- gbar, phibar = Phibar^-1 (-gbar)
+    Out.gbar_u.assign((size_t)T * m, 0.0); Out.gbar_x.assign((size_t)T * n, 0.0);
+    Out.phib_u.assign((size_t)T * m, 0.0); Out.phib_x.assign((size_t)T * n, 0.0);
+    std::vector<ld> gu((size_t)T * m), gx((size_t)T * n), pu((size_t)T * m), px((size_t)T * n);
+    for (int j = 0; j < T; ++j) {
+        for (int c = 0; c < m; ++c)
+            gu[(size_t)j * m + c] = (ld)In.R2[c] * (ld)In.umid[c] + (ld)In.rl[c] + gb[c] + (j >= 1 ? grb[c] : 0.0L) - (j + 1 < T ? grb[c] : 0.0L);
+        for (int r = 0; r < n; ++r) {
+            const bool last = j + 1 == T;
+            gx[(size_t)j * n + r] = last ? (ld)In.Qf2[r] * (ld)In.xmid[r] + (ld)In.qfl[r] : (ld)In.Q2[r] * (ld)In.xmid[r] + (ld)In.ql[r];
+        }
+    }
+    for (int j = 0; j < T; ++j) {
+        for (int c = 0; c < m; ++c) {
+            ld t = 0.0L;
+            for (int i = 0; i < T; ++i) t -= Gl[((size_t)j * T + i) * m + c] * gu[(size_t)i * m + c];
+            pu[(size_t)j * m + c] = t;
+        }
+        for (int r = 0; r < n; ++r) px[(size_t)j * n + r] = -gx[(size_t)j * n + r] * qinv(j + 1, r);
+    }
+    for (size_t i = 0; i < gu.size(); ++i) { Out.gbar_u[i] = (double)gu[i]; Out.phib_u[i] = (double)pu[i]; }
+    for (size_t i = 0; i < gx.size(); ++i) { Out.gbar_x[i] = (double)gx[i]; Out.phib_x[i] = (double)px[i]; }
+    // ---- C as sparse rows (column, value); columns: u_j[c] = j s + c, x_{j+1}[r] = j s + m + r
+    struct Ent { int col; ld v; };
+    std::vector<std::vector<Ent>> Cr(nbn);
+    for (int i = 0; i < T; ++i)
+        for (int r = 0; r < n; ++r) {
+            std::vector<Ent>& row = Cr[(size_t)i * n + r];
+            row.push_back({i * s + m + r, 1.0L});
+            for (int c = 0; c < m; ++c) row.push_back({i * s + c, -(ld)In.bt[(size_t)c * n + r]});
+            if (i >= 1) for (int q = 0; q < n; ++q) row.push_back({(i - 1) * s + m + q, -(ld)In.a1[(size_t)r * n + q]});
+            if (var2 && i >= 2) for (int q = 0; q < n; ++q) row.push_back({(i - 2) * s + m + q, -(ld)In.a2[(size_t)r * n + q]});
+        }
+    if (has_xf) for (int r = 0; r < n; ++r) Cr[(size_t)T * n + r].push_back({(T - 1) * s + m + r, 1.0L});
+    auto zstart = [&](int col) -> ld { const int e = col % s; return e < m ? (ld)In.umid[e] : (ld)In.xmid[e - m]; };
+    // cpb = C z0 (- xf on the terminal rows), betab = C phibar + cpb
+    Out.cpb.assign(nbn, 0.0); Out.betab.assign(nbn, 0.0);
+    auto phib_at = [&](int col) -> ld { const int j = col / s, e = col % s; return e < m ? pu[(size_t)j * m + e] : px[(size_t)j * n + (e - m)]; };
+    std::vector<ld> cpl(nbn), betal(nbn);
+    for (int a = 0; a < nbn; ++a) {
+        ld cz = 0.0L, cp = 0.0L;
+        for (const Ent& e : Cr[a]) { cz += e.v * zstart(e.col); cp += e.v * phib_at(e.col); }
+        if (a >= T * n) cz -= (ld)In.xf[a - T * n];
+        cpl[a] = cz; betal[a] = cp + cz;
+        Out.cpb[a] = (double)cz; Out.betab[a] = (double)(cp + cz);
+    }
+    // ---- P = Phibar^-1 C' (Nz x nbn), Ybar = C P
+    std::vector<ld> P((size_t)Nz * nbn, 0.0L);
+    for (int b = 0; b < nbn; ++b)
+        for (const Ent& e : Cr[b]) {
+            const int j = e.col / s, el = e.col % s;
+            if (el < m) { for (int jj = 0; jj < T; ++jj) P[((size_t)jj * s + el) * nbn + b] += Gl[((size_t)jj * T + j) * m + el] * e.v; }
+            else P[(size_t)e.col * nbn + b] += e.v * qinv(j + 1, el - m);
+        }
+    std::vector<ld> Y((size_t)nbn * nbn, 0.0L);
+    for (int a = 0; a < nbn; ++a)
+        for (const Ent& e : Cr[a]) {
+            const ld* prow = &P[(size_t)e.col * nbn];
+            ld* yrow = &Y[(size_t)a * nbn];
+            for (int b = 0; b < nbn; ++b) yrow[b] += e.v * prow[b];
+        }
+    // Cholesky Y = L L' (lower, in place), then Yinv = L^-T L^-1
+    for (int j = 0; j < nbn; ++j) {
+        ld d = Y[(size_t)j * nbn + j];
+        for (int q = 0; q < j; ++q) d -= Y[(size_t)j * nbn + q] * Y[(size_t)j * nbn + q];
+        if (!(d > 0.0L) || !std::isfinite((double)d)) return;
+        const ld l = sqrtl(d);
+        Y[(size_t)j * nbn + j] = l;
+        for (int i = j + 1; i < nbn; ++i) {
+            ld v = Y[(size_t)i * nbn + j];
+            for (int q = 0; q < j; ++q) v -= Y[(size_t)i * nbn + q] * Y[(size_t)j * nbn + q];
+            Y[(size_t)i * nbn + j] = v / l;
+        }
+    }
+    std::vector<ld> Yi((size_t)nbn * nbn, 0.0L), x(nbn);
+    for (int col = 0; col < nbn; ++col) {
+        for (int i = 0; i < nbn; ++i) {
+            ld v = i == col ? 1.0L : 0.0L;
+            if (i < col) { x[i] = 0.0L; continue; }
+            for (int q = col; q < i; ++q) v -= Y[(size_t)i * nbn + q] * x[q];
+            x[i] = v / Y[(size_t)i * nbn + i];
+        }
+        for (int i = nbn - 1; i >= 0; --i) {
+            ld v = x[i];
+            for (int q = i + 1; q < nbn; ++q) v -= Y[(size_t)q * nbn + i] * x[q];
+            x[i] = v / Y[(size_t)i * nbn + i];
+        }
+        for (int i = 0; i < nbn; ++i) Yi[(size_t)i * nbn + col] = x[i];
+    }
+    Out.Yinv.assign((size_t)nbn * nbn, 0.0);
+    for (int a = 0; a < nbn; ++a)
+        for (int b = 0; b < nbn; ++b) Out.Yinv[(size_t)a * nbn + b] = (double)(0.5L * (Yi[(size_t)a * nbn + b] + Yi[(size_t)b * nbn + a]));
+    for (int a = 0; a < nbn; ++a)
+        for (int b = 0; b < nbn; ++b) Yi[(size_t)a * nbn + b] = (ld)Out.Yinv[(size_t)a * nbn + b];
+    // ---- Xi_u0 = P_{u0,:} Yinv (m x nbn);  G = Gf[0][0] - P_{u0,:} Yinv P_{u0,:}';  y0c = (Kbar^-1 (-[gbar; cpb]))_{u0}
+    std::vector<ld> Xi((size_t)m * nbn, 0.0L);
+    for (int r = 0; r < m; ++r)
+        for (int a = 0; a < nbn; ++a) {
+            const ld pv = P[(size_t)r * nbn + a];                 // (rows 0 .. m-1 of P are the u_0 rows)
+            if (pv == 0.0L) continue;
+            for (int b = 0; b < nbn; ++b) Xi[(size_t)r * nbn + b] += pv * Yi[(size_t)a * nbn + b];
+        }
+    Out.Xiu0t.assign((size_t)T * n * m, 0.0);
+    for (int col = 0; col < T * n; ++col)
+        for (int r = 0; r < m; ++r) Out.Xiu0t[(size_t)col * m + r] = (double)Xi[(size_t)r * nbn + col];
+    Out.G.assign((size_t)m * m, 0.0);
+    for (int r = 0; r < m; ++r)
+        for (int c = r; c < m; ++c) {
+            ld v = r == c ? Gl[((size_t)0 * T + 0) * m + r] : 0.0L;
+            for (int b = 0; b < nbn; ++b) v -= Xi[(size_t)r * nbn + b] * P[(size_t)c * nbn + b];
+            Out.G[(size_t)r * m + c] = (double)v; Out.G[(size_t)c * m + r] = (double)v;
+        }
+    // y0c: f_z = -gbar, f_nu = -cpb:  phi = phibar, nu = Yinv (C phibar + cpb) = Yinv betab, z_u0 = phibar_u0 - P_{u0,:} nu
+    Out.y0c.assign(m, 0.0);
+    {
+        std::vector<ld> nu(nbn, 0.0L);
+        for (int a = 0; a < nbn; ++a) { ld v = 0.0L; for (int b = 0; b < nbn; ++b) v += Yi[(size_t)a * nbn + b] * betal[b]; nu[a] = v; }
+        for (int r = 0; r < m; ++r) {
+            ld v = pu[r];
+            for (int b = 0; b < nbn; ++b) v -= P[(size_t)r * nbn + b] * nu[b];
+            Out.y0c[r] = (double)v;
+        }
+    }
+    for (double v : Out.Yinv) if (!std::isfinite(v)) return;
+    for (double v : Out.G) if (!std::isfinite(v)) return;
+    Out.valid = 1;
+}
+
 int fmpc_host_estimator_gain(const double* A_s, int p, int nx, std::vector<double>& G) {
     typedef long double ld;
     std::vector<ld> M((size_t)nx * nx, 0.0L), V((size_t)nx * nx, 0.0L);

@@ -138,6 +138,40 @@ void fmpc_host_build_loop_images(const FmpcFirstOut& O, int n, int m, int ks, bo
 // operand images of a rows x FA_KC row-major matrix (rows padded to tiles of 16 with zeros)
 void fmpc_host_mfma_a_images(const double* M, int rows, std::vector<double>& img);
 
+// ---- cold-start step WITH the ramp-rate rows (VAR_1/fast_mpc_ineq_const.m:58-76; fmpc_ramp_cold in fmpc_kernel_ramp.hip)
+// From the mid-box start u_j = ubar, x_j = xbar every ramp slack u_j - u_{j-1} (j >= 1) is zero -- constant -- and only the rows
+// of stage 0, u_0 - u_prev, depend on the problem.  So Phi = Phibar + E diag(delta) E' with E the columns of u_0, Phibar constant,
+// delta_c = k (1/sr+^2 + 1/sr-^2) of stage 0: the KKT matrix of the first Newton step is a constant matrix Kbar plus a
+// rank-m diagonal term, and
+//     [d_z ; nu+] = Kbar^-1 f - Kbar^-1 [E; 0] q ,   (diag(1/delta) + G) q = (Kbar^-1 f)_{u_0} ,   G = (Kbar^-1)_{u_0,u_0}
+// (Woodbury), f = -[gbar + E rho ; r_p], rho_c = k (1/sr+ - 1/sr-) of stage 0.  Per problem: ONE m x m Cholesky factorisation
+// and two passes through constant operators, where the general path factors the dense (T n)^2 Schur complement (SURVEY 8 a6').
+// Everything below is constant per (handle, k, du bounds) and built here in long double.  Kbar^-1 is applied through
+//     phi = Phibar^-1 f_z ,  nu = Ybar^-1 (C phi - f_nu) ,  z = phi - Phibar^-1 C' nu ,   Ybar = C Phibar^-1 C'
+// with Phibar^-1 = per actuator the inverse Gf of its T x T tridiagonal, per state entry 1 / (2Q).
+struct FmpcRampColdIn {
+    int n, m, T, nb, var2, has_xf;
+    const double *bt, *a1, *a2;         // bt[c*n + r] = B[r][c]; a1, a2 row-major n x n
+    const double *umax, *umin, *umid, *xmid, *R2, *rl, *Q2, *Qf2, *ql, *qfl, *xf, *dumin, *dumax;
+    double k;
+};
+struct FmpcRampColdOut {
+    int valid;                          // 0: Phibar or Ybar not positive definite / not finite (the general path reports that)
+    std::vector<double> g0;             // [T][m]      Gf_c[j][0]: column 0 of actuator c's inverse tridiagonal
+    std::vector<double> Gf;             // [T*T][m]    Gf_c[i][j] at (i T + j) m + c
+    std::vector<double> phib_u, phib_x; // [T][m], [T][n]   Phibar^-1 (-gbar)
+    std::vector<double> gbar_u, gbar_x; // [T][m], [T][n]   gradient at the start point without the stage-0 ramp rows and without C' nu
+    std::vector<double> hd;             // [T][m]      diagonal of k P'DP without the stage-0 ramp rows
+    std::vector<double> erb;            // [m]         k (1/du_max^2 + 1/du_min^2): minus the off-diagonal of k P'DP between stages
+    std::vector<double> cpb;            // [nb n]      r_p at the start point for b = 0 (terminal rows: xbar - xf)
+    std::vector<double> betab;          // [nb n]      C phibar + cpb
+    std::vector<double> Yinv;           // [nb n][nb n] symmetric
+    std::vector<double> G;              // [m][m] symmetric
+    std::vector<double> Xiu0t;          // [T n][m]    column-major transpose: Xiu0t[col m + r] = d (Kbar^-1 f)_{u_0, r} / d bhat_col
+    std::vector<double> y0c;            // [m]         (Kbar^-1 (-[gbar ; cpb]))_{u_0}
+};
+void fmpc_host_build_ramp_cold(const FmpcRampColdIn& In, FmpcRampColdOut& Out);
+
 // ---- estimator (README.md:456-480): ad_est = lsqminnorm(A_s'*A_s, A_s'*(Y_M - b_s)) = G (Y_M - b_s), G = pinv(A_s' A_s) A_s'
 // A_s: p x nx COLUMN-major (MATLAB).  G: nx x p row-major.  Eigenvalues of A_s'A_s below nx * eps * max are treated as zero
 // (minimum-norm solution, as lsqminnorm).  Returns the numerical rank.

@@ -25,6 +25,7 @@
 #include <math.h>
 #include "fmpc_device.h"
 #include "fmpc_tile_ops.h"
+#include "fmpc_rampcold.h"
 #include "../../include/fastmpc.h"
 
 #define FR_MAX_HALVINGS 64
@@ -267,7 +268,11 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
                  const double* __restrict__ uprev, const double* zinit, const double* __restrict__ nu0,
                  int max_iter, double kbar, double* zout, double* __restrict__ nuout, int* __restrict__ status,
                  int* __restrict__ iters, double* __restrict__ step, int step_ld, double* __restrict__ ws,
-                 size_t ws_stride) {
+                 size_t ws_stride, int it0) {
+    // it0 = 1: CONTINUATION behind fmpc_ramp_cold, which has taken the first Newton step of every problem: zinit (= zout) and nu0
+    // hold the iterate after that step, status / iters / step[0] its record; this launch runs the iterations 1 .. max_iter - 1 with
+    // their exit tests (inf_newton_solver.m:19-22) and adds to the record.  A problem whose first step ended in an error, or that
+    // left before stepping, is skipped.
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NW = NT / 64;
     const int n = M.n, m = M.m, T = M.T, nb = M.nb;
@@ -302,6 +307,7 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
         const double* x0pv = x0p ? x0p + (size_t)p * n : nullptr;
         const double* upv = uprev + (size_t)p * m;
         __syncthreads();
+        if (it0 > 0 && (status[p] < 0 || iters[p] < it0)) continue;      // (uniform: every thread reads the same two words)
         // ================= P0: start point, nu, b  (fast_mpc_init.m:12-27, fast_mpc_eq_const.m)
         for (int idx = tid; idx < Nz; idx += NT) {
             const int e = idx % s;
@@ -322,11 +328,11 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
             b[idx] = v;
         }
         if (step)
-            for (int idx = tid; idx < step_ld; idx += NT) step[(size_t)p * step_ld + idx] = -1.0;
+            for (int idx = tid + it0; idx < step_ld; idx += NT) step[(size_t)p * step_ld + idx] = -1.0;
         __syncthreads();
 
-        int st = FMPC_OK, nsteps = 0;
-        for (int it = 0; it < max_iter; ++it) {
+        int st = it0 > 0 ? status[p] : FMPC_OK, nsteps = it0;
+        for (int it = it0; it < max_iter; ++it) {
             // ================= P1: slacks and residuals
             FR_T0();
             double acc_d = 0.0, acc_p = 0.0;
@@ -673,6 +679,290 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
     }
 }
 
+// =====================================================================================================================
+// Cold-start Newton step WITH the ramp-rate rows in its Woodbury form (fmpc_rampcold.h, fmpc_host.h: FmpcRampColdOut).
+// From the mid-box start only the ramp rows of stage 0 (u_0 - u_prev) depend on the problem: Phi = Phibar + E diag(delta) E', so
+//     [d_z ; nu+] = Kbar^-1 (-[gbar + E s ; r_p]) ,   s = rho + q ,   (diag(1/delta) + G) q = y_u0 ,
+//     y_u0 = y0c - G rho + Xi_u0 bhat                       (the u_0 rows of Kbar^-1 f, f = -[gbar + E rho ; r_p])
+// with Kbar^-1 applied through the constant operators Phibar^-1 (per actuator its T x T inverse Gf), Ybar^-1 (explicit, nb n
+// square) and the sparse C: ONE m x m Cholesky factorisation per problem (fr_tile_cholesky on the matrix cores) where the
+// general path factors the dense (T n)^2 Schur complement and forms its T (T + 1) / 2 blocks B diag(g) B' first -- 0.8 instead
+// of 18.7 MFLOP per problem at (27, 144, 10).  Same step as fmpc_newton_ramp takes from the cold start (inf_newton_solver.m:
+// 10-41 with the rows of VAR_1/fast_mpc_ineq_const.m:58-76), different rounding; exit test, line search, status codes and the
+// step record as there.  One workgroup per problem in flight.
+template <int NT>
+__global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NW = NT / 64;
+    const FmpcDevModel& M = P.M;
+    const int n = M.n, m = M.m, T = M.T, nb = M.nb;
+    const int s = n + m, Nz = T * s, nbn = nb * n, Tm = T * m, Tn = T * n;
+    const int tid = threadIdx.x;
+    const bool var2 = M.var2 != 0;
+    const double kbar = P.kbar;
+    // ---- LDS carve
+    double* sBt = lds;                    // m n    Bt[c n + r] = B[r][c]
+    double* snu0 = sBt + (size_t)m * n;   // nbn
+    double* sbh = snu0 + nbn;             // nbn    bhat (data part of b), zero on the terminal rows
+    double* sbe = sbh + nbn;              // nbn    beta, then nu+
+    double* snup = sbe + nbn;             // nbn
+    double* srho = snup + nbn;            // m
+    double* sdel = srho + m;              // m
+    double* ss = sdel + m;                // m      y_u0, then q (solution), then s = rho + q
+    double* srdu = ss + m;                // T m    r_d on the u entries
+    double* sphi = srdu + Tm;             // T m    v = g0 s, then phi_u, then d_u
+    double* skap = sphi + Tm;             // T m    kappa = B' nu+_j ; before that: partial sums of the m-row products
+    double* red = skap + Tm;              // 16
+    double* spart = red + 16;             // NT     partial sums of the m-row products
+    double* sCh = spart + NT;             // scratch of fr_tile_cholesky: 16 x 17 + 16 NTl + 16 NW + 16
+    for (int i = tid; i < m * n; i += NT) sBt[i] = M.Bt[i];
+    const int NTl = (m + 1 + 15) >> 4;
+    double* Yd = P.ws + (size_t)blockIdx.x * P.ws_stride;
+    double* Wg = Yd + (size_t)NTl * NTl * 256;
+
+    for (int p = blockIdx.x; p < P.batch; p += gridDim.x) {
+        const double* x0v = P.x0 + (size_t)p * n;
+        const double* x0pv = P.x0p ? P.x0p + (size_t)p * n : nullptr;
+        const double* upv = P.uprev + (size_t)p * m;
+        __syncthreads();
+        // ================= P0: delta, rho of the stage-0 ramp rows; bhat; nu0
+        int bad = 0;
+        for (int c = tid; c < m; c += NT) {
+            const double dl = M.umid[c] - upv[c];
+            const double a = 1.0 / (P.dumax[c] - dl), b = 1.0 / (dl - P.dumin[c]);
+            const double de = kbar * (a * a + b * b);
+            sdel[c] = de; srho[c] = kbar * (a - b);
+            if (!(de > 0.0) || isinf(de)) bad = 1;              // (the general path finds the same entry in its first pivot)
+        }
+        double acc_p = 0.0;
+        for (int idx = tid; idx < nbn; idx += NT) {
+            snu0[idx] = P.nu0 ? P.nu0[(size_t)p * nbn + idx] : 0.0;
+            const int i = idx / n, r = idx - i * n;
+            double v = (i < T && P.w) ? P.w[(size_t)p * Tn + idx] : 0.0;
+            if (i == 0) {
+                for (int c = 0; c < n; ++c) v += M.A1t[c * n + r] * x0v[c];
+                if (var2 && x0pv)
+                    for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0pv[c];
+            } else if (i == 1 && i < T && var2) {
+                for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0v[c];
+            }
+            if (i >= T) v = 0.0;                                 // (x_T = xf is part of cpb)
+            sbh[idx] = v;
+            const double rp = P.cpb[idx] - v;                    // r_p = C z0 - b
+            acc_p += rp * rp;
+        }
+        if (P.step)
+            for (int idx = tid; idx < P.step_ld; idx += NT) P.step[(size_t)p * P.step_ld + idx] = -1.0;
+        __syncthreads();
+        // ================= P1: r_d = gbar + E rho + C' nu0 (u entries kept for the line search), exit test
+        double acc_d = 0.0;
+        for (int idx = tid; idx < Tm; idx += NT) {
+            const int j = idx / m, c = idx - j * m;
+            double dot = 0.0;
+            const double* bt = sBt + c * n;
+            const double* nj = snu0 + j * n;
+            for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
+            const double rd = P.gbar_u[idx] + (j == 0 ? srho[c] : 0.0) - dot;
+            srdu[idx] = rd;
+            acc_d += rd * rd;
+        }
+        for (int idx = tid; idx < Tn; idx += NT) {
+            const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
+            double v = P.gbar_x[idx] + snu0[jj * n + r];
+            if (j < T) {
+                const double* nj = snu0 + j * n;
+                for (int c = 0; c < n; ++c) v -= M.A1[c * n + r] * nj[c];
+            }
+            if (var2 && j + 1 < T) {
+                const double* nj = snu0 + (j + 1) * n;
+                for (int c = 0; c < n; ++c) v -= M.A2[c * n + r] * nj[c];
+            }
+            if (j == T && M.has_xf) v += snu0[T * n + r];
+            acc_d += v * v;
+        }
+        const double rp2 = fr_block_sum<NT>(acc_p, red);
+        const double rho2 = fr_block_sum<NT>(acc_d, red) + rp2;
+        const double badsum = fr_block_sum<NT>((double)bad, red);
+        int st = FMPC_OK, nsteps = 0;
+        double t = 1.0;
+        bool moved = false;
+        if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) {
+            // early exit, tested before the step (inf_newton_solver.m:19-22): the start point is returned
+        } else if (badsum > 0.0) {
+            st = FMPC_E_NOT_PD_PHI;
+        } else {
+            // ================= P2: y_u0 = y0c - G rho + Xi_u0 bhat   (rows split over NT / m thread groups, summed in a fixed order)
+            {
+                const int ncb = P.w ? Tn : ((var2 ? 2 : 1) * n < Tn ? (var2 ? 2 : 1) * n : Tn);   // columns of bhat that can be non-zero
+                if (m <= NT) {
+                    const int ngrp = NT / m < 8 ? NT / m : 8;
+                    const int g = tid / m, r = tid - g * m;
+                    if (g < ngrp) {
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int c = g; c < m; c += ngrp) a0 -= P.G[(size_t)c * m + r] * srho[c];
+                        for (int c = g; c < ncb; c += ngrp) a1 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
+                        spart[g * m + r] = a0 + a1;
+                    }
+                    __syncthreads();
+                    if (tid < m) {
+                        double v = P.y0c[tid];
+                        for (int q = 0; q < ngrp; ++q) v += spart[q * m + tid];
+                        ss[tid] = v;
+                    }
+                } else {
+                    for (int r = tid; r < m; r += NT) {
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int c = 0; c < m; ++c) a0 -= P.G[(size_t)c * m + r] * srho[c];
+                        for (int c = 0; c < ncb; ++c) a1 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
+                        ss[r] = P.y0c[r] + (a0 + a1);
+                    }
+                }
+                __syncthreads();
+            }
+            // ================= P3: [M | y_u0] as 16 x 16 tiles (upper tile triangle), M = G + diag(1 / delta); Cholesky; q
+            for (size_t idx = tid; idx < (size_t)NTl * NTl * 256; idx += NT) {
+                const int tile = (int)(idx >> 8), e = (int)(idx & 255), I = tile / NTl, J = tile - I * NTl;
+                const int row = 16 * I + (e >> 4), col = 16 * J + (e & 15);
+                double v = 0.0;
+                if (I <= J && row < m) {
+                    if (col < m) v = P.G[(size_t)row * m + col] + (row == col ? 1.0 / sdel[row] : 0.0);
+                    else if (col == m) v = ss[row];
+                }
+                Yd[idx] = v;
+            }
+            __syncthreads();
+            if (fr_tile_cholesky(Yd, NTl, m, Wg, ss, sCh)) {
+                st = FMPC_E_NOT_PD_SCHUR;
+            } else {
+                // ================= P4: s = rho + q; the pass through the constant operators
+                for (int c = tid; c < m; c += NT) ss[c] += srho[c];
+                __syncthreads();
+                for (int idx = tid; idx < Tm; idx += NT) { const int c = idx % m; sphi[idx] = P.g0[idx] * ss[c]; }      // v = Phibar^-1 E s
+                __syncthreads();
+                for (int idx = tid; idx < nbn; idx += NT) {                   // beta = C phi + r_p
+                    const int i = idx / n, r = idx - i * n;
+                    double v = P.betab[idx] - sbh[idx];
+                    if (i < T) {
+                        const double* vi = sphi + i * m;
+                        double a0 = 0.0, a1 = 0.0;
+                        int c = 0;
+                        for (; c + 1 < m; c += 2) { a0 += sBt[c * n + r] * vi[c]; a1 += sBt[(c + 1) * n + r] * vi[c + 1]; }
+                        if (c < m) a0 += sBt[c * n + r] * vi[c];
+                        v += a0 + a1;
+                    }
+                    sbe[idx] = v;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < Tm; idx += NT) sphi[idx] = P.phib_u[idx] - sphi[idx];                          // phi_u
+                for (int a = tid; a < nbn; a += NT) {                         // nu+ = Ybar^-1 beta   (Yinv symmetric: coalesced along a)
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    int b = 0;
+                    for (; b + 3 < nbn; b += 4) {
+                        a0 += P.Yinv[(size_t)b * nbn + a] * sbe[b];
+                        a1 += P.Yinv[(size_t)(b + 1) * nbn + a] * sbe[b + 1];
+                        a2 += P.Yinv[(size_t)(b + 2) * nbn + a] * sbe[b + 2];
+                        a3 += P.Yinv[(size_t)(b + 3) * nbn + a] * sbe[b + 3];
+                    }
+                    for (; b < nbn; ++b) a0 += P.Yinv[(size_t)b * nbn + a] * sbe[b];
+                    snup[a] = (a0 + a1) + (a2 + a3);
+                }
+                __syncthreads();
+                for (int idx = tid; idx < Tm; idx += NT) {                     // kappa = B' nu+_j
+                    const int j = idx / m, c = idx - j * m;
+                    double dot = 0.0;
+                    const double* bt = sBt + c * n;
+                    const double* nj = snup + j * n;
+                    for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
+                    skap[idx] = dot;
+                }
+                __syncthreads();
+                for (int idx = tid; idx < Tm; idx += NT) {                     // d_u = phi_u + Gf kappa
+                    const int j = idx / m, c = idx - j * m;
+                    double v = sphi[idx];
+                    for (int i = 0; i < T; ++i) v += P.Gf[((size_t)j * T + i) * m + c] * skap[i * m + c];
+                    sphi[idx] = v;
+                }
+                __syncthreads();
+                // ================= P5: line search (closed form of backtracking_inf_newton.m:2-11, frozen barrier gradient), update
+                double be = 0.0, e2 = 0.0;
+                for (int idx = tid; idx < Tm; idx += NT) {
+                    const int j = idx / m, c = idx - j * m;
+                    double e = (P.hd[idx] + (j == 0 ? sdel[c] : 0.0)) * sphi[idx];      // k P'DP d_z on u_j
+                    if (j > 0) e -= P.erb[c] * sphi[idx - m];
+                    if (j + 1 < T) e -= P.erb[c] * sphi[idx + m];
+                    be += srdu[idx] * e;
+                    e2 += e * e;
+                }
+                const double beta_e = fr_block_sum<NT>(be, red);
+                const double eps2 = fr_block_sum<NT>(e2, red);
+                {
+                    const double al = 1e-4;
+                    int halv = 0;
+                    while (true) {
+                        const double gq = (t - 2.0 + 2.0 * al - al * al * t) * rho2 - 2.0 * (1.0 - t) * beta_e + t * eps2;
+                        if (gq <= 0.0) break;
+                        t *= 0.5;
+                        if (++halv >= FR_MAX_HALVINGS) { t = 0.0; st = FMPC_W_LINESEARCH; break; }
+                    }
+                }
+                moved = true;
+                nsteps = 1;
+            }
+        }
+        // ---- outputs: z = z0 + t d_z, nu = nu0 + t (nu+ - nu0); a problem that did not step returns the start point
+        if (P.zout) {
+            double* zp = P.zout + (size_t)p * Nz;
+            for (int idx = tid; idx < Nz; idx += NT) {
+                const int j = idx / s, e = idx - j * s;
+                double v = e < m ? M.umid[e] : M.xmid[e - m];
+                if (moved) {
+                    if (e < m) v += t * sphi[j * m + e];
+                    else {
+                        const int r = e - m, jx = j + 1;
+                        double cv = snup[j * n + r];
+                        if (jx < T) {
+                            const double* nj = snup + jx * n;
+                            for (int c = 0; c < n; ++c) cv -= M.A1[c * n + r] * nj[c];
+                        }
+                        if (var2 && jx + 1 < T) {
+                            const double* nj = snup + (jx + 1) * n;
+                            for (int c = 0; c < n; ++c) cv -= M.A2[c * n + r] * nj[c];
+                        }
+                        if (jx == T && M.has_xf) cv += snup[T * n + r];
+                        v += t * (P.phib_x[j * n + r] - cv / (jx == T ? M.Qf2[r] : M.Q2[r]));
+                    }
+                }
+                zp[idx] = v;
+            }
+        }
+        if (P.u0out)
+            for (int c = tid; c < m; c += NT) P.u0out[(size_t)p * m + c] = M.umid[c] + (moved ? t * sphi[c] : 0.0);
+        if (P.nuout)
+            for (int idx = tid; idx < nbn; idx += NT)
+                P.nuout[(size_t)p * nbn + idx] = snu0[idx] + (moved ? t * (snup[idx] - snu0[idx]) : 0.0);
+        if (moved && P.step && tid == 0 && P.step_ld > 0) P.step[(size_t)p * P.step_ld] = t;
+        if (tid == 0) {
+            if (P.status) P.status[p] = st;
+            if (P.iters) P.iters[p] = nsteps;
+        }
+    }
+}
+
+size_t fmpc_ramp_cold_lds_bytes(int n, int m, int T, int nb) {
+    const size_t nbn = (size_t)nb * n, ntl = ((size_t)m + 1 + 15) / 16;
+    const size_t d = (size_t)m * n + 4 * nbn + 3 * (size_t)m + 3 * (size_t)T * m + 16 + 512 + (16 * 17 + 16 * ntl + 16 * 8 + 16);
+    return d * sizeof(double);
+}
+size_t fmpc_ramp_cold_ws_doubles(int m) { const size_t ntl = ((size_t)m + 1 + 15) / 16; return (ntl * ntl + ntl) * 256; }
+hipError_t fmpc_ramp_cold_prepare(size_t lds_bytes) {
+    return hipFuncSetAttribute((const void*)fmpc_ramp_cold<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+hipError_t fmpc_launch_ramp_cold(const FrColdParams& P, int grid, hipStream_t stream) {
+    const size_t lds = fmpc_ramp_cold_lds_bytes(P.M.n, P.M.m, P.M.T, P.M.nb);
+    hipLaunchKernelGGL(fmpc_ramp_cold<512>, dim3(grid), dim3(512), lds, stream, P);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- host side
 size_t fmpc_ramp_lds_bytes(int n, int m, int nbn) {      // sized for the 1024-thread variant (16 waves)
     const size_t ntl = ((size_t)nbn + 1 + 15) / 16;
@@ -693,16 +983,16 @@ hipError_t fmpc_launch_ramp(const FmpcDevModel& M, const double* dumin, const do
                             const double* x0, const double* x0p, const double* w, const double* uprev,
                             const double* zinit, const double* nu0, int max_iter, double kbar, double* zout,
                             double* nuout, int* status, int* iters, double* step, int step_ld, double* ws,
-                            size_t ws_stride, int threads, hipStream_t stream) {
+                            size_t ws_stride, int threads, hipStream_t stream, int it0) {
     const size_t lds = fmpc_ramp_lds_bytes(M.n, M.m, M.nb * M.n);
     if (threads == 1024)
         hipLaunchKernelGGL(fmpc_newton_ramp<1024>, dim3(grid), dim3(1024), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
-                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride, it0);
     else if (threads == 512)
         hipLaunchKernelGGL(fmpc_newton_ramp<512>, dim3(grid), dim3(512), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
-                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride, it0);
     else
         hipLaunchKernelGGL(fmpc_newton_ramp<256>, dim3(grid), dim3(256), lds, stream, M, dumin, dumax, batch, x0, x0p, w, uprev,
-                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+                           zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride, it0);
     return hipGetLastError();
 }

@@ -137,3 +137,71 @@ def test_ramp_class_one_shot_and_errors(pkg, gpu):
         h.set_ramp(du_max, du_min)                                   # empty ramp interval
     assert e.value.code == pkg.FMPC_E_DIM
     h.close()
+
+
+@pytest.mark.parametrize("n,m,T,var_order,xf,nw,batch,k,edge", [
+    (27, 144, 10, 1, False, 1, 6, 0.01, 0.5),       # BASELINE configs[0], the reference loop's call (one step from the cold start)
+    (27, 144, 10, 1, False, 3, 5, 0.01, 0.5),       # first step in the Woodbury form, two more by the dense factorisation
+    (27, 144, 4, 2, True, 2, 4, 0.01, 0.5),         # VAR(2) dynamics + terminal rows
+    (8, 5, 6, 1, False, 1, 700, 0.01, 0.5),         # more problems than workgroups in flight
+    (8, 5, 6, 1, False, 4, 40, 1.0, 0.9),           # heavy barrier, u_prev next to the ramp bound: the line search backtracks (t = 1/2 .. 1/8)
+    (8, 5, 6, 1, False, 3, 12, 10.0, 0.97),         # ... and collapses for some problems ("no move", FMPC_W_LINESEARCH)
+    (5, 8, 1, 1, False, 2, 3, 0.01, 0.5),           # T = 1: no ramp row between stages at all
+    (20, 33, 5, 1, False, 1, 9, 0.05, 0.8),         # m not a multiple of 16: masked edge tiles of the m x m factorisation
+])
+def test_ramp_cold_start_woodbury_form(pkg, gpu, n, m, T, var_order, xf, nw, batch, k, edge):
+    """fmpc_ramp_cold (the cold-start step with the ramp rows as a constant KKT matrix + a diagonal term on u_0: one m x m
+    factorisation per problem) against the general path of the same library (FMPC_NO_RAMP_COLD=1: dense (T n)^2 factorisation;
+    1e-10 on z, identical iteration counts / status / step lengths) and against the dense oracle (1e-9)."""
+    import os
+    if n == 27:
+        md = pkg.synthetic.make_model(n, m, T, var_order=var_order)
+        data = pkg.synthetic.make_replay_batch(md, r=4, steps=batch)
+        data["nu0"] = data["nu0"][:, :T * n]
+        data["w"] = 0.01 * np.random.default_rng(1).standard_normal((batch, T * n))
+        if xf:
+            md["xf"] = 0.01 * np.random.default_rng(2).standard_normal(n)
+            data["nu0"] = np.random.default_rng(3).random((batch, (T + 1) * n))
+    else:
+        md, data = pkg.synthetic.make_test_problem(n, m, T, seed=17 + n + T, xf=xf, var_order=var_order, batch=batch)
+    rng = np.random.default_rng(5)
+    du_min = -0.4 * (0.5 + rng.random(m)); du_max = 0.4 * (0.5 + rng.random(m))
+    umid = 0.5 * (md["u_min"] + md["u_max"])
+    frac = 0.5 + edge * (rng.random((batch, m)) - 0.5)                   # u_0 - u_prev at `frac` of the way from du_min to du_max
+    u_prev = umid - (du_min + frac * (du_max - du_min))
+    x0p = data["x0_pre"] if var_order == 2 else None
+    h = handle_from_model(pkg, md)
+    h.set_ramp(du_min, du_max)
+    z, info = h.solve(data["x0"], x0p, data["w"], nu0=data["nu0"], n_newton=nw, k=k, return_info=True, u_prev=u_prev)
+    assert h.last_dispatch()[0] == pkg.FMPC_PATH_RAMP and h.last_dual_form() == 5
+    os.environ["FMPC_NO_RAMP_COLD"] = "1"
+    try:
+        hg = handle_from_model(pkg, md)
+    finally:
+        del os.environ["FMPC_NO_RAMP_COLD"]
+    hg.set_ramp(du_min, du_max)
+    zg, ig = hg.solve(data["x0"], x0p, data["w"], nu0=data["nu0"], n_newton=nw, k=k, return_info=True, u_prev=u_prev)
+    assert hg.last_dual_form() == 0
+    assert np.array_equal(info["iters"], ig["iters"]) and np.array_equal(info["status"], ig["status"])
+    assert np.array_equal(canon_steps(info["step"]), canon_steps(ig["step"]))
+    gerr = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-3))
+    assert max(gerr(z[p], zg[p]) for p in range(batch)) <= 1e-10
+    assert max(gerr(info["nu"][p], ig["nu"][p]) for p in range(batch)) <= 1e-8
+    if k >= 1.0:
+        assert (info["step"][:, 0] < 1.0).any(), "no backtracking: the case does not test the line search"
+    aerr = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-3))     # (a collapsed search leaves z at the zero start point)
+    for p in sorted({0, batch // 2, batch - 1}):
+        zo, io = _oracle(md, data["x0"][p], None if x0p is None else x0p[p], data["w"][p], u_prev[p], du_min, du_max, nw, k, data["nu0"][p])
+        assert info["iters"][p] == io["iters"] and np.array_equal(canon_steps(info["step"][p][:io["iters"]]), canon_steps(io["t"][:io["iters"]]))
+        assert aerr(z[p], zo) <= TOL and aerr(info["nu"][p], io["nu"]) <= 1e-7
+    # an explicit start point takes the general path; a NaN in u_prev ends in the same status on both paths, the others unharmed
+    zi = np.tile(np.concatenate([umid, 0.5 * (md["x_min"] + md["x_max"])]), (batch, T))
+    zw = h.solve(data["x0"], x0p, data["w"], z_init=zi, nu0=data["nu0"], n_newton=1, k=k, u_prev=u_prev)
+    assert h.last_dual_form() == 0 and max(gerr(zw[p], (z if nw == 1 else zw)[p]) for p in range(batch)) <= 1e-10
+    up_bad = u_prev.copy(); up_bad[0, 1] = np.nan
+    zb, ib = h.solve(data["x0"], x0p, data["w"], nu0=data["nu0"], n_newton=nw, k=k, return_info=True, u_prev=up_bad, check=False)
+    zc, ic = hg.solve(data["x0"], x0p, data["w"], nu0=data["nu0"], n_newton=nw, k=k, return_info=True, u_prev=up_bad, check=False)
+    assert ib["status"][0] == ic["status"][0] < 0 and ib["iters"][0] == ic["iters"][0] == 0
+    if batch > 1:
+        assert np.array_equal(ib["status"][1:], info["status"][1:]) and all(np.array_equal(zb[p], z[p]) for p in range(1, batch))
+    h.close(); hg.close()
