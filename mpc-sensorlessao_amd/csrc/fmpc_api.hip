@@ -1976,6 +1976,25 @@ static int fmpc_ensure_ramp_cold(fmpc_handle h, double k) {
     const size_t o_g0 = push(O.g0), o_Gf = push(O.Gf), o_pu = push(O.phib_u), o_px = push(O.phib_x), o_gu = push(O.gbar_u), o_gx = push(O.gbar_x),
                  o_hd = push(O.hd), o_er = push(O.erb), o_cp = push(O.cpb), o_bb = push(O.betab), o_Yi = push(O.Yinv), o_G = push(O.G),
                  o_Xi = push(O.Xiu0t), o_y0 = push(O.y0c);
+    size_t o_ik, o_ib;
+    {
+        std::vector<double> ik, ib;
+        fmpc_host_mfma_images(h->hm_bt.data(), h->m, h->n, (h->n + 3) / 4, ik);
+        fmpc_host_mfma_images(h->hm_b.data(), h->n, h->m, (h->m + 3) / 4, ib);
+        o_ik = push(ik); o_ib = push(ib);
+    }
+    size_t o_Gt;
+    {   // G in the LDS tile layout of fr_tile_cholesky_lds: upper tile triangle of [G | rhs] packed, 16 x 16 row-major, zero padded
+        const int m_ = h->m, NTm = (m_ + 15) / 16, NT1 = NTm + 1;
+        std::vector<double> Gt;
+        for (int I = 0; I < NTm; ++I)
+            for (int J = I; J < NT1; ++J)
+                for (int e = 0; e < 256; ++e) {
+                    const int row = 16 * I + (e >> 4), col = 16 * J + (e & 15);
+                    Gt.push_back(row < m_ && col < m_ ? O.G[(size_t)row * m_ + col] : 0.0);
+                }
+        o_Gt = push(Gt);
+    }
     if (h->rc_pool) { (void)hipDeviceSynchronize(); (void)hipFree(h->rc_pool); h->rc_pool = nullptr; }
     h->rc_valid = 0;
     if (hipMalloc((void**)&h->rc_pool, pool.size() * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
@@ -1986,7 +2005,7 @@ static int fmpc_ensure_ramp_cold(fmpc_handle h, double k) {
     P.M = h->dev; P.dumin = h->ramp_du; P.dumax = h->ramp_du + h->m; P.kbar = k;
     P.g0 = h->rc_pool + o_g0; P.Gf = h->rc_pool + o_Gf; P.phib_u = h->rc_pool + o_pu; P.phib_x = h->rc_pool + o_px; P.gbar_u = h->rc_pool + o_gu;
     P.gbar_x = h->rc_pool + o_gx; P.hd = h->rc_pool + o_hd; P.erb = h->rc_pool + o_er; P.cpb = h->rc_pool + o_cp; P.betab = h->rc_pool + o_bb;
-    P.Yinv = h->rc_pool + o_Yi; P.G = h->rc_pool + o_G; P.Xiu0t = h->rc_pool + o_Xi; P.y0c = h->rc_pool + o_y0;
+    P.Yinv = h->rc_pool + o_Yi; P.G = h->rc_pool + o_G; P.Gt = h->rc_pool + o_Gt; P.imgBk = h->rc_pool + o_ik; P.imgBb = h->rc_pool + o_ib; P.Xiu0t = h->rc_pool + o_Xi; P.y0c = h->rc_pool + o_y0;
     h->rc_valid = 1; h->rc_k = k;
     return FMPC_OK;
 }

@@ -55,9 +55,9 @@ __device__ __forceinline__ double fr_block_sum(double v, double* red) {
 
 #ifdef FW_TIMING
 // per-phase time of workgroup 0 (100 MHz ticks): P1, P2, P3, P4 factor, P4 substitutions, P5
-__device__ unsigned long long fr_timing[8];
+__device__ unsigned long long fr_timing[16];
 extern "C" int fmpc_debug_ramp_timing(unsigned long long* out) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fr_timing), sizeof(z)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(fr_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
@@ -257,6 +257,171 @@ __device__ __noinline__ int fr_tile_cholesky(double* Yt, int NTl, int nbn, doubl
 #ifdef FW_TIMING
     if (blockIdx.x == 0 && tid == 0) fr_timing[7] += (unsigned long long)wall_clock64() - _tb;
 #endif
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same factorisation with the tiles IN LDS (the m x m system of the cold-start form, fmpc_ramp_cold): upper tile triangle of
+// [M | rhs] packed, tile (I, J), I <= J < NT1, at FR_TIDX(I, J, NT1) * 256 doubles, row-major 16 x 16 (element 64 r + lane is
+// accumulator register r of that lane); NTm block rows of M, the rhs in column 0 of tile column NTm = NT1 - 1.  Left-looking per
+// block row kb: every wavefront takes the tiles kb + wv, kb + wv + NW, ... of the row, subtracts the products with the block rows
+// already done (operands straight from LDS, the next pair requested before the matrix cores take the current one), the owner of
+// the diagonal tile factors it (ft_potrf16: R(kb,kb), W = R(kb,kb)^-T), then R(kb,J) = W P(kb,J) from registers; the DIAGONAL
+// tiles are updated right-looking in that pass, so a diagonal tile is complete when its block row starts.  Two
+// LDS-only barriers per block row.  The diagonal inverses W go to RIt (global, read back one block row ahead in the backward
+// substitution R x = y).  Returns 1 if a pivot is not positive.  sh: 16 x 17 + 16 NT1 + 16 NW + 16 doubles.
+typedef __attribute__((address_space(3))) double* fr_lds_t;
+#define FR_TIDX(I, J, NT1) ((I) * (NT1) - (I) * ((I) - 1) / 2 + ((J) - (I)))
+#define FR_LOWN 3                       // tiles of a block row per wavefront kept in registers
+__device__ __noinline__ int fr_tile_cholesky_lds(double* tiles_g, int NTm, int mm, double* RIt, double* xout, double* sh_g) {
+    typedef FtT<double> TT;
+    const fr_lds_t tiles = (fr_lds_t)tiles_g;
+    const fr_lds_t sh = (fr_lds_t)sh_g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6, c = lane & 15, g = lane >> 4;
+    const int NT1 = NTm + 1;
+    const fr_lds_t sW = sh;                  // W' of the current diagonal tile, leading dimension 17
+    const fr_lds_t xs = sW + 16 * 17;        // x, padded to 16 NT1
+    const fr_lds_t part = xs + 16 * NT1;     // [NW][16] partial sums of the backward substitution
+    const fr_lds_t tsh = part + 16 * NW;     // [16]
+    __shared__ int sfail_l;
+    if (tid == 0) sfail_l = 0;
+    __syncthreads();
+    for (int kb = 0; kb < NTm; ++kb) {
+        const int cnt = mm - 16 * kb < 16 ? mm - 16 * kb : 16;             // live rows of this block row
+        ft_d4 own[FR_LOWN];
+        int slot = 0;
+#ifdef FW_TIMING
+        const unsigned long long _ta = (unsigned long long)wall_clock64();
+#endif
+        for (int J = kb + wv; J < NT1; J += NW, ++slot) {
+            const fr_lds_t tp = tiles + FR_TIDX(kb, J, NT1) * 256;
+            ft_d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = tp[64 * r + lane];
+            if (kb > 0 && J != kb) {                                        // (the diagonal tiles are kept up to date in pass B)
+                ft_d4 x, z;
+                {
+                    const fr_lds_t X = tiles + FR_TIDX(0, kb, NT1) * 256, Z = tiles + FR_TIDX(0, J, NT1) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[r] = X[64 * r + lane]; z[r] = Z[64 * r + lane]; }
+                }
+                for (int k = 0; k < kb; ++k) {
+                    ft_d4 nx = x, nz = z;
+                    if (k + 1 < kb) {
+                        const fr_lds_t X = tiles + FR_TIDX(k + 1, kb, NT1) * 256, Z = tiles + FR_TIDX(k + 1, J, NT1) * 256;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { nx[r] = X[64 * r + lane]; nz[r] = Z[64 * r + lane]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = TT::mfma_sub(x[r], z[r], acc);
+                    x = nx; z = nz;
+                }
+            }
+            if (J == kb) {
+                ft_d4 Ro, Wo;
+#ifdef FW_TIMING
+                const unsigned long long _tp = (unsigned long long)wall_clock64();
+#endif
+                const bool ok = cnt == 16 ? ft_potrf16_ct<double, 16>(acc, c, g, Ro, Wo) : ft_potrf16<double>(acc, cnt, c, g, Ro, Wo);
+#ifdef FW_TIMING
+                if (blockIdx.x == 0 && lane == 0) fr_timing[7] += (unsigned long long)wall_clock64() - _tp;
+#endif
+                if (!ok && lane == 0) sfail_l = 1;
+                double* ri = RIt + (size_t)kb * 256;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sW[c * 17 + TT::row(g, r)] = Wo[r];
+                    ri[c * 16 + TT::row(g, r)] = Wo[r];
+                    tp[64 * r + lane] = Ro[r];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < FR_LOWN; ++q) if (q == slot) own[q] = acc;
+            }
+        }
+        ft_lds_barrier();
+#ifdef FW_TIMING
+        if (blockIdx.x == 0 && tid == 0) fr_timing[6] += (unsigned long long)wall_clock64() - _ta;
+#endif
+        if (sfail_l) return 1;                                              // uniform
+        {
+            double wop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wop[r] = sW[TT::row(g, r) * 17 + c];
+            slot = 0;
+            for (int J = kb + wv; J < NT1; J += NW, ++slot) {
+                if (J == kb) continue;
+                const fr_lds_t tp = tiles + FR_TIDX(kb, J, NT1) * 256;
+                ft_d4 pv = own[0], o = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 1; q < FR_LOWN; ++q) if (q == slot) pv = own[q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o = TT::mfma(wop[r], pv[r], o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[64 * r + lane] = o[r];
+                if (J < NTm) {
+                    // right-looking for the DIAGONAL tiles only: M(J,J) -= R(kb,J)' R(kb,J) now, from the registers -- the owner of the
+                    // next diagonal tile then starts its 16-step factorisation at once instead of first summing kb products (they
+                    // were the critical path: every other wavefront waits for that tile).  Tile (kb, J) has one owner: no conflict.
+                    const fr_lds_t dp = tiles + FR_TIDX(J, J, NT1) * 256;
+                    ft_d4 dacc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dacc[r] = dp[64 * r + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dacc = TT::mfma_sub(o[r], o[r], dacc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[64 * r + lane] = dacc[r];
+                }
+            }
+        }
+        ft_lds_barrier();                                                   // (the tiles of this block row are read by every wave from here on)
+    }
+    // ---- backward substitution: x_kb = R(kb,kb)^-1 (y_kb - sum_{J>kb} R(kb,J) x_J), y = column 0 of tile column NTm
+    for (int i = tid; i < 16 * NT1; i += blockDim.x) xs[i] = 0.0;
+    __syncthreads();                                                        // (also: the W tiles in RIt are visible to every wave)
+    // (the inverse diagonal tiles come from memory: all of them requested here -- one round trip, not one per block row)
+    constexpr int FR_RIVN = 12;
+    double rivs[FR_RIVN];
+#pragma unroll
+    for (int q = 0; q < FR_RIVN; ++q) rivs[q] = (tid < 256 && q < NTm) ? RIt[(size_t)q * 256 + tid] : 0.0;
+    for (int kb = NTm - 1; kb >= 0; --kb) {
+        double riv = 0.0;
+        if (kb < FR_RIVN) {
+#pragma unroll
+            for (int q = 0; q < FR_RIVN; ++q) if (q == kb) riv = rivs[q];
+        } else if (tid < 256) riv = RIt[(size_t)kb * 256 + tid];
+        double ps[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int J = kb + 1 + wv; J < NTm; J += NW) {
+            const double xv = xs[16 * J + c];
+            const fr_lds_t tp = tiles + FR_TIDX(kb, J, NT1) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps[r] = fma(tp[64 * r + lane], xv, ps[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = ft_row16_sum<double>(ps[r]);
+            if (c == 0) part[wv * 16 + 4 * r + g] = v;
+        }
+        ft_lds_barrier();
+        if (tid < 16) {
+            double sacc = 0.0;
+            for (int q = 0; q < NW; ++q) sacc += part[q * 16 + tid];
+            tsh[tid] = tiles[FR_TIDX(kb, NTm, NT1) * 256 + tid * 16] - sacc;
+        }
+        ft_lds_barrier();
+        if (tid < 256) {
+            const int row = tid >> 4;
+            double v = riv * tsh[c];
+            v = ft_row16_sum<double>(v);
+            if (c == 0) {
+                const int e = 16 * kb + row;
+                xs[e] = e < mm ? v : 0.0;
+                if (e < mm) xout[e] = v;
+            }
+        }
+        ft_lds_barrier();
+    }
     return 0;
 }
 
@@ -690,41 +855,139 @@ fmpc_newton_ramp(FmpcDevModel M, const double* __restrict__ dumin, const double*
 // of 18.7 MFLOP per problem at (27, 144, 10).  Same step as fmpc_newton_ramp takes from the cold start (inf_newton_solver.m:
 // 10-41 with the rows of VAR_1/fast_mpc_ineq_const.m:58-76), different rounding; exit test, line search, status codes and the
 // step record as there.  One workgroup per problem in flight.
+// dst[0 .. cnt) = src[0 .. cnt) (global -> LDS) with eight loads per thread in flight (a load + store loop waits per element)
 template <int NT>
+__device__ __forceinline__ void fr_copy_in(double* dst, const double* __restrict__ src, int cnt, int tid) {
+    for (int i0 = tid; i0 < cnt; i0 += 8 * NT) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; v[u] = src[i < cnt ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; if (i < cnt) dst[i] = v[u]; }
+    }
+}
+// sum_c a[c * as] * x[c] over LDS operands; NC > 0: the length at compile time (straight-line: every read requested up front)
+template <int NC>
+__device__ __forceinline__ double fr_ldsdot_n(const double* a, int as, const double* x, int cnt) {
+    if (NC > 0) {
+        double av[NC > 0 ? NC : 1], xv[NC > 0 ? NC : 1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { av[c] = a[c * as]; xv[c] = x[c]; }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if ((c & 3) == 0) a0 = fma(av[c], xv[c], a0); else if ((c & 3) == 1) a1 = fma(av[c], xv[c], a1);
+            else if ((c & 3) == 2) a2 = fma(av[c], xv[c], a2); else a3 = fma(av[c], xv[c], a3);
+        }
+        return (a0 + a1) + (a2 + a3);
+    }
+    double a0 = 0.0, a1 = 0.0;
+    int c = 0;
+    for (; c + 1 < cnt; c += 2) { a0 += a[c * as] * x[c]; a1 += a[(c + 1) * as] * x[c + 1]; }
+    if (c < cnt) a0 += a[c * as] * x[c];
+    return a0 + a1;
+}
+// sum_c a[c * as] * x[c] over LDS operands, two accumulators
+__device__ __forceinline__ double fr_ldsdot(const double* a, int as, const double* x, int cnt) {
+    double a0 = 0.0, a1 = 0.0;
+    int c = 0;
+    for (; c + 1 < cnt; c += 2) { a0 += a[c * as] * x[c]; a1 += a[(c + 1) * as] * x[c + 1]; }
+    if (c < cnt) a0 += a[c * as] * x[c];
+    return a0 + a1;
+}
+// sum_c A[c * lda + r] * x[c], c < cnt, with four independent loads in flight (a loop of one load + one fma per iteration is one
+// memory round trip per term)
+__device__ __forceinline__ double fr_coldot(const double* __restrict__ A, int lda, int r, const double* x, int cnt, int xs = 1) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = 0;
+    for (; c + 3 < cnt; c += 4) {
+        const double v0 = A[(size_t)c * lda + r], v1 = A[(size_t)(c + 1) * lda + r], v2 = A[(size_t)(c + 2) * lda + r], v3 = A[(size_t)(c + 3) * lda + r];
+        a0 += v0 * x[c * xs]; a1 += v1 * x[(c + 1) * xs]; a2 += v2 * x[(c + 2) * xs]; a3 += v3 * x[(c + 3) * xs];
+    }
+    for (; c < cnt; ++c) a0 += A[(size_t)c * lda + r] * x[c * xs];
+    return (a0 + a1) + (a2 + a3);
+}
+
+// out[i][j] = sum_k X[i][k] Z[j][k] on the fp64 matrix cores, i < rows_x (horizon stages), j < rows_z, k < K:
+//   X  in LDS, row-major with leading dimension ldx (rows beyond rows_x and k beyond K read as zero)
+//   Z  as operand images in memory, [ceil(rows_z / 16)][ks][64] (fmpc_host_mfma_images of the rows_z x K matrix): 512-byte loads
+// One (16 x 16) output tile per wavefront and turn, K in chunks of KCH k-steps whose operands are all requested before the first
+// product.  emit(i, j, value) is called once per live element by the lane that holds it.
+template <int KCH, class EMIT>
+__device__ __forceinline__ void fr_stage_product(const double* X, int ldx, int rows_x, const double* __restrict__ Zimg, int rows_z, int K,
+                                                 int wv, int NW, int lane, EMIT emit) {
+    const int ks = (K + 3) >> 2, ti = (rows_x + 15) >> 4, tj = (rows_z + 15) >> 4, li = lane & 15, lk = lane >> 4;
+    for (int task = wv; task < ti * tj; task += NW) {
+        const int It = task / tj, Jt = task - It * tj;
+        const double* zi = Zimg + (size_t)Jt * ks * 64 + lane;
+        const int xi = 16 * It + li;
+        const double* xr = X + (size_t)(xi < rows_x ? xi : 0) * ldx;
+        const double xm = xi < rows_x ? 1.0 : 0.0;
+        d4 acc = {0, 0, 0, 0};
+        for (int q0 = 0; q0 < ks; q0 += KCH) {
+            double zv[KCH], xv[KCH];
+#pragma unroll
+            for (int u = 0; u < KCH; ++u) {
+                const int q = q0 + u < ks ? q0 + u : ks - 1, kk = 4 * q + lk;
+                zv[u] = zi[(size_t)q * 64];
+                xv[u] = (q0 + u < ks && kk < K) ? xr[kk < K ? kk : 0] * xm : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < KCH; ++u) acc = MFMA64(xv[u], zv[u], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * It + lk + 4 * r, j = 16 * Jt + li;
+            if (i < rows_x && j < rows_z) emit(i, j, acc[r]);
+        }
+    }
+}
+
+// NC: n at compile time (27: the AO size -- the n-long dot products over LDS operands are then straight-line code, their reads
+// requested together) or 0 = any n at run time.
+template <int NT, int NC>
 __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NW = NT / 64;
     const FmpcDevModel& M = P.M;
-    const int n = M.n, m = M.m, T = M.T, nb = M.nb;
+    const int n = NC ? NC : M.n, m = M.m, T = M.T, nb = M.nb;
     const int s = n + m, Nz = T * s, nbn = nb * n, Tm = T * m, Tn = T * n;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool var2 = M.var2 != 0;
     const double kbar = P.kbar;
-    // ---- LDS carve
-    double* sBt = lds;                    // m n    Bt[c n + r] = B[r][c]
-    double* snu0 = sBt + (size_t)m * n;   // nbn
+    const int NTm = (m + 15) >> 4, NT1 = NTm + 1, ntiles = FR_TIDX(NTm - 1, NT1 - 1, NT1) + 1;
+    // ---- LDS carve: what lives through the whole step, then a region used in turn by [phi | kappa] and by the tiles of the
+    //      m x m factorisation.  B is not staged: the three products with it run on the matrix cores from operand images (L2)
+    double* snu0 = lds;                   // nbn
     double* sbh = snu0 + nbn;             // nbn    bhat (data part of b), zero on the terminal rows
-    double* sbe = sbh + nbn;              // nbn    beta, then nu+
-    double* snup = sbe + nbn;             // nbn
+    double* sbe = sbh + nbn;              // nbn    beta
+    double* snup = sbe + nbn;             // nbn    nu+
     double* srho = snup + nbn;            // m
     double* sdel = srho + m;              // m
     double* ss = sdel + m;                // m      y_u0, then q (solution), then s = rho + q
     double* srdu = ss + m;                // T m    r_d on the u entries
-    double* sphi = srdu + Tm;             // T m    v = g0 s, then phi_u, then d_u
-    double* skap = sphi + Tm;             // T m    kappa = B' nu+_j ; before that: partial sums of the m-row products
-    double* red = skap + Tm;              // 16
+    double* red = srdu + Tm;              // 16
     double* spart = red + 16;             // NT     partial sums of the m-row products
-    double* sCh = spart + NT;             // scratch of fr_tile_cholesky: 16 x 17 + 16 NTl + 16 NW + 16
-    for (int i = tid; i < m * n; i += NT) sBt[i] = M.Bt[i];
-    const int NTl = (m + 1 + 15) >> 4;
-    double* Yd = P.ws + (size_t)blockIdx.x * P.ws_stride;
-    double* Wg = Yd + (size_t)NTl * NTl * 256;
+    double* sCh = spart + NT;             // scratch of fr_tile_cholesky_lds: 16 x 17 + 16 NT1 + 16 NW + 16
+    double* sA1 = sCh + (16 * 17 + 16 * NT1 + 16 * NW + 16);    // n n  A1 row-major (and A2 behind it): read by every problem, three times each
+    double* sA2 = sA1 + (size_t)n * n;
+    double* uni = sA2 + (var2 ? (size_t)n * n : 0);
+    uni = (double*)(((size_t)uni + 15) & ~(size_t)15);
+    double* sphi = uni;                   // T m    v = g0 s, then phi_u, then d_u
+    double* skap = sphi + Tm;             // T m    kappa = B' nu+_j
+    double* stl = uni;                    // ntiles x 256: upper tile triangle of [M | y_u0]
+    double* Wg = P.ws + (size_t)blockIdx.x * P.ws_stride;      // inverse diagonal tiles (global: read back one block row ahead)
+    for (int i = tid; i < n * n; i += NT) { sA1[i] = M.A1[i]; if (var2) sA2[i] = M.A2[i]; }
 
     for (int p = blockIdx.x; p < P.batch; p += gridDim.x) {
         const double* x0v = P.x0 + (size_t)p * n;
         const double* x0pv = P.x0p ? P.x0p + (size_t)p * n : nullptr;
         const double* upv = P.uprev + (size_t)p * m;
         __syncthreads();
+        FR_T0();
+        if (tid < 2 * n) spart[tid] = tid < n ? x0v[tid] : (x0pv ? x0pv[tid - n] : 0.0);      // x0, x0_pre through LDS
+        __syncthreads();
+        const double* sx0 = spart;
         // ================= P0: delta, rho of the stage-0 ramp rows; bhat; nu0
         int bad = 0;
         for (int c = tid; c < m; c += NT) {
@@ -740,11 +1003,10 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
             const int i = idx / n, r = idx - i * n;
             double v = (i < T && P.w) ? P.w[(size_t)p * Tn + idx] : 0.0;
             if (i == 0) {
-                for (int c = 0; c < n; ++c) v += M.A1t[c * n + r] * x0v[c];
-                if (var2 && x0pv)
-                    for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0pv[c];
+                v += fr_ldsdot_n<NC>(sA1 + r * n, 1, sx0, n);
+                if (var2 && x0pv) v += fr_ldsdot_n<NC>(sA2 + r * n, 1, sx0 + n, n);
             } else if (i == 1 && i < T && var2) {
-                for (int c = 0; c < n; ++c) v += M.A2t[c * n + r] * x0v[c];
+                v += fr_ldsdot_n<NC>(sA2 + r * n, 1, sx0, n);
             }
             if (i >= T) v = 0.0;                                 // (x_T = xf is part of cpb)
             sbh[idx] = v;
@@ -756,27 +1018,17 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
         __syncthreads();
         // ================= P1: r_d = gbar + E rho + C' nu0 (u entries kept for the line search), exit test
         double acc_d = 0.0;
-        for (int idx = tid; idx < Tm; idx += NT) {
-            const int j = idx / m, c = idx - j * m;
-            double dot = 0.0;
-            const double* bt = sBt + c * n;
-            const double* nj = snu0 + j * n;
-            for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
+        fr_stage_product<8>(snu0, n, T, P.imgBk, m, n, wv, NW, lane, [&](int j, int c, double dot) {     // B' nu0_j on the matrix cores
+            const int idx = j * m + c;
             const double rd = P.gbar_u[idx] + (j == 0 ? srho[c] : 0.0) - dot;
             srdu[idx] = rd;
             acc_d += rd * rd;
-        }
+        });
         for (int idx = tid; idx < Tn; idx += NT) {
             const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
             double v = P.gbar_x[idx] + snu0[jj * n + r];
-            if (j < T) {
-                const double* nj = snu0 + j * n;
-                for (int c = 0; c < n; ++c) v -= M.A1[c * n + r] * nj[c];
-            }
-            if (var2 && j + 1 < T) {
-                const double* nj = snu0 + (j + 1) * n;
-                for (int c = 0; c < n; ++c) v -= M.A2[c * n + r] * nj[c];
-            }
+            if (j < T) v -= fr_ldsdot_n<NC>(sA1 + r, n, snu0 + j * n, n);
+            if (var2 && j + 1 < T) v -= fr_ldsdot_n<NC>(sA2 + r, n, snu0 + (j + 1) * n, n);
             if (j == T && M.has_xf) v += snu0[T * n + r];
             acc_d += v * v;
         }
@@ -786,22 +1038,37 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
         int st = FMPC_OK, nsteps = 0;
         double t = 1.0;
         bool moved = false;
+        FR_TICK(0);
         if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) {
             // early exit, tested before the step (inf_newton_solver.m:19-22): the start point is returned
         } else if (badsum > 0.0) {
             st = FMPC_E_NOT_PD_PHI;
         } else {
-            // ================= P2: y_u0 = y0c - G rho + Xi_u0 bhat   (rows split over NT / m thread groups, summed in a fixed order)
+            // ================= P2: y_u0 = y0c - G rho + Xi_u0 bhat   (rows split over up to 8 thread groups, summed in a fixed order)
             {
                 const int ncb = P.w ? Tn : ((var2 ? 2 : 1) * n < Tn ? (var2 ? 2 : 1) * n : Tn);   // columns of bhat that can be non-zero
                 if (m <= NT) {
                     const int ngrp = NT / m < 8 ? NT / m : 8;
                     const int g = tid / m, r = tid - g * m;
                     if (g < ngrp) {
-                        double a0 = 0.0, a1 = 0.0;
-                        for (int c = g; c < m; c += ngrp) a0 -= P.G[(size_t)c * m + r] * srho[c];
-                        for (int c = g; c < ncb; c += ngrp) a1 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
-                        spart[g * m + r] = a0 + a1;
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                        int c = g;
+                        for (; c + 3 * ngrp < m; c += 4 * ngrp) {
+                            a0 -= P.G[(size_t)c * m + r] * srho[c];
+                            a1 -= P.G[(size_t)(c + ngrp) * m + r] * srho[c + ngrp];
+                            a2 -= P.G[(size_t)(c + 2 * ngrp) * m + r] * srho[c + 2 * ngrp];
+                            a3 -= P.G[(size_t)(c + 3 * ngrp) * m + r] * srho[c + 3 * ngrp];
+                        }
+                        for (; c < m; c += ngrp) a0 -= P.G[(size_t)c * m + r] * srho[c];
+                        c = g;
+                        for (; c + 3 * ngrp < ncb; c += 4 * ngrp) {
+                            a0 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
+                            a1 += P.Xiu0t[(size_t)(c + ngrp) * m + r] * sbh[c + ngrp];
+                            a2 += P.Xiu0t[(size_t)(c + 2 * ngrp) * m + r] * sbh[c + 2 * ngrp];
+                            a3 += P.Xiu0t[(size_t)(c + 3 * ngrp) * m + r] * sbh[c + 3 * ngrp];
+                        }
+                        for (; c < ncb; c += ngrp) a0 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
+                        spart[g * m + r] = (a0 + a1) + (a2 + a3);
                     }
                     __syncthreads();
                     if (tid < m) {
@@ -819,70 +1086,80 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
                 }
                 __syncthreads();
             }
-            // ================= P3: [M | y_u0] as 16 x 16 tiles (upper tile triangle), M = G + diag(1 / delta); Cholesky; q
-            for (size_t idx = tid; idx < (size_t)NTl * NTl * 256; idx += NT) {
-                const int tile = (int)(idx >> 8), e = (int)(idx & 255), I = tile / NTl, J = tile - I * NTl;
-                const int row = 16 * I + (e >> 4), col = 16 * J + (e & 15);
-                double v = 0.0;
-                if (I <= J && row < m) {
-                    if (col < m) v = P.G[(size_t)row * m + col] + (row == col ? 1.0 / sdel[row] : 0.0);
-                    else if (col == m) v = ss[row];
-                }
-                Yd[idx] = v;
+            FR_TICK(1);
+            // ================= P3: [M | y_u0] as 16 x 16 tiles in LDS (upper tile triangle, over B' | phi | kappa), M = G + diag(1 / delta);
+            //                   Cholesky; q
+            fr_copy_in<NT>(stl, P.Gt, ntiles * 256, tid);                       // G in the tile layout (zero padding included)
+            __syncthreads();
+            for (int r = tid; r < m; r += NT) {
+                stl[FR_TIDX(r >> 4, r >> 4, NT1) * 256 + (r & 15) * 17] += 1.0 / sdel[r];       // M = G + diag(1 / delta)
+                stl[FR_TIDX(r >> 4, NTm, NT1) * 256 + (r & 15) * 16] = ss[r];                 // rhs: column 0 of tile column NTm
             }
             __syncthreads();
-            if (fr_tile_cholesky(Yd, NTl, m, Wg, ss, sCh)) {
+            FR_TICK(2);
+            const int npd = fr_tile_cholesky_lds(stl, NTm, m, Wg, ss, sCh);
+            __syncthreads();
+            if (npd) {
                 st = FMPC_E_NOT_PD_SCHUR;
             } else {
-                // ================= P4: s = rho + q; the pass through the constant operators
+                FR_TICK(3);
+                // ================= P4: s = rho + q; the pass through the constant operators  (timing build: ticks 8 .. 11 inside it)
                 for (int c = tid; c < m; c += NT) ss[c] += srho[c];
                 __syncthreads();
                 for (int idx = tid; idx < Tm; idx += NT) { const int c = idx % m; sphi[idx] = P.g0[idx] * ss[c]; }      // v = Phibar^-1 E s
                 __syncthreads();
-                for (int idx = tid; idx < nbn; idx += NT) {                   // beta = C phi + r_p
-                    const int i = idx / n, r = idx - i * n;
-                    double v = P.betab[idx] - sbh[idx];
-                    if (i < T) {
-                        const double* vi = sphi + i * m;
-                        double a0 = 0.0, a1 = 0.0;
-                        int c = 0;
-                        for (; c + 1 < m; c += 2) { a0 += sBt[c * n + r] * vi[c]; a1 += sBt[(c + 1) * n + r] * vi[c + 1]; }
-                        if (c < m) a0 += sBt[c * n + r] * vi[c];
-                        v += a0 + a1;
-                    }
-                    sbe[idx] = v;
-                }
+                for (int idx = tid; idx < nbn; idx += NT) sbe[idx] = P.betab[idx] - sbh[idx];            // beta = C phi + r_p ...
                 __syncthreads();
+                fr_stage_product<12>(sphi, m, T, P.imgBb, n, m, wv, NW, lane, [&](int i, int r, double v) { sbe[i * n + r] += v; });   // ... + B v_i
+                __syncthreads();
+                FR_TICK(8);
                 for (int idx = tid; idx < Tm; idx += NT) sphi[idx] = P.phib_u[idx] - sphi[idx];                          // phi_u
-                for (int a = tid; a < nbn; a += NT) {                         // nu+ = Ybar^-1 beta   (Yinv symmetric: coalesced along a)
-                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                    int b = 0;
-                    for (; b + 3 < nbn; b += 4) {
-                        a0 += P.Yinv[(size_t)b * nbn + a] * sbe[b];
-                        a1 += P.Yinv[(size_t)(b + 1) * nbn + a] * sbe[b + 1];
-                        a2 += P.Yinv[(size_t)(b + 2) * nbn + a] * sbe[b + 2];
-                        a3 += P.Yinv[(size_t)(b + 3) * nbn + a] * sbe[b + 3];
+                // nu+ = Ybar^-1 beta: a wavefront per row, the lanes along the row (Yinv symmetric, row-major: coalesced), five
+                // independent loads per lane and row, rows in flight back to back
+                for (int a0 = wv * 8; a0 < nbn; a0 += NW * 8) {           // eight rows x five column steps per wavefront in flight
+                    double acc[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+                    for (int b0 = 0; b0 < nbn; b0 += 5 * 64) {
+                        double yv[8][5], xb[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int b = b0 + 64 * u + lane, bc = b < nbn ? b : nbn - 1;
+                            xb[u] = b < nbn ? sbe[bc] : 0.0;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) yv[q][u] = P.Yinv[(size_t)(a0 + q < nbn ? a0 + q : nbn - 1) * nbn + bc];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u)
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc[q] = fma(yv[q][u], xb[u], acc[q]);
                     }
-                    for (; b < nbn; ++b) a0 += P.Yinv[(size_t)b * nbn + a] * sbe[b];
-                    snup[a] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const double v = fr_wave_sum(acc[q]);
+                        if (lane == 0 && a0 + q < nbn) snup[a0 + q] = v;
+                    }
                 }
                 __syncthreads();
-                for (int idx = tid; idx < Tm; idx += NT) {                     // kappa = B' nu+_j
+                FR_TICK(9);
+                fr_stage_product<8>(snup, n, T, P.imgBk, m, n, wv, NW, lane, [&](int j, int c, double v) { skap[j * m + c] = v; });   // kappa = B' nu+_j
+                __syncthreads();
+                FR_TICK(10);
+                for (int idx = tid; idx < Tm; idx += NT) {                     // d_u = phi_u + Gf kappa   (eight loads in flight per output)
                     const int j = idx / m, c = idx - j * m;
-                    double dot = 0.0;
-                    const double* bt = sBt + c * n;
-                    const double* nj = snup + j * n;
-                    for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
-                    skap[idx] = dot;
+                    const double* gp = P.Gf + (size_t)j * T * m + c;
+                    double acc = 0.0;
+                    for (int i0 = 0; i0 < T; i0 += 8) {
+                        double gv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) gv[q] = gp[(size_t)(i0 + q < T ? i0 + q : T - 1) * m];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc += (i0 + q < T ? gv[q] : 0.0) * skap[(i0 + q < T ? i0 + q : T - 1) * m + c];
+                    }
+                    sphi[idx] += acc;
                 }
                 __syncthreads();
-                for (int idx = tid; idx < Tm; idx += NT) {                     // d_u = phi_u + Gf kappa
-                    const int j = idx / m, c = idx - j * m;
-                    double v = sphi[idx];
-                    for (int i = 0; i < T; ++i) v += P.Gf[((size_t)j * T + i) * m + c] * skap[i * m + c];
-                    sphi[idx] = v;
-                }
-                __syncthreads();
+                FR_TICK(11);
                 // ================= P5: line search (closed form of backtracking_inf_newton.m:2-11, frozen barrier gradient), update
                 double be = 0.0, e2 = 0.0;
                 for (int idx = tid; idx < Tm; idx += NT) {
@@ -920,14 +1197,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
                     else {
                         const int r = e - m, jx = j + 1;
                         double cv = snup[j * n + r];
-                        if (jx < T) {
-                            const double* nj = snup + jx * n;
-                            for (int c = 0; c < n; ++c) cv -= M.A1[c * n + r] * nj[c];
-                        }
-                        if (var2 && jx + 1 < T) {
-                            const double* nj = snup + (jx + 1) * n;
-                            for (int c = 0; c < n; ++c) cv -= M.A2[c * n + r] * nj[c];
-                        }
+                        if (jx < T) cv -= fr_ldsdot_n<NC>(sA1 + r, n, snup + jx * n, n);
+                        if (var2 && jx + 1 < T) cv -= fr_ldsdot_n<NC>(sA2 + r, n, snup + (jx + 1) * n, n);
                         if (jx == T && M.has_xf) cv += snup[T * n + r];
                         v += t * (P.phib_x[j * n + r] - cv / (jx == T ? M.Qf2[r] : M.Q2[r]));
                     }
@@ -945,21 +1216,27 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
             if (P.status) P.status[p] = st;
             if (P.iters) P.iters[p] = nsteps;
         }
+        FR_TICK(5);
     }
 }
 
 size_t fmpc_ramp_cold_lds_bytes(int n, int m, int T, int nb) {
-    const size_t nbn = (size_t)nb * n, ntl = ((size_t)m + 1 + 15) / 16;
-    const size_t d = (size_t)m * n + 4 * nbn + 3 * (size_t)m + 3 * (size_t)T * m + 16 + 512 + (16 * 17 + 16 * ntl + 16 * 8 + 16);
-    return d * sizeof(double);
+    const size_t nbn = (size_t)nb * n, ntm = ((size_t)m + 15) / 16, nt1 = ntm + 1;
+    const size_t ntiles = (ntm - 1) * nt1 - (ntm - 1) * (ntm - 2) / 2 + (nt1 - 1 - (ntm - 1)) + 1;      // FR_TIDX(ntm - 1, nt1 - 1, nt1) + 1
+    const size_t keep = 4 * nbn + 3 * (size_t)m + (size_t)T * m + 16 + 512 + (16 * 17 + 16 * nt1 + 16 * 8 + 16) + 2 * (size_t)n * n + 2;
+    const size_t uni = 2 * (size_t)T * m > ntiles * 256 ? 2 * (size_t)T * m : ntiles * 256;
+    return (keep + uni) * sizeof(double);
 }
-size_t fmpc_ramp_cold_ws_doubles(int m) { const size_t ntl = ((size_t)m + 1 + 15) / 16; return (ntl * ntl + ntl) * 256; }
+size_t fmpc_ramp_cold_ws_doubles(int m) { const size_t ntm = ((size_t)m + 15) / 16; return ntm * 256; }
 hipError_t fmpc_ramp_cold_prepare(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void*)fmpc_ramp_cold<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)fmpc_ramp_cold<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)fmpc_ramp_cold<512, 27>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 hipError_t fmpc_launch_ramp_cold(const FrColdParams& P, int grid, hipStream_t stream) {
     const size_t lds = fmpc_ramp_cold_lds_bytes(P.M.n, P.M.m, P.M.T, P.M.nb);
-    hipLaunchKernelGGL(fmpc_ramp_cold<512>, dim3(grid), dim3(512), lds, stream, P);
+    if (P.M.n == 27) hipLaunchKernelGGL((fmpc_ramp_cold<512, 27>), dim3(grid), dim3(512), lds, stream, P);
+    else hipLaunchKernelGGL((fmpc_ramp_cold<512, 0>), dim3(grid), dim3(512), lds, stream, P);
     return hipGetLastError();
 }
 

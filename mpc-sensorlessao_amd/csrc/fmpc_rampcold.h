@@ -8,7 +8,8 @@ struct FrColdParams {
     FmpcDevModel M;
     const double* dumin; const double* dumax;
     // constants per (handle, k, ramp bounds): see FmpcRampColdOut
-    const double *g0, *Gf, *phib_u, *phib_x, *gbar_u, *gbar_x, *hd, *erb, *cpb, *betab, *Yinv, *G, *Xiu0t, *y0c;
+    const double *g0, *Gf, *phib_u, *phib_x, *gbar_u, *gbar_x, *hd, *erb, *cpb, *betab, *Yinv, *G, *Gt, *Xiu0t, *y0c;
+    const double *imgBk, *imgBb;        // operand images of B' (m x n, k = state entry) and of B (n x m, k = actuator): fmpc_host_mfma_images      // Gt: G as the packed upper tile triangle of [G | 0] (FR_TIDX order)
     int batch;
     double kbar;
     const double *x0, *x0p, *w, *uprev, *nu0;
