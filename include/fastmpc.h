@@ -290,6 +290,14 @@ int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                            const double* z_init, const double* nu0, int n_newton, double k,
                            double* z_out, double* nu_out, int* status, int* iters, double* step,
                            void* stream);
+/* The ramp twin of fmpc_solve_u0_device: also leaves the first moves u0 = z(1:m) in u0_out (u_prev = U(1:nu), README.md:589).
+ * From the cold start with n_newton = 1 the step's own kernel writes them (no further launch) and z_out may be NULL: nothing
+ * of z is written then; otherwise z_out == NULL works in a scratch array of the handle. */
+int fmpc_solve_ramp_u0_device(fmpc_handle h, int batch,
+                              const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                              const double* z_init, const double* nu0, int n_newton, double k,
+                              double* z_out, double* nu_out, int* status, int* iters, double* step,
+                              double* u0_out, void* stream);
 
 /*
  * VAR(2) model identification (the step that produces A1, A2 for the solver; reference README.md:108-130):

@@ -70,6 +70,7 @@ SIGNATURES = {
     "fmpc_var_identify_device": (C.c_int, [C.c_int] * 4 + [_vp] * 5),
     "fmpc_solve_ramp": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5),
     "fmpc_solve_ramp_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 5 + [_vp]),
+    "fmpc_solve_ramp_u0_device": (C.c_int, [_vp, C.c_int] + [_vp] * 6 + [C.c_int, C.c_double] + [_vp] * 6 + [_vp]),
     "fmpc_phase_residual_device": (C.c_int, [_vp, C.c_int, C.c_longlong] + [_vp] * 4 + [_vp]),
     "fmpc_est_create": (C.c_int, [C.POINTER(_vp)] + [C.c_int] * 4 + [_vp, _vp, C.c_double, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "fmpc_est_destroy": (C.c_int, [_vp]),

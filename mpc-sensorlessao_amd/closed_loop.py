@@ -35,7 +35,7 @@ class ClosedLoop:
         self.w = torch.zeros((batch, T * n), **f64)
         self.u = [torch.zeros((batch, m), **f64) for _ in range(3)]     # ring: u[k], u[k-1], u[k-2]
         # keep_z=False: only the first moves leave the solve (z_out = NULL at the C ABI; README.md:589 applies U(1:nu) only)
-        self.z = torch.empty((batch, handle.nz), **f64) if (keep_z or ramp) else None
+        self.z = torch.empty((batch, handle.nz), **f64) if keep_z else None
         self.status = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.steps_done = 0

@@ -1991,7 +1991,7 @@ static int fmpc_ensure_ramp_cold(fmpc_handle h, double k) {
             for (int J = I; J < NT1; ++J)
                 for (int e = 0; e < 256; ++e) {
                     const int row = 16 * I + (e >> 4), col = 16 * J + (e & 15);
-                    Gt.push_back(row < m_ && col < m_ ? O.G[(size_t)row * m_ + col] : 0.0);
+                    Gt.push_back(row < m_ && col < m_ ? O.G[(size_t)row * ((m_ + 1) & ~1) + col] : 0.0);
                 }
         o_Gt = push(Gt);
     }
@@ -2010,12 +2010,14 @@ static int fmpc_ensure_ramp_cold(fmpc_handle h, double k) {
     return FMPC_OK;
 }
 
-extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
-                                      const double* x0, const double* x0_pre, const double* w, const double* u_prev,
-                                      const double* z_init, const double* nu0, int n_newton, double k,
-                                      double* z_out, double* nu_out, int* status, int* iters, double* step,
-                                      void* stream) {
-    if (!h || !x0 || !z_out || !u_prev) return FMPC_E_NULL;
+// fmpc_solve_ramp_device (u0_out == NULL) / fmpc_solve_ramp_u0_device: the first moves come from the cold-start kernel itself when
+// it takes the whole solve (budget 1), from the unpack kernel otherwise; z_out == NULL (first moves only) works in a scratch array
+static int fmpc_solve_ramp_device_impl(fmpc_handle h, int batch,
+                                       const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                                       const double* z_init, const double* nu0, int n_newton, double k,
+                                       double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                       double* u0_out, void* stream) {
+    if (!h || !x0 || (!z_out && !u0_out) || !u_prev) return FMPC_E_NULL;
     if (!h->ramp_du) return FMPC_E_UNSUPPORTED;                    // fmpc_set_ramp first
     if (!fmpc_tl_contiguous_z && fmpc_effective_zld(h) > h->T * (h->n + h->m)) return FMPC_E_UNSUPPORTED;   // padded z rows: the cold-start affine step only
     if (batch < 0) return FMPC_E_DIM;
@@ -2023,6 +2025,17 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
     if (hipSetDevice(h->device) != hipSuccess) return FMPC_E_HIP;
     std::lock_guard<std::mutex> lk(h->mu);
     const int max_iter = n_newton > 0 ? n_newton : 1000;
+    const bool z_null = z_out == nullptr;
+    const bool cold_only = z_init == nullptr && max_iter == 1 && !h->rc_disabled;   // (the cold-start kernel then needs no z array at all)
+    if (z_null && !cold_only) {
+        const size_t need = (size_t)batch * h->T * (h->n + h->m);
+        if (need > h->zs_doubles) {
+            if (h->zs) { (void)hipDeviceSynchronize(); (void)hipFree(h->zs); h->zs = nullptr; h->zs_doubles = 0; }
+            if (hipMalloc((void**)&h->zs, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+            h->zs_doubles = need;
+        }
+        z_out = h->zs;
+    }
     // one workgroup per problem in flight; the workspace holds the dense Y of each (nb n)^2 doubles
     const size_t stride = fmpc_ramp_ws_doubles(h->n, h->m, h->T, h->nb);
     // up to one problem per CU: 512-thread workgroups (latency: 0.61 instead of 0.82 ms per Newton step at n = 27,
@@ -2079,7 +2092,10 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
             if (max_iter > 1) { const int rw = ensure_general_ws(); if (rw != FMPC_OK) return rw; }
             FrColdParams P = h->rc_P;
             P.batch = batch; P.x0 = x0; P.x0p = x0_pre; P.w = w; P.uprev = u_prev; P.nu0 = nu0;
-            P.zout = z_out; P.nuout = nu_first; P.u0out = nullptr; P.status = st_first; P.iters = it_first; P.step = step;
+            if (max_iter > 1 && !z_out) {                            // (cold_only was assumed but the budget is larger: cannot happen; guard)
+                return FMPC_E_NULL;
+            }
+            P.zout = z_out; P.nuout = nu_first; P.u0out = max_iter == 1 ? u0_out : nullptr; P.status = st_first; P.iters = it_first; P.step = step;
             P.step_ld = fmpc_step_ld(n_newton); P.ws = h->rc_ws; P.ws_stride = cstride;
             if (fmpc_guard_begin(h, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
             hipError_t e = fmpc_launch_ramp_cold(P, cgrid, (hipStream_t)stream);
@@ -2088,17 +2104,48 @@ extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
                 e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_out,
                                      nu_first, max_iter, k, z_out, nu_out, st_first, it_first, step, fmpc_step_ld(n_newton),
                                      h->ramp_ws, stride, threads, (hipStream_t)stream, 1);
+            if (e == hipSuccess && max_iter > 1 && u0_out)
+                e = fmpc_launch_unpack(h->n, h->m, h->T, batch, z_out, nullptr, nullptr, u0_out, (hipStream_t)stream);
             fmpc_guard_end(h, (hipStream_t)stream);
             return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+        }
+        if (z_null && !z_out) {                                      // the cold-start form is not available after all: scratch iterate
+            const size_t need = (size_t)batch * h->T * (h->n + h->m);
+            if (need > h->zs_doubles) {
+                if (h->zs) { (void)hipDeviceSynchronize(); (void)hipFree(h->zs); h->zs = nullptr; h->zs_doubles = 0; }
+                if (hipMalloc((void**)&h->zs, need * sizeof(double)) != hipSuccess) return FMPC_E_ALLOC;
+                h->zs_doubles = need;
+            }
+            z_out = h->zs;
         }
     }
     { const int rw = ensure_general_ws(); if (rw != FMPC_OK) return rw; }
     if (fmpc_guard_begin(h, (hipStream_t)stream) != FMPC_OK) return FMPC_E_HIP;
-    const hipError_t e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_init,
-                                          nu0, max_iter, k, z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
-                                          h->ramp_ws, stride, threads, (hipStream_t)stream);
+    hipError_t e = fmpc_launch_ramp(h->dev, h->ramp_du, h->ramp_du + h->m, batch, grid, x0, x0_pre, w, u_prev, z_init,
+                                    nu0, max_iter, k, z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
+                                    h->ramp_ws, stride, threads, (hipStream_t)stream);
+    if (e == hipSuccess && u0_out)
+        e = fmpc_launch_unpack(h->n, h->m, h->T, batch, z_out, nullptr, nullptr, u0_out, (hipStream_t)stream);
     fmpc_guard_end(h, (hipStream_t)stream);
     return e == hipSuccess ? FMPC_OK : FMPC_E_HIP;
+}
+
+extern "C" int fmpc_solve_ramp_device(fmpc_handle h, int batch,
+                                      const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                                      const double* z_init, const double* nu0, int n_newton, double k,
+                                      double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                      void* stream) {
+    if (!z_out) return FMPC_E_NULL;
+    return fmpc_solve_ramp_device_impl(h, batch, x0, x0_pre, w, u_prev, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step, nullptr, stream);
+}
+
+extern "C" int fmpc_solve_ramp_u0_device(fmpc_handle h, int batch,
+                                         const double* x0, const double* x0_pre, const double* w, const double* u_prev,
+                                         const double* z_init, const double* nu0, int n_newton, double k,
+                                         double* z_out, double* nu_out, int* status, int* iters, double* step,
+                                         double* u0_out, void* stream) {
+    if (!u0_out) return FMPC_E_NULL;
+    return fmpc_solve_ramp_device_impl(h, batch, x0, x0_pre, w, u_prev, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step, u0_out, stream);
 }
 
 // host-pointer solve; u_prev != NULL selects the ramp-rate path

@@ -767,11 +767,12 @@ void fmpc_host_build_ramp_cold(const FmpcRampColdIn& In, FmpcRampColdOut& Out) {
         }
         for (int i = 0; i < nbn; ++i) Yi[(size_t)i * nbn + col] = x[i];
     }
-    Out.Yinv.assign((size_t)nbn * nbn, 0.0);
+    const int ldy = (nbn + 1) & ~1;                               // rows an even number of doubles apart (16-byte loads), pad column zero
+    Out.Yinv.assign((size_t)nbn * ldy, 0.0);
     for (int a = 0; a < nbn; ++a)
-        for (int b = 0; b < nbn; ++b) Out.Yinv[(size_t)a * nbn + b] = (double)(0.5L * (Yi[(size_t)a * nbn + b] + Yi[(size_t)b * nbn + a]));
+        for (int b = 0; b < nbn; ++b) Out.Yinv[(size_t)a * ldy + b] = (double)(0.5L * (Yi[(size_t)a * nbn + b] + Yi[(size_t)b * nbn + a]));
     for (int a = 0; a < nbn; ++a)
-        for (int b = 0; b < nbn; ++b) Yi[(size_t)a * nbn + b] = (ld)Out.Yinv[(size_t)a * nbn + b];
+        for (int b = 0; b < nbn; ++b) Yi[(size_t)a * nbn + b] = (ld)Out.Yinv[(size_t)a * ldy + b];
     // ---- Xi_u0 = P_{u0,:} Yinv (m x nbn);  G = Gf[0][0] - P_{u0,:} Yinv P_{u0,:}';  y0c = (Kbar^-1 (-[gbar; cpb]))_{u0}
     std::vector<ld> Xi((size_t)m * nbn, 0.0L);
     for (int r = 0; r < m; ++r)
@@ -780,15 +781,16 @@ void fmpc_host_build_ramp_cold(const FmpcRampColdIn& In, FmpcRampColdOut& Out) {
             if (pv == 0.0L) continue;
             for (int b = 0; b < nbn; ++b) Xi[(size_t)r * nbn + b] += pv * Yi[(size_t)a * nbn + b];
         }
-    Out.Xiu0t.assign((size_t)T * n * m, 0.0);
+    const int ldg = (m + 1) & ~1;                                 // (rows of G and of Xiu0t an even number of doubles apart: 16-byte loads)
+    Out.Xiu0t.assign((size_t)T * n * ldg, 0.0);
     for (int col = 0; col < T * n; ++col)
-        for (int r = 0; r < m; ++r) Out.Xiu0t[(size_t)col * m + r] = (double)Xi[(size_t)r * nbn + col];
-    Out.G.assign((size_t)m * m, 0.0);
+        for (int r = 0; r < m; ++r) Out.Xiu0t[(size_t)col * ldg + r] = (double)Xi[(size_t)r * nbn + col];
+    Out.G.assign((size_t)m * ldg, 0.0);
     for (int r = 0; r < m; ++r)
         for (int c = r; c < m; ++c) {
             ld v = r == c ? Gl[((size_t)0 * T + 0) * m + r] : 0.0L;
             for (int b = 0; b < nbn; ++b) v -= Xi[(size_t)r * nbn + b] * P[(size_t)c * nbn + b];
-            Out.G[(size_t)r * m + c] = (double)v; Out.G[(size_t)c * m + r] = (double)v;
+            Out.G[(size_t)r * ldg + c] = (double)v; Out.G[(size_t)c * ldg + r] = (double)v;
         }
     // y0c: f_z = -gbar, f_nu = -cpb:  phi = phibar, nu = Yinv (C phibar + cpb) = Yinv betab, z_u0 = phibar_u0 - P_{u0,:} nu
     Out.y0c.assign(m, 0.0);

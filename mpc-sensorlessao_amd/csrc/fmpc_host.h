@@ -165,9 +165,9 @@ struct FmpcRampColdOut {
     std::vector<double> erb;            // [m]         k (1/du_max^2 + 1/du_min^2): minus the off-diagonal of k P'DP between stages
     std::vector<double> cpb;            // [nb n]      r_p at the start point for b = 0 (terminal rows: xbar - xf)
     std::vector<double> betab;          // [nb n]      C phibar + cpb
-    std::vector<double> Yinv;           // [nb n][nb n] symmetric
-    std::vector<double> G;              // [m][m] symmetric
-    std::vector<double> Xiu0t;          // [T n][m]    column-major transpose: Xiu0t[col m + r] = d (Kbar^-1 f)_{u_0, r} / d bhat_col
+    std::vector<double> Yinv;           // [nb n][ldy] symmetric, rows ldy = nb n rounded up to even apart (pad column zero)
+    std::vector<double> G;              // [m][ldg] symmetric, ldg = m rounded up to even (pad column zero)
+    std::vector<double> Xiu0t;          // [T n][ldg]  column-major transpose: Xiu0t[col ldg + r] = d (Kbar^-1 f)_{u_0, r} / d bhat_col
     std::vector<double> y0c;            // [m]         (Kbar^-1 (-[gbar ; cpb]))_{u_0}
 };
 void fmpc_host_build_ramp_cold(const FmpcRampColdIn& In, FmpcRampColdOut& Out);

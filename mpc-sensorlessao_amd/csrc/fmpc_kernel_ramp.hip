@@ -866,6 +866,36 @@ __device__ __forceinline__ void fr_copy_in(double* dst, const double* __restrict
         for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT; if (i < cnt) dst[i] = v[u]; }
     }
 }
+// part[g][r] = sign * sum over the columns c = g, g + G, ... < ncols of At[c ld + r] x[c], for r < rows and the G = min(8, NT / pairs)
+// column groups (pairs = ceil(rows / 2)): a thread owns a PAIR of rows (one 16-byte load per column: ld even, At 16-byte aligned)
+// of one group, eight loads in flight, no cross-lane reduction; the caller adds the G partial sums per row.  Returns G.
+// (Measured on the 270 x 270 product of the ramp cold form: a wavefront per row with shuffles to sum the lanes took 17 us however
+// the loads were arranged -- the eight reductions per row block were the time -- against ~5 us this way.)
+template <int NT>
+__device__ __forceinline__ int fr_matvec_pairs(const double* __restrict__ At, int ld, int rows, int ncols, const double* x, double sign,
+                                               double* part, int pld, int tid) {
+    typedef double d2r __attribute__((ext_vector_type(2)));
+    const int pairs = (rows + 1) >> 1;
+    int G = NT / pairs; if (G > 8) G = 8; if (G < 1) G = 1;
+    for (int t = tid; t < G * pairs; t += NT) {                       // (one pass unless pairs > NT)
+        const int g = t / pairs, r = 2 * (t - g * pairs);
+        double ax = 0.0, ay = 0.0;
+        for (int c0 = g; c0 < ncols; c0 += 8 * G) {
+            d2r v[8]; double xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * G, cc = c < ncols ? c : c0;
+                v[u] = *(const d2r*)(At + (size_t)cc * ld + r);
+                xv[u] = c < ncols ? x[cc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ax = fma(v[u].x, xv[u], ax); ay = fma(v[u].y, xv[u], ay); }
+        }
+        part[(size_t)g * pld + r] = sign * ax;
+        if (r + 1 < pld) part[(size_t)g * pld + r + 1] = sign * ay;
+    }
+    return G;
+}
 // sum_c a[c * as] * x[c] over LDS operands; NC > 0: the length at compile time (straight-line: every read requested up front)
 template <int NC>
 __device__ __forceinline__ double fr_ldsdot_n(const double* a, int as, const double* x, int cnt) {
@@ -1044,45 +1074,20 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
         } else if (badsum > 0.0) {
             st = FMPC_E_NOT_PD_PHI;
         } else {
-            // ================= P2: y_u0 = y0c - G rho + Xi_u0 bhat   (rows split over up to 8 thread groups, summed in a fixed order)
+            // ================= P2: y_u0 = y0c - G rho + Xi_u0 bhat   (row pairs x column groups, summed in a fixed order)
             {
                 const int ncb = P.w ? Tn : ((var2 ? 2 : 1) * n < Tn ? (var2 ? 2 : 1) * n : Tn);   // columns of bhat that can be non-zero
-                if (m <= NT) {
-                    const int ngrp = NT / m < 8 ? NT / m : 8;
-                    const int g = tid / m, r = tid - g * m;
-                    if (g < ngrp) {
-                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                        int c = g;
-                        for (; c + 3 * ngrp < m; c += 4 * ngrp) {
-                            a0 -= P.G[(size_t)c * m + r] * srho[c];
-                            a1 -= P.G[(size_t)(c + ngrp) * m + r] * srho[c + ngrp];
-                            a2 -= P.G[(size_t)(c + 2 * ngrp) * m + r] * srho[c + 2 * ngrp];
-                            a3 -= P.G[(size_t)(c + 3 * ngrp) * m + r] * srho[c + 3 * ngrp];
-                        }
-                        for (; c < m; c += ngrp) a0 -= P.G[(size_t)c * m + r] * srho[c];
-                        c = g;
-                        for (; c + 3 * ngrp < ncb; c += 4 * ngrp) {
-                            a0 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
-                            a1 += P.Xiu0t[(size_t)(c + ngrp) * m + r] * sbh[c + ngrp];
-                            a2 += P.Xiu0t[(size_t)(c + 2 * ngrp) * m + r] * sbh[c + 2 * ngrp];
-                            a3 += P.Xiu0t[(size_t)(c + 3 * ngrp) * m + r] * sbh[c + 3 * ngrp];
-                        }
-                        for (; c < ncb; c += ngrp) a0 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
-                        spart[g * m + r] = (a0 + a1) + (a2 + a3);
-                    }
-                    __syncthreads();
-                    if (tid < m) {
-                        double v = P.y0c[tid];
-                        for (int q = 0; q < ngrp; ++q) v += spart[q * m + tid];
-                        ss[tid] = v;
-                    }
-                } else {
-                    for (int r = tid; r < m; r += NT) {
-                        double a0 = 0.0, a1 = 0.0;
-                        for (int c = 0; c < m; ++c) a0 -= P.G[(size_t)c * m + r] * srho[c];
-                        for (int c = 0; c < ncb; ++c) a1 += P.Xiu0t[(size_t)c * m + r] * sbh[c];
-                        ss[r] = P.y0c[r] + (a0 + a1);
-                    }
+                const int ldg = (m + 1) & ~1;
+                double* pg = uni;                          // [8][ldg] partial sums of -G rho, then [8][ldg] of Xi_u0 bhat (the region is free here)
+                double* px = uni + 8 * (size_t)ldg;
+                const int g1 = fr_matvec_pairs<NT>(P.G, ldg, m, m, srho, -1.0, pg, ldg, tid);
+                const int g2 = fr_matvec_pairs<NT>(P.Xiu0t, ldg, m, ncb, sbh, 1.0, px, ldg, tid);
+                __syncthreads();
+                for (int r = tid; r < m; r += NT) {
+                    double v = P.y0c[r];
+                    for (int q = 0; q < g1; ++q) v += pg[(size_t)q * ldg + r];
+                    for (int q = 0; q < g2; ++q) v += px[(size_t)q * ldg + r];
+                    ss[r] = v;
                 }
                 __syncthreads();
             }
@@ -1114,30 +1119,16 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 2 : 1) fmpc_ramp_cold(FrColdPa
                 __syncthreads();
                 FR_TICK(8);
                 for (int idx = tid; idx < Tm; idx += NT) sphi[idx] = P.phib_u[idx] - sphi[idx];                          // phi_u
-                // nu+ = Ybar^-1 beta: a wavefront per row, the lanes along the row (Yinv symmetric, row-major: coalesced), five
-                // independent loads per lane and row, rows in flight back to back
-                for (int a0 = wv * 8; a0 < nbn; a0 += NW * 8) {           // eight rows x five column steps per wavefront in flight
-                    double acc[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-                    for (int b0 = 0; b0 < nbn; b0 += 5 * 64) {
-                        double yv[8][5], xb[5];
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) {
-                            const int b = b0 + 64 * u + lane, bc = b < nbn ? b : nbn - 1;
-                            xb[u] = b < nbn ? sbe[bc] : 0.0;
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) yv[q][u] = P.Yinv[(size_t)(a0 + q < nbn ? a0 + q : nbn - 1) * nbn + bc];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 5; ++u)
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) acc[q] = fma(yv[q][u], xb[u], acc[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const double v = fr_wave_sum(acc[q]);
-                        if (lane == 0 && a0 + q < nbn) snup[a0 + q] = v;
+                // nu+ = Ybar^-1 beta (Yinv symmetric: its rows are its columns)
+                {
+                    const int ldy = (nbn + 1) & ~1;
+                    double* py = skap + Tm;                                    // [8][ldy] behind phi | kappa (the tiles are done with)
+                    const int gy = fr_matvec_pairs<NT>(P.Yinv, ldy, nbn, nbn, sbe, 1.0, py, ldy, tid);
+                    __syncthreads();
+                    for (int a1 = tid; a1 < nbn; a1 += NT) {
+                        double v = 0.0;
+                        for (int q = 0; q < gy; ++q) v += py[(size_t)q * ldy + a1];
+                        snup[a1] = v;
                     }
                 }
                 __syncthreads();
@@ -1224,7 +1215,10 @@ size_t fmpc_ramp_cold_lds_bytes(int n, int m, int T, int nb) {
     const size_t nbn = (size_t)nb * n, ntm = ((size_t)m + 15) / 16, nt1 = ntm + 1;
     const size_t ntiles = (ntm - 1) * nt1 - (ntm - 1) * (ntm - 2) / 2 + (nt1 - 1 - (ntm - 1)) + 1;      // FR_TIDX(ntm - 1, nt1 - 1, nt1) + 1
     const size_t keep = 4 * nbn + 3 * (size_t)m + (size_t)T * m + 16 + 512 + (16 * 17 + 16 * nt1 + 16 * 8 + 16) + 2 * (size_t)n * n + 2;
-    const size_t uni = 2 * (size_t)T * m > ntiles * 256 ? 2 * (size_t)T * m : ntiles * 256;
+    const size_t ph4 = 2 * (size_t)T * m + 8 * ((nbn + 1) & ~(size_t)1);     // [phi | kappa | partial sums of the Yinv product]
+    const size_t ph2 = 16 * (((size_t)m + 1) & ~(size_t)1);                    // partial sums of the two products of y_u0
+    size_t uni = ph4 > ntiles * 256 ? ph4 : ntiles * 256;
+    if (ph2 > uni) uni = ph2;
     return (keep + uni) * sizeof(double);
 }
 size_t fmpc_ramp_cold_ws_doubles(int m) { const size_t ntm = ((size_t)m + 15) / 16; return ntm * 256; }

@@ -218,8 +218,8 @@ class FastMPCHandle:
         chk(x0, self.n, "x0"); chk(x0_pre, self.n, "x0_pre"); chk(w, self.T * self.n, "w")
         chk(z_init, self.nz, "z_init"); chk(nu0, self.nu_len, "nu0"); chk(u_prev, self.m, "u_prev")
         n_newton = 0 if n_newton is None else int(n_newton)
-        if not want_z and (u0_out is None or u_prev is not None):
-            raise FastMPCError(_lib.FMPC_E_NULL, "want_z=False needs u0_out (and no ramp rows)")
+        if not want_z and u0_out is None:
+            raise FastMPCError(_lib.FMPC_E_NULL, "want_z=False needs u0_out")
         if z_out is None and want_z:
             ld_ = getattr(self, "_z_ld", 0)
             z_out = (torch.empty((batch, ld_), dtype=torch.float64, device=dev)[:, :self.nz] if ld_ > self.nz
@@ -255,12 +255,14 @@ class FastMPCHandle:
 
     def _solve_device_call(self, batch, p, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step, u_prev, u0_out,
                            stream, zld=0):
-        if u_prev is not None:
+        if u_prev is not None and u0_out is not None:
+            rc = self._lib.fmpc_solve_ramp_u0_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
+                                                     p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
+                                                     p(iters), p(step), p(u0_out), stream)
+        elif u_prev is not None:
             rc = self._lib.fmpc_solve_ramp_device(self._h, batch, p(x0), p(x0_pre), p(w), p(u_prev), p(z_init),
                                                   p(nu0), n_newton, float(k), p(z_out), p(nu_out), p(status),
                                                   p(iters), p(step), stream)
-            if rc == _lib.FMPC_OK and u0_out is not None:
-                rc = self._lib.fmpc_unpack_device(self._h, batch, p(z_out), None, None, p(u0_out), stream)
         else:
             rc = self._lib.fmpc_solve_u0_device_ld(self._h, batch, p(x0), p(x0_pre), p(w), p(z_init), p(nu0),
                                                    n_newton, float(k), p(z_out), p(nu_out), p(status),

@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     FmpcRampColdOut O;
     fmpc_host_build_ramp_cold(In, O);
     if (!O.valid) return fail("builder reports invalid");
-    if ((int)O.G.size() != m * m || (int)O.Yinv.size() != nbn * nbn || (int)O.Xiu0t.size() != T * n * m) return fail("sizes");
+    if ((int)O.G.size() != m * ((m + 1) & ~1) || (int)O.Yinv.size() != nbn * ((nbn + 1) & ~1) || (int)O.Xiu0t.size() != T * n * ((m + 1) & ~1)) return fail("sizes");
 
     double worst = 0.0;
     for (int prob = 0; prob < 3; ++prob) {
@@ -94,12 +94,12 @@ int main(int argc, char** argv) {
         std::vector<double> yu0(m);
         for (int r = 0; r < m; ++r) {
             double v = O.y0c[r];
-            for (int c = 0; c < m; ++c) v -= O.G[(size_t)c * m + r] * rho[c];
-            for (int col = 0; col < T * n; ++col) v += O.Xiu0t[(size_t)col * m + r] * bh[col];
+            for (int c = 0; c < m; ++c) v -= O.G[(size_t)c * ((m + 1) & ~1) + r] * rho[c];
+            for (int col = 0; col < T * n; ++col) v += O.Xiu0t[(size_t)col * ((m + 1) & ~1) + r] * bh[col];
             yu0[r] = v;
         }
         std::vector<ld> Mq((size_t)m * m), q(m);
-        for (int r = 0; r < m; ++r) { for (int c = 0; c < m; ++c) Mq[(size_t)r * m + c] = O.G[(size_t)r * m + c]; Mq[(size_t)r * m + r] += 1.0L / delta[r]; q[r] = yu0[r]; }
+        for (int r = 0; r < m; ++r) { for (int c = 0; c < m; ++c) Mq[(size_t)r * m + c] = O.G[(size_t)r * ((m + 1) & ~1) + c]; Mq[(size_t)r * m + r] += 1.0L / delta[r]; q[r] = yu0[r]; }
         if (!solve_dense(Mq, q, m)) return fail("M singular");
         std::vector<double> sv(m), phiu((size_t)T * m), beta(nbn), nup(nbn), kap((size_t)T * m), dz(Nz);
         for (int c = 0; c < m; ++c) sv[c] = rho[c] + (double)q[c];
@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
             if (i < T) for (int c = 0; c < m; ++c) v += bt[(size_t)c * n + r] * O.g0[(size_t)i * m + c] * sv[c];
             beta[a] = v;
         }
-        for (int a = 0; a < nbn; ++a) { double v = 0.0; for (int b = 0; b < nbn; ++b) v += O.Yinv[(size_t)b * nbn + a] * beta[b]; nup[a] = v; }
+        for (int a = 0; a < nbn; ++a) { double v = 0.0; for (int b = 0; b < nbn; ++b) v += O.Yinv[(size_t)b * ((nbn + 1) & ~1) + a] * beta[b]; nup[a] = v; }
         for (int j = 0; j < T; ++j) for (int c = 0; c < m; ++c) { double v = 0.0; for (int r = 0; r < n; ++r) v += bt[(size_t)c * n + r] * nup[(size_t)j * n + r]; kap[(size_t)j * m + c] = v; }
         for (int j = 0; j < T; ++j) {
             for (int c = 0; c < m; ++c) {
