@@ -15,6 +15,8 @@
   aoloop1         the loop with its estimator, one realisation: residual screen, PSF windows (columns split over two workgroups), finish by quarters,
                   combine, first-move kernel, flag-mode launch
   estimator256    phase-diversity estimator, 256 screens of 512 x 512 per call (fmpc_est_psf<4>, fmpc_est_finish, fmpc_est_combine)
+  config0_ramp    configs[0]: VAR(1), T = 10, ramp-rate rows: 200 SEQUENTIAL closed-loop steps of one realisation (loop inputs + fmpc_ramp_cold,
+                  the cold-start step in its Woodbury form, writing the first moves itself), then the 200-problem replay batch with budgets 1 and 5
   budget5         configs[1] with the Newton budget of the reference's test (5) and the exit test: panel-path first step, decision
                   + compaction, continuation of the ~9 % that go on by the tiled kernel"""
 import importlib, os, sys
@@ -50,6 +52,27 @@ if target == "estimator256":
     torch.cuda.synchronize()
     print(target, "ad_est norm", float(ad.norm()))
     est.close()
+    sys.exit(0)
+if target == "config0_ramp":
+    T0 = 10
+    m0 = pkg.synthetic.make_model(27, 144, T0, var_order=1)
+    h0 = pkg.FastMPCHandle(m0["A1"], None, m0["B"], m0["Q"], m0["R"], m0["Qf"], m0["u_min"], m0["u_max"], m0["x_min"], m0["x_max"], T0, var_order=1)
+    h0.set_ramp(-0.2121 * np.ones(144), 0.2121 * np.ones(144))
+    a0 = pkg.synthetic.make_realisation(m0, r=0, steps=201)[1:201]
+    ta0 = torch.from_numpy(np.ascontiguousarray(a0[:, None, :])).to(dev)
+    loop0 = pkg.ClosedLoop(h0, 1, n_newton=1, k=1e-2, ramp=True, keep_z=False)
+    for s_ in range(200):
+        loop0.step(ta0[s_])
+    torch.cuda.synchronize()
+    d0 = pkg.synthetic.make_replay_batch(m0, r=0, steps=200)
+    tx0 = torch.from_numpy(d0["x0"]).to(dev); tn0 = torch.from_numpy(np.ascontiguousarray(d0["nu0"][:, :T0 * 27])).to(dev)
+    tup = torch.from_numpy(0.05 * np.random.default_rng(7).standard_normal((200, 144))).to(dev)
+    for nw0 in (1, 5):
+        for _ in range(reps):
+            z0, s0, i0 = h0.solve_device(tx0, None, None, None, tn0, nw0, 1e-2, u_prev=tup)
+    torch.cuda.synchronize()
+    print(target, "form", h0.last_dual_form(), "loop status", int(loop0.status.abs().sum()), "iters", int(i0.sum()))
+    h0.close()
     sys.exit(0)
 n, m, T, B = (65, 144, 60, 1024) if target == "configs4" else (27, 144, 30, 512 if target in ("batch512", "dense_w512", "closed512", "closed512u0") else (64 if target == "walk64" else 2000))
 model = pkg.synthetic.make_model(n, m, T)

@@ -84,6 +84,13 @@ def test_config0_200_sequential_steps_with_ramp_rows(pkg, gpu):
     errs = [np.abs(U0[s] - ref["u0"][s]).max() / max(np.abs(ref["u0"][s]).max(), 1e-2) for s in range(steps)]
     assert max(errs) <= 1e-7, (int(np.argmax(errs)), max(errs))
     assert rel_err(X0, ref["x0"]) <= 1e-8
+    # round 5: every step is the cold-start step in its Woodbury form (fmpc_ramp_cold); with first moves only (keep_z=False:
+    # z_out = NULL at fmpc_solve_ramp_u0_device) the step's own kernel writes u0 and nothing of z -- the same trajectory bit for bit
+    assert h.last_dual_form() == 5
+    loop2 = pkg.ClosedLoop(h, 1, n_newton=1, k=1e-2, ramp=True, keep_z=False)
+    U2, X2 = loop2.run(torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda:0")))
+    torch.cuda.synchronize()
+    assert loop2.z is None and np.array_equal(U2.cpu().numpy()[:, 0], U0) and np.array_equal(X2.cpu().numpy()[:, 0], X0)
     h.close()
 
 
