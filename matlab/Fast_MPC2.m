@@ -39,6 +39,25 @@ classdef Fast_MPC2
             for i = 1:numel(ks), z = obj.solve_once(z, 0, ks(i)); end
             x_opt = z;
         end
+        function U0 = first_moves(obj, X0, X0_pre, W, nw, k)
+            % NOT in the reference class: the batch form of "solve, then u_prev = U(1:nu)" (README.md:555,589) for a REPLAY of many
+            % timesteps / realisations with this object's model -- X0, X0_pre: n x batch, W: T*n x batch or [] -- through
+            % fmpc_create + fmpc_solve_u0 (include/fastmpc.h): only the first moves (m x batch) come back over PCIe, not the
+            % N_z x batch iterates (2.3 MB instead of 82 MB per 2000 problems at (27,144,30)).  Cold start (x_init is ignored);
+            % nu0 = NULL (zeros) -- the dual start only enters the step-length test (SURVEY App. B-D5).
+            n = size(obj.Q,1); m = size(obj.R,1); batch = size(X0,2);
+            P = @(a) libpointer('doublePtr', a);
+            ph = libpointer('voidPtrPtr');
+            rc = calllib('libfastmpc', 'fmpc_create', ph, n, m, obj.T, 2, P(obj.A1), P(obj.A2), P(obj.B), P(obj.Q), P(obj.R), P(obj.Qf), ...
+                         P(obj.q), P(obj.r), P(obj.qf), P(obj.u_min), P(obj.u_max), P(obj.x_min), P(obj.x_max), P(obj.x_final), obj.device);
+            if rc < 0, error('Fast_MPC2:create', '%s', calllib('libfastmpc', 'fmpc_strerror', rc)); end
+            pu = libpointer('doublePtr', zeros(m, batch));
+            rc = calllib('libfastmpc', 'fmpc_solve_u0', ph.Value, batch, P(X0), P(X0_pre), P(W), P([]), P([]), nw, k, P([]), pu, ...
+                         libpointer('int32Ptr', []), libpointer('int32Ptr', []));
+            calllib('libfastmpc', 'fmpc_destroy', ph.Value);
+            if rc < 0, error('Fast_MPC2:solve', '%s', calllib('libfastmpc', 'fmpc_strerror', rc)); end
+            U0 = pu.Value;
+        end
         % ---- dense builders of the reference class (VAR_2/Fast_MPC2.m:56-67).  The device path never forms H, P, C;
         % these are host-side MATLAB, written from the index maps of the solver (z = [u0;x1;u1;x2;...;u_{T-1};x_T]) and
         % kept so that callers of objective_function / inequality_const / equality_const / fomulate_mpc keep working.
