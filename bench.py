@@ -45,7 +45,7 @@ if ROOT not in sys.path:
 
 N_MODES, N_ACT, HORIZON, BATCH = 27, 144, 30, 2000
 N_NEWTON, K_BAR = 1, 1e-2    # README.md:551-552
-FP64_PEAK_TFLOPS = 78.6      # MI355X datasheet fp64 vector = matrix peak (scripts/mfma_f64_rate.hip measures 77.7)
+FP64_PEAK_TFLOPS = 78.6      # MI355X datasheet fp64 vector = matrix peak (scripts/probes/mfma_f64_rate.hip measures 77.7)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix = vector peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s
 MIN_LEG_MS = 50.0            # every timed GPU leg lasts at least this long

@@ -1377,7 +1377,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 }
                 if (ph == 2 && h->small_tiled) {
                     // the continuation is a handful of problems per CU at most: the tiled kernel (4 wavefronts per problem)
-                    // finishes one in 0.45 ms where the one-wavefront kernel needs 1.0 ms (scripts/latency_190.py)
+                    // finishes one in 0.45 ms where the one-wavefront kernel needs 1.0 ms (round 2 measurement)
                     const int last = ((volatile int*)h->pn_cnt_host)[1];
                     const int hint = last >= 0 ? last + last / 2 + 16 : 0;
                     const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, nullptr, nu0, n_newton, k, z_out, nu_out, status, iters,
@@ -1402,7 +1402,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         if (mode == 0 && h->small_tiled && batch <= 1024) {
             // Every problem factors its own Schur complement and there are at most 4 problems per CU: the tiled kernel's
             // 2 (4) wavefronts per problem finish a problem in 0.5 (0.4) ms where the one-wavefront kernel needs 1.0 ms;
-            // beyond 1024 problems the one-wavefront kernel's 8 problems per CU win (measured: scripts/latency_190.py)
+            // beyond 1024 problems the one-wavefront kernel's 8 problems per CU win (measured in round 2)
             const int rc_t = fmpc_solve_tiled(h, 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k, z_out, nu_out, status, iters, step,
                                               u0_out, (hipStream_t)stream, batch <= 512 ? h->small_nw : 2);
             if (rc_t != FMPC_E_UNSUPPORTED) return rc_t;

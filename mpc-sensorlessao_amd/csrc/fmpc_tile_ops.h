@@ -18,7 +18,7 @@ template <> struct FtT<double> {
     typedef ft_d4 v4;
     static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ v4 mfma_sub(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1); }   // c - a b (neg:[1,0,0])
-    // accumulator layout (measured, scripts/mfma_f64_probe.hip): register r of lane (c, g) is row g + 4 r, column c
+    // accumulator layout (measured, scripts/probes/mfma_f64_probe.hip): register r of lane (c, g) is row g + 4 r, column c
     static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
     static constexpr int kg(int k) { return k & 3; }
     static constexpr int kr(int k) { return k >> 2; }

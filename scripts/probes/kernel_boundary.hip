@@ -1,7 +1,7 @@
 // Microbenchmark: what a kernel costs beyond the lifetime of its wavefronts, as a function of the bytes it wrote.
 // A streaming-write kernel records the first start and the last end of its wavefronts (constant 100 MHz clock); the launch
 // is also timed with HIP events in a stream of back-to-back launches.
-//   hipcc --offload-arch=gfx950 -O3 scripts/kernel_boundary.hip -o scripts/kernel_boundary && scripts/kernel_boundary
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/kernel_boundary.hip -o scripts/probes/kernel_boundary && scripts/probes/kernel_boundary
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void writer(double* out, size_t n_per_block, unsigned long long* tmin, unsigned long long* tmax) {

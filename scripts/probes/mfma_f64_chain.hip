@@ -1,5 +1,5 @@
 // Microbenchmark: v_mfma_f64_16x16x4_f64 issue rate vs. the number of independent accumulator chains and waves per SIMD.
-// Build: hipcc --offload-arch=gfx950 -O3 scripts/mfma_f64_chain.hip -o scripts/mfma_f64_chain ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_f64_chain.hip -o scripts/probes/mfma_f64_chain ; run on the GPU box.
 // Result (MI355X): 64 cycles per MFMA, a single wave per SIMD already saturates the pipe, independent accumulator
 // chains change nothing; with several waves per SIMD the oldest wave is served first.
 #include <hip/hip_runtime.h>

@@ -1,6 +1,6 @@
 // Microbenchmark: v_mfma_f64_16x16x4_f64 fed from LDS (B operand) and from global memory (A operand), the inner loop of the
 // dense-form product (fmpc_kernel_inv.hip).  Prints cycles per MFMA and wave for a few feeding patterns.
-//   hipcc --offload-arch=gfx950 -O3 scripts/mfma_lds_feed.hip -o scripts/mfma_lds_feed && scripts/mfma_lds_feed
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_lds_feed.hip -o scripts/probes/mfma_lds_feed && scripts/probes/mfma_lds_feed
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
