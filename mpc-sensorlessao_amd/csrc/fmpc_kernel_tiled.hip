@@ -1347,13 +1347,10 @@ static hipError_t ft_prepare(size_t lds) {
         return hipErrorInvalidValue;                                                           \
     }                                                                                          \
     /* the AO sizes (n = 27 Zernike modes; n = 65: radial order 10) with their block structure at compile time, for the   \
-       default wavefront counts only.  (<double, 2, 4, 11> is deliberately absent: that instance came out wrong in several  \
-       builds -- deterministically, and differently from build to build -- while the same source with the block structure  \
-       at run time, and every other instance, passes; ROCm 7.2 hipcc.  Non-default wave counts use the run-time form.    \
-       Since the phases are separate functions it agrees bitwise with the run-time form (tests/test_gpu_tiled.py, stress   \
-       test); FMPC_TILED_CT_NW4=1 switches it in per launch for such checks only.)                                         */ \
+       default wavefront counts only; other wavefront counts use the run-time form.  (An instance <double, 2, 4, 11> existed  \
+       until round 5: miscompiled by round 2's monolithic build, never root-caused, bitwise equal to the run-time form since  \
+       the phases are separate functions, 3-4 % faster -- removed rather than kept as a switch; docs/DESIGN_HISTORY.md.)    */ \
     if (!is_float && nlast == 11 && NB == 2 && NW == 2) return fn<double, 2, 2, 11>(__VA_ARGS__);  \
-    if (!is_float && nlast == 11 && NB == 2 && NW == 4 && ft_try_ct_nw4()) return fn<double, 2, 4, 11>(__VA_ARGS__);  \
     if (is_float && nlast == 11 && NB == 2 && NW == 4) return fn<float, 2, 4, 11>(__VA_ARGS__);    \
     if (is_float && nlast == 1 && NB == 5 && NW == 8) return fn<float, 5, 8, 1>(__VA_ARGS__);      \
     if (is_float && nlast == 1 && NB == 5 && NW == 4) return fn<float, 5, 4, 1>(__VA_ARGS__);      \
@@ -1405,13 +1402,10 @@ bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* N
     return true;
 }
 size_t fmpc_tiled_lds_bytes(int NB, int mb, int NW, int is_float, int nb, size_t pr_doubles) { return ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb, pr_doubles).total; }
-static bool ft_try_ct_nw4();
 static int ft_nlast(int n, int NB) {
     const char* e = getenv("FMPC_TILED_GENERIC");                 // experiments: the instance with the block structure at run time
     return (e && e[0] == '1') ? -1 : n - 16 * (NB - 1);
 }
-// experiments only: the instance <double, 2, 4, 11> that is out of production (see FT_DISPATCH); scripts/tiled_ct_probe.py
-static bool ft_try_ct_nw4() { const char* e = getenv("FMPC_TILED_CT_NW4"); return e && e[0] == '1'; }
 hipError_t fmpc_tiled_prepare(int n, int NB, int NW, int is_float, size_t lds_bytes, int denseR) {
     const int nlast = ft_nlast(n, NB);
     FT_DISPATCH(ft_prepare, lds_bytes)

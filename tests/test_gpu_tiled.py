@@ -314,15 +314,12 @@ def test_many_seed_stress_of_the_production_instances(pkg, gpu, monkeypatch):
         return h_
     # (a handle created with FMPC_SMALL_TILED_NW=4 takes the tiled kernel with FOUR wavefronts per problem for explicit-start batches <= 512; FMPC_TILED=1
     #  forces the tiled kernel with its default of two.  FMPC_TILED_NW is read at the first tiled solve, not at create time.)
-    # "tiled_nw4_ct": the instance <double,2,4,11> itself (block structure at compile time), switched in per launch by
-    # FMPC_TILED_CT_NW4=1.  Since the phases of the kernel became separate functions with their own register allocations
-    # (round 3: the monolithic function spilled 928 bytes per lane) it agrees with the others on every seed; it stays out
-    # of production until that has held over more builds (3-4 % faster than the run-time form, no more).
+    # (Round 5: the compile-time instance <double,2,4,11> and its switch are gone; four wavefronts per problem = the run-time form.)
     # Round 4: the default for small batches is TWO wavefronts per problem ("default": what production takes); four are opt-in
     # (FMPC_SMALL_TILED_NW=4 at create time / fmpc_set_small_batch_kernel(h, 4)) and stay under this stress test.
-    hs = {"default": make({}), "tiled_nw4": make({"FMPC_SMALL_TILED_NW": "4"}), "tiled_nw4_ct": make({"FMPC_SMALL_TILED_NW": "4"}),
+    hs = {"default": make({}), "tiled_nw4": make({"FMPC_SMALL_TILED_NW": "4"}),
           "tiled_nw2": make({"FMPC_TILED": "1"}), "wave": make({"FMPC_NO_SMALL_TILED": "1"})}
-    want_nw = {"default": 2, "tiled_nw4": 4, "tiled_nw4_ct": 4, "tiled_nw2": 2}
+    want_nw = {"default": 2, "tiled_nw4": 4, "tiled_nw2": 2}
     worst = 0.0
     for seed in range(24):
         rng = np.random.default_rng(1000 + seed)
@@ -336,21 +333,17 @@ def test_many_seed_stress_of_the_production_instances(pkg, gpu, monkeypatch):
         for name, h in hs.items():
             nu = torch.empty((B, T * n), dtype=torch.float64, device=dev)
             stp = torch.empty((B, 2), dtype=torch.float64, device=dev)
-            if name == "tiled_nw4_ct":
-                monkeypatch.setenv("FMPC_TILED_CT_NW4", "1")
             z, st, it = h.solve_device(x0, x0p, None, zi, nu0, 2, 1e-2, nu_out=nu, step=stp)
             torch.cuda.synchronize()
-            monkeypatch.delenv("FMPC_TILED_CT_NW4", raising=False)
             out[name] = (z.cpu().numpy(), nu.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), stp.cpu().numpy())
-        want = {"default": pkg._lib.FMPC_PATH_TILED, "tiled_nw4": pkg._lib.FMPC_PATH_TILED, "tiled_nw4_ct": pkg._lib.FMPC_PATH_TILED,
+        want = {"default": pkg._lib.FMPC_PATH_TILED, "tiled_nw4": pkg._lib.FMPC_PATH_TILED,
                 "tiled_nw2": pkg._lib.FMPC_PATH_TILED, "wave": pkg.FMPC_PATH_WAVE}
         for name, h in hs.items():
             assert h.last_dispatch()[0] == want[name]
             assert name == "wave" or h.last_tiled_wavefronts() == want_nw[name], (name, h.last_tiled_wavefronts())
         ref = out["wave"]
         assert int((ref[2] < 0).sum()) == 0
-        assert np.array_equal(out["tiled_nw4_ct"][0], out["tiled_nw4"][0]) and np.array_equal(out["tiled_nw4_ct"][1], out["tiled_nw4"][1]), seed
-        for name in ("default", "tiled_nw4", "tiled_nw4_ct", "tiled_nw2"):
+        for name in ("default", "tiled_nw4", "tiled_nw2"):
             o = out[name]
             assert np.array_equal(o[2], ref[2]) and np.array_equal(o[3], ref[3]), (seed, name)
             assert np.array_equal(canon_steps(o[4]), canon_steps(ref[4])), (seed, name)
