@@ -740,6 +740,31 @@ def _main(real_out):
             dt = time.perf_counter() - t0
         assert int((loop0.status < 0).sum()) == 0
         rc0["closed_loop_200_sequential_steps"] = {"value": 200 / dt, "unit": "MPC steps/s", "ms_per_loop_step": dt / 200 * 1e3, "n_newton": 1}
+        # the literal per-timestep call of configs[0]: the reference's 21-argument VAR_1 constructor set through fmpc_solve_once (host pointers)
+        try:
+            import ctypes as C0
+            lib0 = pkg.load()
+            lib0.fmpc_solve_once_cache_clear()
+            F0 = lambda M_: np.asfortranarray(M_).ravel(order="K").copy()
+            P0 = lambda a_: None if a_ is None else np.ascontiguousarray(a_, dtype=np.float64).ctypes.data_as(C0.c_void_p)
+            k0 = [F0(m0["Q"]), F0(m0["R"]), F0(m0["Qf"]), F0(m0["A1"]), F0(m0["B"]), -0.2121 * np.ones(m), 0.2121 * np.ones(m), np.zeros(T0 * n)]
+            up0 = 0.05 * np.random.default_rng(9).standard_normal((64, m))
+            zo0 = np.empty(T0 * (n + m)); it0_ = C0.c_int()
+
+            def once0(i_):
+                return lib0.fmpc_solve_once(n, m, T0, 1, P0(k0[0]), P0(k0[1]), None, P0(k0[2]), None, None, None, P0(m0["x_min"]), P0(m0["x_max"]),
+                                            P0(m0["u_min"]), P0(m0["u_max"]), P0(k0[5]), P0(k0[6]), P0(d0["x0"][i_]), None, P0(up0[i_]), P0(k0[3]), None,
+                                            P0(k0[4]), P0(k0[7]), None, None, P0(d0["nu0"][i_, :T0 * n]), 1, K_BAR, local_rank, P0(zo0), C0.byref(it0_))
+            t0 = time.perf_counter(); assert once0(0) == 0; tf0 = time.perf_counter() - t0
+            ts0 = []
+            for i_ in range(1, 41):
+                t0 = time.perf_counter(); assert once0(i_) == 0; ts0.append(time.perf_counter() - t0)
+            rc0["solve_once_literal_call"] = {"what": "fmpc_solve_once with the VAR_1 constructor's argument set per timestep (du_min, du_max, u_prev: ramp rows on), host "
+                                                      "pointers, PCIe inclusive: first call (create + upload + the constants of the cold-start form) vs the following calls",
+                                              "first_call_ms": tf0 * 1e3, "next_calls_ms_median": float(np.median(ts0)) * 1e3, "MPC_steps_per_s": 1.0 / float(np.median(ts0))}
+            lib0.fmpc_solve_once_cache_clear()
+        except Exception as ex_:
+            rc0["solve_once_literal_call"] = {"error": repr(ex_)}
         h0.close()
         extra["config0_var1_ramp"] = rc0
         # ------------------------------------------------------------------ the literal drop-in call (host pointers, one problem)
