@@ -800,6 +800,7 @@ static int fmpc_tiled_build(fmpc_handle h, int t) {
 // nw_override: wavefronts per problem other than the handle's default (2 or 4, fp64 without dense R): few problems per CU
 // are solved faster by more wavefronts each (the latency of a problem is what counts then)
 static bool fmpc_capturing(hipStream_t stream);
+__global__ void fmpc_zero_ints(int* p, int n) { if ((int)threadIdx.x < n) p[threadIdx.x] = 0; }
 struct FmpcTiledPlan { int NWu; size_t ldsu; int grid; size_t slot; };
 // Everything a tiled launch needs BEFORE anything is enqueued: the instance is built and prepared, the launch is sized and its
 // workspace exists.  A caller that enqueues another launch first (the first-step / continuation split) plans first and falls
@@ -1439,7 +1440,11 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
                 h->gn_cnt_host[0] = -1; h->gn_cnt_host[1] = -1;
             }
             double* nu_arr = nu_out ? nu_out : h->gn_nu;               // nu after the first step, per problem: what the continuation starts from
-            if (hipMemsetAsync(h->gn_cnt, 0, 2 * sizeof(int), (hipStream_t)stream) != hipSuccess) return FMPC_E_HIP;
+            // (a kernel, not hipMemsetAsync: a captured graph holding the 8-byte memset node faulted on its SECOND launch --
+            // "write access to a read-only page", ROCm 7.2, round 5; with this kernel node instead, and the 8-byte device-to-host
+            // copy node below kept, any number of launches is fine: tests/test_gpu_recorded.py)
+            hipLaunchKernelGGL(fmpc_zero_ints, dim3(1), dim3(64), 0, (hipStream_t)stream, h->gn_cnt, 2);
+            if (hipGetLastError() != hipSuccess) return FMPC_E_HIP;
             e = fmpc_launch_wave(h->dev, h->wave, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                  z_out, nu_arr, status, iters, step, fmpc_step_ld(n_newton), h->ws, stride,
                                  h->wave_lds, (hipStream_t)stream, mode, h->sh_fac, h->sh_rs, h->sh_ok, h->cold_d,
