@@ -67,7 +67,10 @@ const char* fmpc_strerror(int code);
  * fast_mpc_ineq_const.m:46-56).
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
- *   n          <= 79 (n <= 64: fp64 kernels; 64 < n <= 79: fp32 factor + fp64 residuals, see fmpc_set_precision).
+ *   n          any.  Specialised kernels: n = 27 (the AO configuration), n <= 47 in fp64 and n <= 79 with the fp32 factor + fp64
+ *              residuals (fmpc_set_precision) on the matrix cores; every other size with diagonal Q, R, Qf (the reference checks
+ *              shapes only, fast_mpc_objective.m:17-47) is solved in fp64 by the generic kernel with its tiles in the HBM
+ *              workspace -- a size fallback without a speed claim (tests/test_gpu_any_size.py: n = 83 .. 130).
  *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices.  Dense Q or Qf:
  *              solved by the tiled kernel, n <= 47 in fp64, <= 79 with the fp32 factor.  Dense R: the u block of Phi is
  *              then a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS by the
@@ -318,7 +321,9 @@ int fmpc_var_identify_device(int n, int num_train, int num_samples, int batch, c
  *                        (inf_newton_solver.m:27,30) and the two triangular sweeps (:31-32) in fp32 on the matrix
  *                        cores; the residuals r_d, r_p (:12-17), the right-hand side (:28-29), d_z, the line search
  *                        and the iterate z, nu stay fp64, so every Newton step refines the fp32 KKT solve of the
- *                        previous one against fp64 residuals.  Default for 64 < n <= 79 (only path there).
+ *                        previous one against fp64 residuals.  Default where no matrix-core fp64 kernel exists and this one
+ *                        does (47 < n <= 79, and smaller n whose fp64 tiles do not fit); FMPC_PREC_F64 is accepted there too
+ *                        with diagonal weights and selects the generic kernel with its tiles in the workspace (slow, exact).
  * FMPC_E_UNSUPPORTED when the handle's size has no kernel of that type.
  */
 #define FMPC_PREC_F64        0

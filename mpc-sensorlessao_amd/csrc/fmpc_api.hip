@@ -27,7 +27,8 @@ extern "C" unsigned long long fmpc_alloc_generation(void) { return fmpc_alloc_ge
 
 // kernels / launchers (fmpc_kernel_generic.hip)
 size_t fmpc_generic_lds_bytes(int n, int m);
-hipError_t fmpc_generic_prepare(size_t lds_bytes);
+size_t fmpc_generic_big_lds_bytes(int n, int m);
+hipError_t fmpc_generic_prepare(size_t lds_bytes, int big);
 // fmpc_kernel_ramp.hip
 size_t fmpc_ramp_lds_bytes(int n, int m, int nbn);
 size_t fmpc_ramp_ws_doubles(int n, int m, int T, int nb);
@@ -41,7 +42,7 @@ hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const
                                const double* x0p, const double* w, const double* zinit,
                                const double* nu0, int max_iter, double kbar, double* zout,
                                double* nuout, int* status, int* iters, double* step, int step_ld,
-                               double* ws, size_t ws_stride, hipStream_t stream);
+                               double* ws, size_t ws_stride, hipStream_t stream, int big);
 hipError_t fmpc_launch_unpack(int n, int m, int T, int batch, const double* z, double* U,
                               double* X, double* u0, hipStream_t stream);
 hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
@@ -138,7 +139,8 @@ struct fmpc_handle_s {
     int* pn_sched; int pn_nsf, pn_nsb, pn_limg_cap;
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // tiled kernel (fmpc_kernel_tiled.hip): workgroup per problem, any n <= 79; images per arithmetic type, built on first use
-    int generic_ok;                      // the generic kernel's LDS tiles fit (n <= 64)
+    int generic_ok;                      // the generic kernel's LDS tiles fit (n <= 64), or generic_big
+    int generic_big;                     // sizes no other kernel takes (n > 79 ...), diagonal weights: the generic kernel with its tiles in the workspace
     int prec;                            // FMPC_PREC_F64 / FMPC_PREC_F32_MIXED of the per-problem-factor path
     int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
     struct Tiled { int ready, NB, NW; size_t lds; void* pool; int* ipool; double* bm; FtModel V; } tl[2];   // bm: padded fp64 images   // [0] fp64, [1] fp32
@@ -299,9 +301,16 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     // per-problem-factor paths: the generic kernel (n <= 64 and its tiles fit the LDS), else the tiled kernel in fp64
     // (n <= 47), else the tiled kernel with an fp32 factor (n <= 79: "fp32 mixed precision", BASELINE configs[4])
     size_t lds = fmpc_generic_lds_bytes(n, m);
-    const bool generic_ok = !denseQ && !denseR && n <= 64 && lds <= FMPC_LDS_LIMIT;
+    bool generic_ok = !denseQ && !denseR && n <= 64 && lds <= FMPC_LDS_LIMIT;
     const int nb_ = T + (xf ? 1 : 0);
     const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr, denseR), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr, denseR);
+    // Any other size with diagonal weights (the reference checks shapes only, fast_mpc_objective.m:17-47): the generic kernel
+    // with its tiles in the HBM workspace ("big": a size fallback, fp64, no speed claim).  FMPC_GENERIC_BIG=1 forces it (tests).
+    bool generic_big = false;
+    { const char* fb = getenv("FMPC_GENERIC_BIG");
+      if ((!generic_ok && !tiled64 && !tiled32) || (fb && fb[0] == '1'))
+          generic_big = !denseQ && !denseR && fmpc_generic_big_lds_bytes(n, m) <= FMPC_LDS_LIMIT; }
+    if (generic_big) { generic_ok = true; lds = fmpc_generic_big_lds_bytes(n, m); }
     if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
     if (!generic_ok) lds = 0;
 
@@ -322,7 +331,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->rc_valid = 0; h->rc_failed = 0; h->rc_last = 0; h->rc_k = 0.0; h->rc_failed_k = 0.0; h->rc_pool = nullptr;
     h->rc_ws = nullptr; h->rc_ws_doubles = 0; h->rc_nu = nullptr; h->rc_si = nullptr; h->rc_cap = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
-    h->generic_ok = generic_ok ? 1 : 0;
+    h->generic_ok = generic_ok ? 1 : 0; h->generic_big = generic_big ? 1 : 0;
     h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
@@ -351,6 +360,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->wg_per_cu = lds ? (int)(FMPC_LDS_LIMIT / lds) : 1;
     if (h->wg_per_cu < 1) h->wg_per_cu = 1;
     if (h->wg_per_cu > 8) h->wg_per_cu = 8;
+    if (generic_big && h->wg_per_cu > 2) h->wg_per_cu = 2;         // (a workspace slot holds the whole factor: nb 3 n (n + 1) doubles)
 
     const bool var2 = var_order == 2;
     const int nn = n * n;
@@ -464,7 +474,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
     h->loop_M1 = h->pool_d + oM1; h->loop_M2 = h->pool_d + oM2;
 
-    if (generic_ok && fmpc_generic_prepare(lds) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
+    if (generic_ok && fmpc_generic_prepare(lds, generic_big ? 1 : 0) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
     // host copies the tiled kernel's images are built from (on first use of an arithmetic type)
     h->hm_blocks = yall; h->hm_idxD = idxD; h->hm_idx1 = idx1; h->hm_idx2 = idx2; h->hm_bt = bt;
     h->hm_a1f = a1; h->hm_a2f = a2;
@@ -880,8 +890,15 @@ extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
     if (!h) return FMPC_E_NULL;
     if (mode != FMPC_PREC_F64 && mode != FMPC_PREC_F32_MIXED) return FMPC_E_DIM;
     if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, h->nb, 1, nullptr, nullptr, h->denseR)) return FMPC_E_UNSUPPORTED;
-    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr)) return FMPC_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr)) {
+        // sizes whose default is the fp32 factor (47 < n <= 79, diagonal weights): fp64 on request through the generic kernel
+        // with its tiles in the workspace (slow; the fp64 answer on the device for a configs[4]-sized problem)
+        const size_t lds = fmpc_generic_big_lds_bytes(h->n, h->m);
+        if (h->denseQ || h->denseR || lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+        if (fmpc_generic_prepare(lds, 1) != hipSuccess) return FMPC_E_HIP;
+        h->generic_ok = 1; h->generic_big = 1; h->lds_bytes = lds; h->wg_per_cu = 2;
+    }
     h->prec = mode;
     return FMPC_OK;
 }
@@ -893,7 +910,7 @@ static int fmpc_grid_for(fmpc_handle h, int batch) {
 
 // grows the per-workgroup workspace; caller holds h->mu
 static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
-    const FmpcWsLayout L = fmpc_ws_layout(h->n, h->m, h->T, h->nb);
+    const FmpcWsLayout L = fmpc_ws_layout(h->n, h->m, h->T, h->nb, h->generic_big != 0);
     *stride = L.total;
     const size_t need = L.total * (size_t)grid;
     if (need > h->ws_doubles) {
@@ -1466,11 +1483,12 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
         h->last_path = FMPC_PATH_GENERIC;
         const int grid = fmpc_grid_for(h, batch);
         size_t stride = 0;
-        int rc = fmpc_ensure_ws(h, h->num_cu * h->wg_per_cu, &stride);   // full size once: no regrowth
+        // full size once: no regrowth (big: a slot holds the whole factor -- as many slots as the launch has workgroups, grown on demand)
+        int rc = fmpc_ensure_ws(h, h->generic_big ? grid : h->num_cu * h->wg_per_cu, &stride);
         if (rc != FMPC_OK) return rc;
         e = fmpc_launch_generic(h->dev, batch, grid, x0, x0_pre, w, z_init, nu0, max_iter, k,
                                 z_out, nu_out, status, iters, step, fmpc_step_ld(n_newton),
-                                h->ws, stride, (hipStream_t)stream);
+                                h->ws, stride, (hipStream_t)stream, h->generic_big);
         if (e == hipSuccess && u0_out)
             e = fmpc_launch_unpack(h->n, h->m, h->T, batch, z_out, nullptr, nullptr, u0_out, (hipStream_t)stream);
     }

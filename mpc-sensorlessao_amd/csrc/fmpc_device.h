@@ -32,10 +32,10 @@ struct FmpcDevModel {
 // Per-workgroup scratch in HBM (doubles).  The factor tiles are written during the forward
 // sweep and streamed back once, in reverse, by the backward sweep.
 struct FmpcWsLayout {
-    size_t b, nu, hess, winv, rdu, rdx, rp, y, dnu, fac, total;
+    size_t b, nu, hess, winv, rdu, rdx, rp, y, dnu, fac, tiles, total;
 };
 
-__host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int T, int nb) {
+__host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int T, int nb, bool big = false) {
     FmpcWsLayout L;
     size_t o = 0;
     const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
@@ -49,6 +49,7 @@ __host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int 
     L.y = o;    o += nbn;
     L.dnu = o;  o += nbn;
     L.fac = o;  o += (size_t)nb * 3 * n * (n + 1);
+    L.tiles = o; if (big) o += 6 * (size_t)n * (n + 1);          // the generic kernel's tiles when they do not fit the LDS (any n)
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }

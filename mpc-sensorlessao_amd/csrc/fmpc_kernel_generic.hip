@@ -1,4 +1,7 @@
-// Generic fastMPC Newton kernel for gfx950: any (n <= 64, m, T) whose tiles fit the LDS.
+// Generic fastMPC Newton kernel for gfx950: any (n <= 64, m, T) whose tiles fit the LDS -- and, as the instance BIG, ANY (n, m, T)
+// with diagonal weights (the reference checks shapes only, fast_mpc_objective.m:17-47): the same code with B' read from the model
+// and the six n x (n + 1) tiles in the workgroup's slot of the HBM workspace (L2-resident at the sizes in question) instead of LDS.
+// BIG is the size fallback behind the tiled kernel (n <= 79): correctness at any size, not speed.
 //
 // One 256-thread workgroup owns one problem at a time and runs the whole
 // `inf_newton_solver` loop for it (reference: Fast_MPC/VAR_2/inf_newton_solver.m:10-41):
@@ -43,7 +46,8 @@ __device__ __forceinline__ double fmpc_block_sum(double v, double* red) {
     return s;
 }
 
-extern "C" __global__ void __launch_bounds__(FMPC_THREADS)
+template <bool BIG>
+__global__ void __launch_bounds__(FMPC_THREADS)
 fmpc_newton_generic(FmpcDevModel M, int batch,
                     const double* __restrict__ x0, const double* __restrict__ x0p,
                     const double* __restrict__ w, const double* zinit,
@@ -58,20 +62,21 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
     const int tid = threadIdx.x;
     const bool var2 = M.var2 != 0;
 
-    // ---- LDS carve
-    double* sBt = lds;                    // m*n
-    double* tile0 = sBt + (size_t)m * n;  // 6 tiles n*ldt
-    double* sw = tile0 + 6 * tsz;         // m     winv of the current stage
+    const FmpcWsLayout L = fmpc_ws_layout(n, m, T, nb, BIG);
+    double* wsp = ws + (size_t)blockIdx.x * ws_stride;
+    // ---- LDS carve (BIG: B' stays in the model, the tiles live in the workspace slot)
+    const double* sBt = BIG ? M.Bt : lds;                                 // m*n
+    double* tile0 = BIG ? wsp + L.tiles : lds + (size_t)m * n;            // 6 tiles n*ldt
+    double* sw = BIG ? lds : tile0 + 6 * tsz;                             // m     winv of the current stage
     double* sv1 = sw + m;                 // n     d_nu_{i+1}
     double* sv2 = sv1 + n;                // n     d_nu_{i+2}
     double* srs = sv2 + n;                // n     1/sqrt(pivot)
     double* red = srs + n;                // 8
     int* sflag = (int*)(red + 8);         // 2
 
-    for (int i = tid; i < m * n; i += FMPC_THREADS) sBt[i] = M.Bt[i];
+    if (!BIG)
+        for (int i = tid; i < m * n; i += FMPC_THREADS) lds[i] = M.Bt[i];
 
-    const FmpcWsLayout L = fmpc_ws_layout(n, m, T, nb);
-    double* wsp = ws + (size_t)blockIdx.x * ws_stride;
     double* b = wsp + L.b;
     double* nu = wsp + L.nu;
     double* hess = wsp + L.hess;
@@ -368,7 +373,16 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                         tv[r] = v;
                     }
                     __syncthreads();
-                    if (tid < 64) {                                  // wave 0: lane j <-> entry j
+                    if (BIG) {
+                        // any n: column-oriented substitution by the whole workgroup, one barrier per row
+                        for (int r = n - 1; r >= 0; --r) {
+                            const double xr = tv[r] / tL[r * ldt + r];
+                            for (int c = tid; c < r; c += FMPC_THREADS) tv[c] -= tL[r * ldt + c] * xr;
+                            if (tid == 0) dnu[i * n + r] = xr;
+                            __syncthreads();
+                        }
+                        for (int r = tid; r < n; r += FMPC_THREADS) { sv2[r] = sv1[r]; sv1[r] = dnu[i * n + r]; }
+                    } else if (tid < 64) {                           // wave 0: lane j <-> entry j
                         double v = (tid < n) ? tv[tid] : 0.0;
                         for (int r = n - 1; r >= 0; --r) {
                             const double xr = __shfl(v, r, 64) / tL[r * ldt + r];
@@ -822,21 +836,28 @@ size_t fmpc_generic_lds_bytes(int n, int m) {
     const size_t d = (size_t)m * n + 6 * (size_t)n * (n + 1) + m + 3 * (size_t)n + 8 + 2;
     return d * sizeof(double);
 }
+size_t fmpc_generic_big_lds_bytes(int n, int m) { return ((size_t)m + 3 * (size_t)n + 8 + 2) * sizeof(double); }
 
 hipError_t fmpc_launch_generic(const FmpcDevModel& M, int batch, int grid, const double* x0,
                                const double* x0p, const double* w, const double* zinit,
                                const double* nu0, int max_iter, double kbar, double* zout,
                                double* nuout, int* status, int* iters, double* step, int step_ld,
-                               double* ws, size_t ws_stride, hipStream_t stream) {
+                               double* ws, size_t ws_stride, hipStream_t stream, int big) {
+    if (big) {
+        hipLaunchKernelGGL(fmpc_newton_generic<true>, dim3(grid), dim3(FMPC_THREADS), fmpc_generic_big_lds_bytes(M.n, M.m), stream, M, batch,
+                           x0, x0p, w, zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step, step_ld, ws, ws_stride);
+        return hipGetLastError();
+    }
     const size_t lds = fmpc_generic_lds_bytes(M.n, M.m);
-    hipLaunchKernelGGL(fmpc_newton_generic, dim3(grid), dim3(FMPC_THREADS), lds, stream, M, batch,
+    hipLaunchKernelGGL(fmpc_newton_generic<false>, dim3(grid), dim3(FMPC_THREADS), lds, stream, M, batch,
                        x0, x0p, w, zinit, nu0, max_iter, kbar, zout, nuout, status, iters, step,
                        step_ld, ws, ws_stride);
     return hipGetLastError();
 }
 
-hipError_t fmpc_generic_prepare(size_t lds_bytes) {
-    return hipFuncSetAttribute((const void*)fmpc_newton_generic,
+hipError_t fmpc_generic_prepare(size_t lds_bytes, int big) {
+    if (big) return hipFuncSetAttribute((const void*)fmpc_newton_generic<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    return hipFuncSetAttribute((const void*)fmpc_newton_generic<false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 

@@ -1,0 +1,79 @@
+"""Sizes no specialised kernel takes (n > 79 with diagonal weights; the reference checks shapes only, fast_mpc_objective.m:17-47):
+the generic kernel's instance with its tiles in the HBM workspace ("big").  Same bar as tests/test_gpu_parity.py: 1e-9 on z
+against the structured oracle, identical iteration counts, status codes and line-search steps."""
+import numpy as np
+import pytest
+
+from tests.util import handle_from_model, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(pkg, model, data, nw, k, z_init=None, tol=1e-9, expect_path=None, prec=None):
+    h = handle_from_model(pkg, model)
+    if prec:
+        h.set_precision(prec)
+    z, info = h.solve(data["x0"], data.get("x0_pre"), data.get("w"), z_init=z_init, nu0=data.get("nu0"), n_newton=nw, k=k,
+                      return_info=True, check=False)
+    path = h.last_dispatch()[0]
+    h.close()
+    if expect_path is not None:
+        assert path == expect_path, path
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, nw, k, z_init)
+    assert np.array_equal(info["status"], sto), (info["status"], sto)
+    assert np.array_equal(info["iters"], ito), (info["iters"], ito)
+    for p in range(z.shape[0]):
+        assert rel_err(z[p], zo[p]) <= tol, (p, rel_err(z[p], zo[p]))
+        assert rel_err(info["nu"][p], nuo[p]) <= 1e-7
+        assert np.array_equal(info["step"][p][:ito[p]], np.array(steps[p])), (p, info["step"][p], steps[p])
+    return z, info
+
+
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("var_order", [2, 1])
+def test_big_instance_on_the_reference_demo_config(pkg, gpu, monkeypatch, xf, var_order):
+    """The instance forced on a size the LDS instance takes too (test_fast_mpc.m:8-37: n = 8, m = 5, T = 10): cold start with
+    budgets 1, 5 and 0 (= until convergence), and an off-centre start under a strong barrier (backtracking)."""
+    monkeypatch.setenv("FMPC_GENERIC_BIG", "1")
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=3, xf=xf, var_order=var_order, batch=4)
+    for nw in (1, 5, 0):
+        _compare(pkg, model, data, nw, 0.01, expect_path=pkg.FMPC_PATH_GENERIC)
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=7, umax=0.3, xf=xf, var_order=var_order, batch=6)
+    rng = np.random.default_rng(11)
+    z0 = np.zeros((6, 10, 13))
+    z0[:, :, :5] = rng.uniform(-0.25, 0.25, (6, 10, 5)); z0[:, :, 5:] = rng.uniform(-1, 1, (6, 10, 8))
+    z, info = _compare(pkg, model, data, 8, 10.0, z_init=z0.reshape(6, 130), expect_path=pkg.FMPC_PATH_GENERIC)
+    assert np.any((info["step"] > 0) & (info["step"] < 1)), "case must exercise backtracking"
+
+
+@pytest.mark.parametrize("n,m,T,var_order,xf", [(100, 40, 5, 2, True), (130, 150, 4, 1, False), (83, 7, 3, 2, False), (70, 300, 2, 2, False)])
+def test_sizes_beyond_the_specialised_kernels(pkg, gpu, n, m, T, var_order, xf):
+    """n > 79 (the tiled kernel's limit) with diagonal weights: solved, by the generic path, to the parity bar; w and an explicit
+    dual start included.  n = 70 (default there: the fp32 factor) takes the same path when fp64 is asked for."""
+    model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + m, xf=xf, var_order=var_order, batch=3)
+    for nw in (1, 4):
+        _compare(pkg, model, data, nw, 0.01, expect_path=pkg.FMPC_PATH_GENERIC, prec="f64" if n <= 79 else None)
+
+
+def test_first_moves_and_device_entry_at_a_big_size(pkg, gpu):
+    import torch
+    dev = torch.device("cuda:0")
+    model, data = pkg.synthetic.make_test_problem(96, 20, 4, seed=5, batch=5)
+    h = handle_from_model(pkg, model)
+    z = h.solve(data["x0"], data.get("x0_pre"), data.get("w"), n_newton=3, k=0.01)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    u0 = torch.empty((5, 20), dtype=torch.float64, device=dev)
+    zd = h.solve_device(t(data["x0"]), t(data.get("x0_pre")), t(data.get("w")), None, None, 3, 0.01, u0_out=u0)[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(zd.cpu().numpy(), z) and np.array_equal(u0.cpu().numpy(), z[:, :20])
+    h.close()
+
+
+def test_dense_weights_at_a_big_size_are_refused_cleanly(pkg, gpu):
+    model, data = pkg.synthetic.make_test_problem(100, 10, 3, seed=2, batch=1)
+    Qd = np.array(model["Q"], dtype=float)
+    Qd[0, 1] = Qd[1, 0] = 1e-3
+    model["Q"] = Qd
+    with pytest.raises(pkg.FastMPCError) as ei:
+        handle_from_model(pkg, model)
+    assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED

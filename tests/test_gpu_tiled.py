@@ -179,16 +179,28 @@ def test_tiled_fp32_random_models_over_the_block_sizes(pkg, gpu, n, m, T, var, x
 
 
 def test_precision_switch_errors(pkg, gpu):
+    """Dense weights have no fp64 kernel beyond n = 47 and no kernel at all beyond n = 79: refused cleanly.  (Diagonal weights: any
+    size is solved -- fp64 on request at n = 65, and n = 80 at all -- by the generic kernel's workspace instance,
+    tests/test_gpu_any_size.py.)"""
     model = pkg.synthetic.make_model(65, 144, 4)
-    h = handle_from_model(pkg, model)
+    Qd = np.array(model["Q"], dtype=float)
+    Qd[0, 1] = Qd[1, 0] = 1e-3 * Qd[0, 0]
+    dense = dict(model, Q=Qd)
+    h = handle_from_model(pkg, dense)
     with pytest.raises(pkg.FastMPCError) as e:
-        h.set_precision("f64")                            # no fp64 kernel at n = 65
+        h.set_precision("f64")                            # dense Q: no fp64 kernel at n = 65
     assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
     h.close()
+    h = handle_from_model(pkg, model)
+    h.set_precision("f64"); h.set_precision("f32"); h.set_precision("f64")     # diagonal weights: both, back and forth
+    h.close()
     model = pkg.synthetic.make_model(80, 16, 4)
+    Qd = np.array(model["Q"], dtype=float)
+    Qd[0, 1] = Qd[1, 0] = 1e-3 * Qd[0, 0]
     with pytest.raises(pkg.FastMPCError) as e:
-        handle_from_model(pkg, model)
+        handle_from_model(pkg, dict(model, Q=Qd))
     assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    handle_from_model(pkg, model).close()
 
 
 def test_tiled_repeated_solves_alternating_wave_counts(pkg, gpu, tiled_env, monkeypatch):
