@@ -581,6 +581,21 @@ def _main(real_out):
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "newton_iters_per_problem": it4b / B4,
             "note": "exit test of inf_newton_solver.m:19-22 (absolute 1e-6): an fp32 factor step leaves ||r|| ~ 1e-3 where the exact step "
                     "leaves 1e-9, so the fp32 path uses more of the budget than the fp64 oracle (DESIGN.md, tiled kernel)"}
+        # the same problems in fp64 through the size fallback (fmpc_newton_generic<true>, tiles in the HBM workspace): what "any size"
+        # costs, and the fp64 answer the fp32 step is measured against on the device
+        h4.set_precision("f64")
+        B4g = 256
+        r4g = Replay(h4, to_dev(d4["x0"][:B4g]), to_dev(d4["x0_pre"][:B4g]), to_dev(d4["nu0"][:B4g]), 1)
+        e_, s_, k_ = timed(r4g.step, 2, 1, min_ms=0.0)
+        r4g.check()
+        z64 = r4g.z.clone()
+        h4.set_precision("f32")
+        r4g.step(); torch.cuda.synchronize(dev)
+        extra["any_size_fallback_n65_fp64"] = {
+            "what": "configs[4]'s model, %d problems, fp64 on request (fmpc_set_precision): the generic kernel's workspace instance, the path of "
+                    "every n > 79 with diagonal weights; no speed claim" % B4g,
+            "value": B4g * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": pkg.FMPC_PATH_GENERIC,
+            "fp32_factor_step_vs_this": float((r4g.z - z64).norm() / z64.norm())}
         h4.close()
         # ------------------------------------------------------------------ tiled kernel at (27,144,30) in both arithmetic types
         for tag, prec in (("tiled_fp32_budget1", "f32"),):
