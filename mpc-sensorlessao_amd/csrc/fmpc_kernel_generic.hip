@@ -806,10 +806,55 @@ fmpc_loop_inputs_mfma27(int m, int T, int batch, int rows, const double* __restr
     LI_TICK(4);
 }
 
+// Any size (n > LI_NMAX, or B' and a row slice beyond the LDS): one workgroup per problem, B u1 and B u2 in LDS (2 n doubles), a thread
+// per row of w.  The size fallback of the two kernels above -- same outputs, no tiling.
+__global__ void __launch_bounds__(256)
+fmpc_loop_inputs_any(int n, int m, int T, const double* __restrict__ Bt, const double* __restrict__ M1, const double* __restrict__ M2,
+                     const double* __restrict__ a, const double* x0_last, const double* __restrict__ u1, const double* __restrict__ u2,
+                     double* x0, double* __restrict__ x0_pre, double* __restrict__ w, double* __restrict__ lv) {
+    extern __shared__ double sh[];
+    double* bu1 = sh; double* bu2 = sh + n;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const double* up1 = u1 ? u1 + (size_t)p * m : nullptr;
+    const double* up2 = u2 ? u2 + (size_t)p * m : nullptr;
+    for (int r = tid; r < n; r += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = 0; c < m; ++c) {
+            const double b = Bt[(size_t)c * n + r];
+            if (up1) s1 += b * up1[c];
+            if (up2) s2 += b * up2[c];
+        }
+        bu1[r] = s1; bu2[r] = s2;
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += 256) {
+        const size_t g = (size_t)p * n + r;
+        const double xl = x0_last ? x0_last[g] : 0.0;            // (x0 may alias x0_last: read before the write below)
+        x0_pre[g] = xl;
+        x0[g] = a[g] + bu1[r];
+        if (lv) { lv[(size_t)p * 2 * n + r] = bu1[r]; lv[(size_t)p * 2 * n + n + r] = bu2[r]; }
+    }
+    const int Tn = T * n;
+    for (int e = tid; e < Tn; e += 256) {
+        const double* r1 = M1 + (size_t)e * n; const double* r2 = M2 + (size_t)e * n;
+        double acc = 0.0;
+        for (int q = 0; q < n; ++q) acc -= r1[q] * bu1[q] + r2[q] * bu2[q];
+        w[(size_t)p * Tn + e] = acc;
+    }
+}
+
 hipError_t fmpc_launch_loop_inputs(int n, int m, int T, int batch, const double* Bt, const double* M1, const double* M2,
                                    const double* a, const double* x0_last, const double* u1, const double* u2,
                                    double* x0, double* x0_pre, double* w, hipStream_t stream, double* lv) {
-    if (n > LI_NMAX) return hipErrorInvalidValue;
+    const size_t lds_plain = (2 * LI_PT * n + 2 * (size_t)((T * n + LI_RS - 1) / LI_RS) * (n + 1) + (size_t)m * n + 2 * LI_PT * m) * sizeof(double);
+    size_t lds27 = 0;
+    if (n == 27) { size_t su_d = 2 * (size_t)LI_PT * (m + 1); if (su_d < 4096) su_d = 4096; lds27 = ((size_t)m * n + su_d) * sizeof(double); }
+    if (n > LI_NMAX || (n != 27 && lds_plain > 160 * 1024) || (n == 27 && lds27 > 160 * 1024)) {
+        if (2 * (size_t)n * sizeof(double) > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fmpc_loop_inputs_any, dim3(batch), dim3(256), 2 * (size_t)n * sizeof(double), stream,
+                           n, m, T, Bt, M1, M2, a, x0_last, u1, u2, x0, x0_pre, w, lv);
+        return hipGetLastError();
+    }
     if (n == 27) {
         const int Tn = T * n, rs = (Tn + 63) / 64, rows = (Tn + rs - 1) / rs;      // <= 64 rows = 4 tiles per workgroup
         size_t su_d = 2 * (size_t)LI_PT * (m + 1);                 // u1, u2 of the tile; afterwards the partial tiles of B u (4 x 4 x 256)

@@ -77,3 +77,30 @@ def test_dense_weights_at_a_big_size_are_refused_cleanly(pkg, gpu):
     with pytest.raises(pkg.FastMPCError) as ei:
         handle_from_model(pkg, model)
     assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+
+
+def test_closed_loop_step_at_a_big_size(pkg, gpu):
+    """The coefficient-space loop entry (README.md:482-497) at n = 96: loop inputs by the any-size kernel + the solve by the generic
+    path, against the same two steps done by hand (numpy inputs + host-pointer solve)."""
+    import torch
+    from tests.test_gpu_closed_loop import design_matrices
+    dev = torch.device("cuda:0")
+    n, m, T, R = 96, 20, 4, 6
+    model, _ = pkg.synthetic.make_test_problem(n, m, T, seed=9, batch=1)
+    rng = np.random.default_rng(3)
+    a, xl, u1, u2 = 0.1 * rng.standard_normal((R, n)), 0.1 * rng.standard_normal((R, n)), 0.1 * rng.standard_normal((R, m)), 0.1 * rng.standard_normal((R, m))
+    h = handle_from_model(pkg, model)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    f = dict(dtype=torch.float64, device=dev)
+    x0, x0p, w = torch.empty((R, n), **f), torch.empty((R, n), **f), torch.empty((R, T * n), **f)
+    z = torch.empty((R, h.nz), **f)
+    u0 = torch.empty((R, m), **f)
+    h.loop_step_device(t(a), t(xl), t(u1), t(u2), x0, x0p, w, n_newton=3, k=0.01, z_out=z, u0_out=u0)
+    torch.cuda.synchronize()
+    M1, M2 = design_matrices(model["A1"], model["A2"], T)
+    bu1, bu2 = (model["B"] @ u1.T).T, (model["B"] @ u2.T).T
+    w_ref = -(M1 @ bu1.T).T - (M2 @ bu2.T).T
+    assert np.abs(w.cpu().numpy() - w_ref).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
+    z_ref = h.solve(a + bu1, xl, w_ref, n_newton=3, k=0.01)
+    assert rel_err(z.cpu().numpy(), z_ref) <= 1e-10 and np.array_equal(u0.cpu().numpy(), z.cpu().numpy()[:, :m])
+    h.close()

@@ -94,10 +94,11 @@ def test_config0_200_sequential_steps_with_ramp_rows(pkg, gpu):
     h.close()
 
 
-@pytest.mark.parametrize("n,m,T", [(27, 144, 30), (27, 97, 7), (8, 5, 6)])
+@pytest.mark.parametrize("n,m,T", [(27, 144, 30), (27, 97, 7), (8, 5, 6), (96, 20, 4), (60, 300, 12)])
 def test_loop_inputs_kernel_against_numpy(pkg, gpu, n, m, T):
     """fmpc_loop_inputs_device alone (several 16-problem tiles, a ragged last one; matrix-core kernel for n = 27, the
-    plain one otherwise): x0 = a + B u1, x0_pre = x0_last, w = -M1 B u1 - M2 B u2, and the NULL variants of the first steps."""
+    plain one otherwise, the any-size one for n > 64 or beyond the LDS): x0 = a + B u1, x0_pre = x0_last, w = -M1 B u1 - M2 B u2,
+    and the NULL variants of the first steps."""
     import torch
     md = pkg.synthetic.make_model(n, m, T)
     R = 37
