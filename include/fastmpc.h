@@ -114,6 +114,9 @@ int fmpc_dims(fmpc_handle h, int* n, int* m, int* T, int* nz, int* nu_len);
  *   step        step_ld x batch, nullable: accepted t of every Newton step (unused tail = -1);
  *               step_ld = fmpc_step_ld(n_newton)
  * Returns the worst per-problem status (most negative error, else largest warning).
+ * Staging: the inputs are packed into one pinned block, copied up once, the outputs copied down once.  A call of up to
+ * 128 KB in all (the reference's per-timestep call: one problem) skips both copies -- the kernels read the pinned block and,
+ * from the cold start with a budget of 1, write z into it directly (round 5: 51 -> 43 us per call; FMPC_NO_ZEROCOPY=1 for A/B).
  */
 int fmpc_solve(fmpc_handle h, int batch,
                const double* x0, const double* x0_pre, const double* w,

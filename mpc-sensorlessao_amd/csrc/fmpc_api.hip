@@ -2179,6 +2179,7 @@ extern "C" int fmpc_solve_ramp_u0_device(fmpc_handle h, int batch,
 // transfers and one synchronisation where round 3 issued up to six blocking hipMemcpy each way (163 us per call).  Larger
 // batches are bandwidth-bound and copy straight between the caller's arrays and the device block.
 #define FMPC_PIN_LIMIT ((size_t)1 << 20)
+#define FMPC_ZC_LIMIT ((size_t)128 << 10)      /* calls this small skip the copies: the kernels work on the pinned block itself */
 static int fmpc_solve_host(fmpc_handle h, int batch,
                            const double* x0, const double* x0_pre, const double* w, const double* u_prev,
                            const double* z_init, const double* nu0,
@@ -2224,27 +2225,39 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
             pin = (char*)h->pin;
         }
     }
-    auto dptr = [&](const void* src, size_t o) -> const double* { return src ? (const double*)(base + o) : nullptr; };
+    // A call of a few problems (the reference's per-timestep call is ONE) is all latency: the two copies and their
+    // synchronisation are 23 of its 54 us (round 5, scripts/once_latency.py).  Up to FMPC_ZC_LIMIT bytes the kernels read the
+    // inputs straight from the pinned block (it is device-accessible) -- no copy up -- and, when the iterate is written once
+    // (cold start, Newton budget 1: no kernel uses z as its working storage except for a flagged problem), write the outputs
+    // straight into it -- no copy down.  FMPC_NO_ZEROCOPY=1: the copies as before (A/B).
+    static const bool no_zc = [] { const char* e = getenv("FMPC_NO_ZEROCOPY"); return e && e[0] == '1'; }();
+    char* pin_dev = nullptr;
+    if (pin && !no_zc && off <= FMPC_ZC_LIMIT && hipHostGetDevicePointer((void**)&pin_dev, pin, 0) != hipSuccess) pin_dev = nullptr;
+    const bool zc_in = pin_dev != nullptr;
+    const bool zc_out = zc_in && n_newton == 1 && z_init == nullptr && u_prev == nullptr;
+    char* const base_in = zc_in ? pin_dev : base;
+    char* const base_o = zc_out ? pin_dev : base;
+    auto dptr = [&](const void* src, size_t o) -> const double* { return src ? (const double*)(base_in + o) : nullptr; };
     if (pin) {
         auto pack = [&](size_t o, const double* src, size_t cnt) { if (src) memcpy(pin + o, src, cnt * 8); };
         pack(o_x0, x0, n * B); pack(o_x0p, x0_pre, n * B); pack(o_w, w, Tn * B); pack(o_zi, z_init, Nz * B); pack(o_nu0, nu0, nbn * B);
         pack(o_up, u_prev, (size_t)h->m * B);
-        if (hipMemcpyAsync(base, pin, in_bytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) return FMPC_E_HIP;
+        if (!zc_in && hipMemcpyAsync(base, pin, in_bytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) return FMPC_E_HIP;
     } else {
         auto up = [&](size_t o, const double* src, size_t cnt) { return !src || hipMemcpy(base + o, src, cnt * 8, hipMemcpyHostToDevice) == hipSuccess; };
         if (!up(o_x0, x0, n * B) || !up(o_x0p, x0_pre, n * B) || !up(o_w, w, Tn * B) || !up(o_zi, z_init, Nz * B) || !up(o_nu0, nu0, nbn * B) ||
             !up(o_up, u_prev, (size_t)h->m * B)) return FMPC_E_HIP;
     }
-    int* d_st = (int*)(base + o_st);
-    int* d_it = (int*)(base + o_it);
-    double* d_nu = nu_out ? (double*)(base + o_nu) : nullptr;
-    double* d_step = step ? (double*)(base + o_step) : nullptr;
+    int* d_st = (int*)(base_o + o_st);
+    int* d_it = (int*)(base_o + o_it);
+    double* d_nu = nu_out ? (double*)(base_o + o_nu) : nullptr;
+    double* d_step = step ? (double*)(base_o + o_step) : nullptr;
     fmpc_tl_contiguous_z = 1;                                   // (the staging block's rows are contiguous: fmpc_set_z_ld is for device batches)
-    double* d_z = z_out ? (double*)(base + o_z) : nullptr;
+    double* d_z = z_out ? (double*)(base_o + o_z) : nullptr;
     int rc = u_prev ? fmpc_solve_ramp_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(u_prev, o_up), dptr(z_init, o_zi),
                                              dptr(nu0, o_nu0), n_newton, k, d_z, d_nu, d_st, d_it, d_step, nullptr)
             : u0_out ? fmpc_solve_u0_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
-                                            n_newton, k, d_z, d_nu, d_st, d_it, d_step, (double*)(base + o_u0), nullptr)
+                                            n_newton, k, d_z, d_nu, d_st, d_it, d_step, (double*)(base_o + o_u0), nullptr)
                     : fmpc_solve_device(h, batch, dptr(x0, o_x0), dptr(x0_pre, o_x0p), dptr(w, o_w), dptr(z_init, o_zi), dptr(nu0, o_nu0),
                                         n_newton, k, d_z, d_nu, d_st, d_it, d_step, nullptr);
     fmpc_tl_contiguous_z = 0;
@@ -2252,7 +2265,7 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     std::vector<int> stv;
     const int* st;
     if (pin) {
-        if (hipMemcpyAsync(pin + o_out, base + o_out, off - o_out, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return FMPC_E_HIP;
+        if (!zc_out && hipMemcpyAsync(pin + o_out, base + o_out, off - o_out, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return FMPC_E_HIP;
         if (hipStreamSynchronize(nullptr) != hipSuccess) return FMPC_E_HIP;
         if (z_out) memcpy(z_out, pin + o_z, Nz * B * 8);
         if (u0_out) memcpy(u0_out, pin + o_u0, (size_t)h->m * B * 8);

@@ -439,3 +439,50 @@ def test_host_pointer_first_move_entry(pkg, gpu):
         assert lib.fmpc_solve_u0(h._h, B, _p(d["x0"]), _p(d["x0_pre"]), None, None, None, 1, 1e-2, _p(zr), None, None, None) == pkg.FMPC_E_NULL
         assert lib.fmpc_solve_u0(h._h, -1, _p(d["x0"]), None, None, None, None, 1, 1e-2, None, _p(ur), None, None) == pkg.FMPC_E_DIM
         h.close()
+
+
+def test_small_host_calls_work_on_the_pinned_block(pkg, gpu, monkeypatch):
+    """A host-pointer call of a few problems skips both copies (the kernels read the inputs from, and -- cold start, budget 1 --
+    write the outputs into, the pinned block itself).  Same numbers, bit for bit, as the same call with the copies
+    (FMPC_NO_ZEROCOPY=1, read once per process: a child process) and as the device entry -- also when problems are flagged and
+    the exact path then uses z in host memory as its working iterate, with w, with a budget, from an explicit start."""
+    import subprocess, sys, os, tempfile
+    md = pkg.synthetic.make_model(27, 144, 30)
+    md["u_min"] = -0.1 * np.ones(144); md["u_max"] = 0.1 * np.ones(144)          # tight bounds: some decisions are not clear-cut
+    d = pkg.synthetic.make_replay_batch(md, r=20, steps=2)
+    x0 = d["x0"] * np.array([[0.05], [5.0]]); x0p = d["x0_pre"] * np.array([[0.05], [5.0]])
+    rng = np.random.default_rng(1)
+    w = 0.01 * rng.standard_normal((2, 30 * 27)); zi = 0.02 * rng.standard_normal((2, 30 * 171))
+    cases = (dict(n_newton=1), dict(n_newton=1, w=w), dict(n_newton=3), dict(n_newton=2, z_init=zi))
+    h = handle_from_model(pkg, md)
+    got = []
+    for kw in cases:
+        z, info = h.solve(x0, x0p, kw.get("w"), z_init=kw.get("z_init"), nu0=d["nu0"], n_newton=kw["n_newton"], k=1e-2, return_info=True, check=False)
+        u0 = h.solve_u0(x0, x0p, kw.get("w"), z_init=kw.get("z_init"), nu0=d["nu0"], n_newton=kw["n_newton"], k=1e-2, check=False)
+        assert np.array_equal(u0, z[:, :144])
+        got.append((z, info["nu"], info["status"], info["iters"], info["step"]))
+    assert h.last_dispatch()[0] is not None
+    z1, i1 = h.solve(x0, x0p, None, nu0=d["nu0"], n_newton=1, k=1e-2, return_info=True, check=False)
+    assert h.last_dispatch()[1] > 0, "no problem was flagged: the case does not exercise the exact path on host memory"
+    h.close()
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), x0=x0, x0p=x0p, w=w, zi=zi, nu0=d["nu0"])
+        code = (
+            "import importlib, sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "pkg = importlib.import_module('mpc-sensorlessao_amd')\n"
+            "from tests.util import handle_from_model\n"
+            "md = pkg.synthetic.make_model(27, 144, 30); md['u_min'] = -0.1 * np.ones(144); md['u_max'] = 0.1 * np.ones(144)\n"
+            "a = np.load(%r); h = handle_from_model(pkg, md); out = {}\n"
+            "cases = (dict(n_newton=1), dict(n_newton=1, w=a['w']), dict(n_newton=3), dict(n_newton=2, z_init=a['zi']))\n"
+            "for i, kw in enumerate(cases):\n"
+            "    z, info = h.solve(a['x0'], a['x0p'], kw.get('w'), z_init=kw.get('z_init'), nu0=a['nu0'], n_newton=kw['n_newton'], k=1e-2, return_info=True, check=False)\n"
+            "    out['z%%d' %% i] = z; out['nu%%d' %% i] = info['nu']; out['st%%d' %% i] = info['status']; out['it%%d' %% i] = info['iters']; out['sp%%d' %% i] = info['step']\n"
+            "np.savez(%r, **out)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "in.npz"), os.path.join(td, "out.npz"))
+        env = dict(os.environ, FMPC_NO_ZEROCOPY="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ref = np.load(os.path.join(td, "out.npz"))
+        for i, (z, nu, st, it, sp) in enumerate(got):
+            assert np.array_equal(z, ref["z%d" % i]) and np.array_equal(nu, ref["nu%d" % i]), i
+            assert np.array_equal(st, ref["st%d" % i]) and np.array_equal(it, ref["it%d" % i]) and np.array_equal(sp, ref["sp%d" % i], equal_nan=True), i
