@@ -178,7 +178,7 @@ struct fmpc_handle_s {
     // staging for the host-pointer entry points
     void* stage;
     size_t stage_bytes;
-    void* pin; size_t pin_bytes;         // pinned host twin of the staging block for small host-pointer solves (fmpc_solve_host)
+    void* pin; void* pin_dev; size_t pin_bytes;         // pinned host twin of the staging block for small host-pointer solves (fmpc_solve_host)
 };
 
 extern "C" int fmpc_version(void) { return FMPC_VERSION; }
@@ -325,7 +325,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->nb = T + h->has_xf; h->device = device;
     h->pool_d = nullptr; h->pool_i = nullptr; h->ws = nullptr; h->ws_doubles = 0; h->zs = nullptr; h->zs_doubles = 0;
     h->stage = nullptr; h->stage_bytes = 0; h->lds_bytes = lds;
-    h->pin = nullptr; h->pin_bytes = 0;
+    h->pin = nullptr; h->pin_bytes = 0; h->pin_dev = nullptr;
     h->ramp_du = nullptr; h->ramp_ws = nullptr; h->ramp_ws_doubles = 0;
     { const char* e = getenv("FMPC_NO_RAMP_COLD"); h->rc_disabled = (e && e[0] == '1') ? 1 : 0; }
     h->rc_valid = 0; h->rc_failed = 0; h->rc_last = 0; h->rc_k = 0.0; h->rc_failed_k = 0.0; h->rc_pool = nullptr;
@@ -2206,6 +2206,7 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     const bool pinned = off <= FMPC_PIN_LIMIT;
     char* base;
     char* pin = nullptr;
+    char* pin_dev = nullptr;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         if (off > h->stage_bytes) {
@@ -2219,10 +2220,14 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
                 if (h->pin) { (void)hipDeviceSynchronize(); (void)hipHostFree(h->pin); h->pin = nullptr; h->pin_bytes = 0; }
                 size_t want = 64 * 1024;
                 while (want < off) want *= 2;
-                if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) == hipSuccess) h->pin_bytes = want;
-                else h->pin = nullptr;                              // (no pinned memory: the blocking copies below still work)
+                h->pin_dev = nullptr;
+                if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) == hipSuccess) {
+                    h->pin_bytes = want;
+                    if (hipHostGetDevicePointer(&h->pin_dev, h->pin, 0) != hipSuccess) h->pin_dev = nullptr;   // (the block as the kernels see it)
+                } else h->pin = nullptr;                            // (no pinned memory: the blocking copies below still work)
             }
             pin = (char*)h->pin;
+            pin_dev = (char*)h->pin_dev;
         }
     }
     // A call of a few problems (the reference's per-timestep call is ONE) is all latency: the two copies and their
@@ -2231,9 +2236,7 @@ static int fmpc_solve_host(fmpc_handle h, int batch,
     // (cold start, Newton budget 1: no kernel uses z as its working storage except for a flagged problem), write the outputs
     // straight into it -- no copy down.  FMPC_NO_ZEROCOPY=1: the copies as before (A/B).
     static const bool no_zc = [] { const char* e = getenv("FMPC_NO_ZEROCOPY"); return e && e[0] == '1'; }();
-    char* pin_dev = nullptr;
-    if (pin && !no_zc && off <= FMPC_ZC_LIMIT && hipHostGetDevicePointer((void**)&pin_dev, pin, 0) != hipSuccess) pin_dev = nullptr;
-    const bool zc_in = pin_dev != nullptr;
+    const bool zc_in = pin != nullptr && pin_dev != nullptr && !no_zc && off <= FMPC_ZC_LIMIT;
     const bool zc_out = zc_in && n_newton == 1 && z_init == nullptr && u_prev == nullptr;
     char* const base_in = zc_in ? pin_dev : base;
     char* const base_o = zc_out ? pin_dev : base;
