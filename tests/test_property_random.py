@@ -151,3 +151,31 @@ def test_hip_equals_structured_oracle_on_random_problems(pkg, gpu):
         h.close()
     assert solved >= 200, solved
     print("random problems solved on the device: %d, worst relative error on z %.2e" % (solved, worst))
+
+
+@pytest.mark.gpu
+def test_hip_equals_structured_oracle_on_random_problems_of_any_size(pkg, gpu):
+    """The same property beyond the specialised kernels' sizes (n = 80 .. 140, diagonal weights): the generic kernel with its tiles
+    in the HBM workspace (tests/test_gpu_any_size.py), 12 random models, cold and explicit starts, linear costs, terminal rows."""
+    from tests.util import oracle_batch
+    rng = np.random.default_rng(20261005)
+    worst, solved = 0.0, 0
+    for i in range(12):
+        n = int(rng.integers(80, 141)); m = int(rng.integers(1, 201)); T = int(rng.integers(1, 7))
+        c = dict(seed=5000 + i, n=n, m=m, T=T, var_order=int(rng.integers(1, 3)), xf=bool(rng.integers(0, 2)) and m >= n, lin=bool(rng.integers(0, 2)),
+                 k=float(rng.choice([1e-2, 1e-1, 1.0])), nw=int(rng.integers(1, 5)), warm=bool(rng.integers(0, 2)), batch=int(rng.integers(2, 4)))
+        model, data = random_problem(c["seed"], n, m, T, c["var_order"], False, False, c["xf"], c["lin"], batch=c["batch"])
+        zi = random_interior_start(c["seed"], model, c["batch"]) if c["warm"] else None
+        h = handle_from_model(pkg, model)
+        z, info = h.solve(data["x0"], data["x0_pre"], data["w"], z_init=zi, nu0=data["nu0"], n_newton=c["nw"], k=c["k"], return_info=True, check=False)
+        assert h.last_dispatch()[0] == pkg.FMPC_PATH_GENERIC
+        h.close()
+        zo, nuo, ito, sto, steps = oracle_batch(model, data, c["nw"], c["k"], z_init=zi)
+        assert np.array_equal(info["status"], sto) and (sto >= 0).all(), (c, info["status"], sto)
+        assert np.array_equal(info["iters"], ito), c
+        for p in range(c["batch"]):
+            e = rel_err(z[p], zo[p])
+            worst = max(worst, e)
+            assert e <= 1e-9, (c, p, e)
+        solved += c["batch"]
+    print("random problems of any size solved on the device: %d, worst relative error on z %.2e" % (solved, worst))
