@@ -68,14 +68,15 @@ const char* fmpc_strerror(int code);
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
  *   n          any.  Specialised kernels: n = 27 (the AO configuration), n <= 47 in fp64 and n <= 79 with the fp32 factor + fp64
- *              residuals (fmpc_set_precision) on the matrix cores; every other size with diagonal Q, R, Qf (the reference checks
- *              shapes only, fast_mpc_objective.m:17-47) is solved in fp64 by the generic kernel with its tiles in the HBM
- *              workspace -- a size fallback without a speed claim (tests/test_gpu_any_size.py: n = 83 .. 130).
- *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices.  Dense Q or Qf:
- *              solved by the tiled kernel, n <= 47 in fp64, <= 79 with the fp32 factor.  Dense R: the u block of Phi is
- *              then a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS by the
- *              tiled kernel in fp64 (n <= 47, m (m + 1) / 2 + m (n + 2) doubles of LDS: m = 144 fits); a generality
- *              path, ~13 x slower than a diagonal R.  Ramp rows (fmpc_set_ramp) need diagonal weights.
+ *              residuals (fmpc_set_precision) on the matrix cores; every other size (the reference checks shapes only,
+ *              fast_mpc_objective.m:17-47) is solved in fp64 by the generic kernel with its tiles in the HBM workspace -- a size
+ *              fallback without a speed claim (tests/test_gpu_any_size.py: n = 83 .. 140).
+ *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices, at any size.  Dense Q
+ *              or Qf: the tiled kernel (n <= 47 in fp64, <= 79 with the fp32 factor), beyond it the workspace instance.  Dense
+ *              R: the u block of Phi is then a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored
+ *              per stage (ft_dense_r) -- in LDS by the tiled kernel in fp64 (n <= 47, m (m + 1) / 2 + m (n + 2) doubles:
+ *              m = 144 fits), in the workspace beyond; a generality path, ~13 x slower than a diagonal R.  Ramp rows
+ *              (fmpc_set_ramp) need diagonal weights and n <= 64.
  *              Not positive definite / not symmetric: FMPC_E_NOT_PD_PHI (the reference's chol(KKT_H) error,
  *              inf_newton_solver.m:24).
  *   q,r,qf     NULL = zeros (fast_mpc_objective.m:26-47).

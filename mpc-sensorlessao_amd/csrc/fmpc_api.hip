@@ -309,7 +309,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     bool generic_big = false;
     { const char* fb = getenv("FMPC_GENERIC_BIG");
       if ((!generic_ok && !tiled64 && !tiled32) || (fb && fb[0] == '1'))
-          generic_big = !denseQ && !denseR && fmpc_generic_big_lds_bytes(n, m) <= FMPC_LDS_LIMIT; }
+          generic_big = fmpc_generic_big_lds_bytes(n, m) <= FMPC_LDS_LIMIT; }   // (dense Q, Qf, R: taken)
     if (generic_big) { generic_ok = true; lds = fmpc_generic_big_lds_bytes(n, m); }
     if (!generic_ok && !tiled64 && !tiled32) return FMPC_E_UNSUPPORTED;
     if (!generic_ok) lds = 0;
@@ -420,6 +420,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     for (int i = 0; i < n; ++i) xmid[i] = (x_min[i] + x_max[i]) / 2;
     const size_t oumid = push(umid.data(), m), oxmid = push(xmid.data(), n);
     const size_t oxf = push_opt(xf, n);
+    // dense Q, Qf for the generic kernel's workspace instance: 2Q, 2Qf and their inverses
+    const size_t oQ2m = push(Q2m.data(), nn), oQf2m = push(Qf2m.data(), nn), oXm = push(X.data(), nn), oXfm = push(Xf.data(), nn);
+    const size_t oR2m = denseR ? push(R2full.data(), R2full.size()) : 0;
     // closed-loop prediction matrices (main.mlx, MPC_DesignMatrices): M1_0 = A1, M2_0 = A2, M1_1 = A1^2 + A2,
     // M2_1 = A1 A2, M1_i = A1 M1_{i-1} + A2 M1_{i-2}, M2_i = M1_{i-1} A2
     std::vector<double> lm1((size_t)T * nn, 0.0), lm2((size_t)T * nn, 0.0);
@@ -472,6 +475,8 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     D.umin = h->pool_d + oumin; D.umax = h->pool_d + oumax; D.umid = h->pool_d + oumid;
     D.xmid = h->pool_d + oxmid; D.xf = h->pool_d + oxf; D.Yblk = h->pool_d + oY;
     D.idxD = h->pool_i; D.idx1 = h->pool_i + h->nb; D.idx2 = h->pool_i + 2 * h->nb;
+    D.denseR = denseR ? 1 : 0; D.R2m = denseR ? h->pool_d + oR2m : nullptr;
+    D.denseQ = denseQ ? 1 : 0; D.Q2m = h->pool_d + oQ2m; D.Qf2m = h->pool_d + oQf2m; D.Xm = h->pool_d + oXm; D.Xfm = h->pool_d + oXfm;
     h->loop_M1 = h->pool_d + oM1; h->loop_M2 = h->pool_d + oM2;
 
     if (generic_ok && fmpc_generic_prepare(lds, generic_big ? 1 : 0) != hipSuccess) { fmpc_destroy(h); return FMPC_E_HIP; }
@@ -895,7 +900,7 @@ extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
         // sizes whose default is the fp32 factor (47 < n <= 79, diagonal weights): fp64 on request through the generic kernel
         // with its tiles in the workspace (slow; the fp64 answer on the device for a configs[4]-sized problem)
         const size_t lds = fmpc_generic_big_lds_bytes(h->n, h->m);
-        if (h->denseQ || h->denseR || lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
+        if (lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
         if (fmpc_generic_prepare(lds, 1) != hipSuccess) return FMPC_E_HIP;
         h->generic_ok = 1; h->generic_big = 1; h->lds_bytes = lds; h->wg_per_cu = 2;
     }
@@ -910,7 +915,7 @@ static int fmpc_grid_for(fmpc_handle h, int batch) {
 
 // grows the per-workgroup workspace; caller holds h->mu
 static int fmpc_ensure_ws(fmpc_handle h, int grid, size_t* stride) {
-    const FmpcWsLayout L = fmpc_ws_layout(h->n, h->m, h->T, h->nb, h->generic_big != 0);
+    const FmpcWsLayout L = fmpc_ws_layout(h->n, h->m, h->T, h->nb, h->generic_big != 0, h->denseR != 0);
     *stride = L.total;
     const size_t need = L.total * (size_t)grid;
     if (need > h->ws_doubles) {
@@ -1256,7 +1261,7 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
     const int zld = (!z_null && !fmpc_tl_contiguous_z && fmpc_effective_zld(h) > h->T * (h->n + h->m)) ? fmpc_effective_zld(h) : 0;
     if (zld && (w != nullptr || z_init != nullptr || max_iter != 1 || h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ ||
                 h->denseR || !h->use_wave || !h->sh_enabled || !h->pn_enabled)) return FMPC_E_UNSUPPORTED;
-    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ || h->denseR || (!h->use_wave && !h->generic_ok))
+    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || ((h->denseQ || h->denseR) && !h->generic_big) || (!h->use_wave && !h->generic_ok))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
     if (h->use_wave) {

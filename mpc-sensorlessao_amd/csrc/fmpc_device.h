@@ -15,6 +15,10 @@ struct FmpcDevModel {
     const double* R2;         // 2*diag(R)  (m)            Phi u-block without the barrier term
     const double* Q2;         // 2*diag(Q)  (n)
     const double* Qf2;        // 2*diag(Qf) (n)
+    int denseQ;               // Q or Qf not diagonal (generic kernel, workspace instance only): 2Q, 2Qf and their inverses, n x n row-major
+    const double* Q2m; const double* Qf2m; const double* Xm; const double* Xfm;
+    int denseR;               // R not diagonal (same instance): 2R, m x m row-major
+    const double* R2m;
     const double* rl;         // linear cost r (m), q (n), qf (n)
     const double* ql;
     const double* qfl;
@@ -32,10 +36,10 @@ struct FmpcDevModel {
 // Per-workgroup scratch in HBM (doubles).  The factor tiles are written during the forward
 // sweep and streamed back once, in reverse, by the backward sweep.
 struct FmpcWsLayout {
-    size_t b, nu, hess, winv, rdu, rdx, rp, y, dnu, fac, tiles, total;
+    size_t b, nu, hess, winv, rdu, rdx, rp, y, dnu, fac, tiles, drs, zt, total;
 };
 
-__host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int T, int nb, bool big = false) {
+__host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int T, int nb, bool big = false, bool dense_r = false) {
     FmpcWsLayout L;
     size_t o = 0;
     const size_t nbn = (size_t)nb * n, Tm = (size_t)T * m, Tn = (size_t)T * n;
@@ -50,6 +54,9 @@ __host__ __device__ static inline FmpcWsLayout fmpc_ws_layout(int n, int m, int 
     L.dnu = o;  o += nbn;
     L.fac = o;  o += (size_t)nb * 3 * n * (n + 1);
     L.tiles = o; if (big) o += 6 * (size_t)n * (n + 1);          // the generic kernel's tiles when they do not fit the LDS (any n)
+    // dense R in that instance: the scratch of ft_dense_r (packed triangle, right-hand sides, pivots) and [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]] per stage
+    L.drs = o; if (big && dense_r) o += (size_t)m * (m + 1) / 2 + (size_t)m * (n + 2);
+    L.zt = o; if (big && dense_r) o += (size_t)T * m * (n + 1);
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "fmpc_device.h"
+#include "fmpc_dense_r.h"
 #include "../../include/fastmpc.h"
 
 #define FMPC_THREADS 256
@@ -62,7 +63,9 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
     const int tid = threadIdx.x;
     const bool var2 = M.var2 != 0;
 
-    const FmpcWsLayout L = fmpc_ws_layout(n, m, T, nb, BIG);
+    const FmpcWsLayout L = fmpc_ws_layout(n, m, T, nb, BIG, BIG && M.denseR != 0);
+    const bool DR = BIG && M.denseR != 0;       // dense R: Rt_j^-1 applied through zt (ft_dense_r), not through winv
+    const int ZLD = n + 1;
     double* wsp = ws + (size_t)blockIdx.x * ws_stride;
     // ---- LDS carve (BIG: B' stays in the model, the tiles live in the workspace slot)
     const double* sBt = BIG ? M.Bt : lds;                                 // m*n
@@ -87,6 +90,7 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
     double* y = wsp + L.y;
     double* dnu = wsp + L.dnu;
     double* fac = wsp + L.fac;
+    double* zt = wsp + L.zt;
 
     for (int p = blockIdx.x; p < batch; p += gridDim.x) {
         double* zp = zout + (size_t)p * Nz;
@@ -128,22 +132,40 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                 const double u = zp[j * s + c];
                 const double dp = 1.0 / (M.umax[c] - u), dm = 1.0 / (u - M.umin[c]);
                 const double hs = kbar * (dp * dp + dm * dm);
-                const double rt = M.R2[c] + hs;
-                if (!(rt > 0.0) || isinf(rt)) bad = 1;
+                const double rt = (DR ? 0.0 : M.R2[c]) + hs;
+                if (DR ? (!(hs >= 0.0) || isinf(hs)) : (!(rt > 0.0) || isinf(rt))) bad = 1;
                 double dot = 0.0;
                 const double* bt = sBt + c * n;
                 const double* nj = nu + j * n;
                 for (int r = 0; r < n; ++r) dot += bt[r] * nj[r];
-                const double rd = M.R2[c] * u + M.rl[c] + kbar * (dp - dm) - dot;
+                double ru2;                                             // (2R u_j)_c
+                if (DR) {
+                    const double* rr = M.R2m + (size_t)c * m;
+                    const double* uj = zp + j * s;
+                    ru2 = 0.0;
+                    for (int q = 0; q < m; ++q) ru2 += rr[q] * uj[q];
+                } else {
+                    ru2 = M.R2[c] * u;
+                }
+                const double rd = ru2 + M.rl[c] + kbar * (dp - dm) - dot;
                 hess[idx] = hs;
-                winv[idx] = 1.0 / rt;
+                winv[idx] = DR ? 0.0 : 1.0 / rt;
                 rdu[idx] = rd;
                 acc_d += rd * rd;
             }
             for (int idx = tid; idx < T * n; idx += FMPC_THREADS) {
                 const int jj = idx / n, r = idx - jj * n, j = jj + 1;   // x_j, j = 1..T
                 const double x = zp[jj * s + m + r];
-                double v = (j == T ? M.Qf2[r] * x + M.qfl[r] : M.Q2[r] * x + M.ql[r]) + nu[jj * n + r];
+                double v;
+                if (BIG && M.denseQ) {                                  // dense Q, Qf (fast_mpc_objective.m:52-55): (2Q x_j)_r
+                    const double* qr = (j == T ? M.Qf2m : M.Q2m) + (size_t)r * n;
+                    const double* xj = zp + jj * s + m;
+                    double t = 0.0;
+                    for (int c = 0; c < n; ++c) t += qr[c] * xj[c];
+                    v = t + (j == T ? M.qfl[r] : M.ql[r]) + nu[jj * n + r];
+                } else {
+                    v = (j == T ? M.Qf2[r] * x + M.qfl[r] : M.Q2[r] * x + M.ql[r]) + nu[jj * n + r];
+                }
                 if (j < T) {
                     const double* nj = nu + j * n;
                     for (int c = 0; c < n; ++c) v -= M.A1[c * n + r] * nj[c];
@@ -154,8 +176,19 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                 }
                 if (j == T && M.has_xf) v += nu[T * n + r];
                 rdx[idx] = v;
-                dnu[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);   // Phi^-1 r_d on x_j (temp)
+                if (!(BIG && M.denseQ)) dnu[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);   // Phi^-1 r_d on x_j (temp)
                 acc_d += v * v;
+            }
+            if (BIG && M.denseQ) {
+                __syncthreads();
+                for (int idx = tid; idx < T * n; idx += FMPC_THREADS) {
+                    const int jj = idx / n, r = idx - jj * n;
+                    const double* xr = (jj + 1 == T ? M.Xfm : M.Xm) + (size_t)r * n;
+                    const double* vj = rdx + jj * n;
+                    double t = 0.0;
+                    for (int c = 0; c < n; ++c) t += xr[c] * vj[c];
+                    dnu[idx] = t;
+                }
             }
             for (int idx = tid; idx < nbn; idx += FMPC_THREADS) {
                 const int i = idx / n, r = idx - i * n;
@@ -184,6 +217,11 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
             // early exit, tested before the step (inf_newton_solver.m:19-22)
             if (sqrt(rho2) <= 1e-6 && sqrt(rp2) <= 1e-8) break;
             if (badsum > 0.0) { st = FMPC_E_NOT_PD_PHI; break; }
+            if (DR) {
+                // dense R (fast_mpc_objective.m:51-54): factor Rt_j = 2R + k diag(..) of every stage, zt[j] = [Rt_j^-1 B' | Rt_j^-1 r_d[u_j]]
+                __syncthreads();
+                if (ft_dense_r(wsp + L.drs, M.R2m, m, M.Bt, hess, rdu, zt, n, m, T)) { st = FMPC_E_NOT_PD_PHI; break; }
+            }
 
             // ================= P2: rhs_i = r_p,i - (C Phi^-1 r_d)_i   (into y)
             for (int idx = tid; idx < nbn; idx += FMPC_THREADS) {
@@ -194,7 +232,8 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                     cv = phx[i * n + r];
                     const double* ru = rdu + i * m;
                     const double* wi = winv + i * m;
-                    for (int c = 0; c < m; ++c) cv -= sBt[c * n + r] * (ru[c] * wi[c]);
+                    if (DR) { const double* zj = zt + (size_t)i * m * ZLD + n; for (int c = 0; c < m; ++c) cv -= sBt[c * n + r] * zj[(size_t)c * ZLD]; }
+                    else for (int c = 0; c < m; ++c) cv -= sBt[c * n + r] * (ru[c] * wi[c]);
                     if (i >= 1) {
                         const double* px = phx + (i - 1) * n;
                         for (int c = 0; c < n; ++c) cv -= M.A1t[c * n + r] * px[c];
@@ -239,7 +278,8 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                             double acc = Yd[a * n + bb];
                             if (hasB) {
                                 double t = 0.0;
-                                for (int c = 0; c < m; ++c) t += sBt[c * n + a] * sw[c] * sBt[c * n + bb];
+                                if (DR) { const double* zi_ = zt + (size_t)i * m * ZLD + bb; for (int c = 0; c < m; ++c) t += sBt[c * n + a] * zi_[(size_t)c * ZLD]; }
+                                else for (int c = 0; c < m; ++c) t += sBt[c * n + a] * sw[c] * sBt[c * n + bb];
                                 acc += t;
                             }
                             if (vA) {
@@ -408,7 +448,14 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                 const double* dj = dnu + j * n;
                 for (int r = 0; r < n; ++r) dot += bt[r] * dj[r];
                 const double rd = rdu[idx];
-                const double du = (dot - rd) * winv[idx];
+                double du;
+                if (DR) {                                               // d_u = Rt^-1 (B' d_nu - r_d[u]) = Z d_nu - Rt^-1 r_d[u]
+                    const double* zc = zt + ((size_t)j * m + c) * ZLD;
+                    du = -zc[n];
+                    for (int r = 0; r < n; ++r) du += zc[r] * dj[r];
+                } else {
+                    du = (dot - rd) * winv[idx];
+                }
                 const double e = hess[idx] * du;        // k P'DP dz
                 be += rd * e;
                 e2 += e * e;
@@ -426,7 +473,19 @@ fmpc_newton_generic(FmpcDevModel M, int batch,
                     for (int c = 0; c < n; ++c) v += M.A2[c * n + r] * dj[c];
                 }
                 if (j == T && M.has_xf) v -= dnu[T * n + r];
-                rdx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);   // reuse as d_x
+                if (BIG && M.denseQ) rp[idx] = v;               // (r_p is dead since P2: takes the right-hand side of d_x)
+                else rdx[idx] = v / (j == T ? M.Qf2[r] : M.Q2[r]);   // reuse as d_x
+            }
+            if (BIG && M.denseQ) {
+                __syncthreads();
+                for (int idx = tid; idx < T * n; idx += FMPC_THREADS) {
+                    const int jj = idx / n, r = idx - jj * n;
+                    const double* xr = (jj + 1 == T ? M.Xfm : M.Xm) + (size_t)r * n;
+                    const double* vj = rp + jj * n;
+                    double t = 0.0;
+                    for (int c = 0; c < n; ++c) t += xr[c] * vj[c];
+                    rdx[idx] = t;
+                }
             }
             const double beta_e = fmpc_block_sum(be, red);
             const double eps2 = fmpc_block_sum(e2, red);

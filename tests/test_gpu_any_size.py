@@ -69,14 +69,34 @@ def test_first_moves_and_device_entry_at_a_big_size(pkg, gpu):
     h.close()
 
 
-def test_dense_weights_at_a_big_size_are_refused_cleanly(pkg, gpu):
-    model, data = pkg.synthetic.make_test_problem(100, 10, 3, seed=2, batch=1)
-    Qd = np.array(model["Q"], dtype=float)
-    Qd[0, 1] = Qd[1, 0] = 1e-3
-    model["Q"] = Qd
-    with pytest.raises(pkg.FastMPCError) as ei:
-        handle_from_model(pkg, model)
-    assert ei.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+def test_dense_state_weights_at_any_size(pkg, gpu, monkeypatch):
+    """Dense symmetric positive definite Q, Qf (fast_mpc_objective.m:52-55) beyond the tiled kernel's sizes: the workspace
+    instance applies 2Q, 2Qf and their inverses as matrices.  Also forced on a small model, and fp64 on request at n = 60."""
+    from tests.test_property_random import random_problem
+    for (seed, n, m, T, var, xf, lin) in ((11, 90, 30, 4, 2, False, True), (12, 84, 100, 3, 1, True, False)):
+        model, data = random_problem(seed, n, m, T, var, True, False, xf, lin, batch=3)
+        _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC)
+    model, data = random_problem(13, 60, 20, 4, 2, True, False, False, True, batch=2)
+    _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC, prec="f64")
+    monkeypatch.setenv("FMPC_GENERIC_BIG", "1")
+    model, data = random_problem(14, 9, 6, 5, 2, True, False, True, True, batch=4)
+    _compare(pkg, model, data, 4, 0.01, expect_path=pkg.FMPC_PATH_GENERIC)
+
+
+def test_dense_input_weight_at_any_size(pkg, gpu, monkeypatch):
+    """Dense symmetric positive definite R (fast_mpc_objective.m:51-54; the u block of Phi is then a dense m x m matrix per stage and
+    Newton step, inf_newton_KKT_H.m:13) beyond the tiled kernel's n <= 47: factored per stage in the workspace (ft_dense_r).  With
+    dense Q too, with backtracking (tight bounds, off-centre start), and forced on a small model."""
+    from tests.test_property_random import random_problem, random_interior_start
+    for (seed, n, m, T, var, dq, xf, lin) in ((21, 90, 30, 3, 2, False, False, True), (22, 60, 70, 3, 1, True, True, False)):
+        model, data = random_problem(seed, n, m, T, var, dq, True, xf, lin, batch=3)
+        _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC)
+    model, data = random_problem(23, 85, 12, 4, 2, False, True, False, True, batch=3, umax=0.4)
+    zi = random_interior_start(23, model, 3)
+    z, info = _compare(pkg, model, data, 6, 5.0, z_init=zi, expect_path=pkg.FMPC_PATH_GENERIC)
+    monkeypatch.setenv("FMPC_GENERIC_BIG", "1")
+    model, data = random_problem(24, 9, 6, 5, 2, True, True, True, True, batch=4)
+    _compare(pkg, model, data, 4, 0.01, expect_path=pkg.FMPC_PATH_GENERIC)
 
 
 def test_closed_loop_step_at_a_big_size(pkg, gpu):

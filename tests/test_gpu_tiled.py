@@ -179,28 +179,24 @@ def test_tiled_fp32_random_models_over_the_block_sizes(pkg, gpu, n, m, T, var, x
 
 
 def test_precision_switch_errors(pkg, gpu):
-    """Dense weights have no fp64 kernel beyond n = 47 and no kernel at all beyond n = 79: refused cleanly.  (Diagonal weights: any
-    size is solved -- fp64 on request at n = 65, and n = 80 at all -- by the generic kernel's workspace instance,
-    tests/test_gpu_any_size.py.)"""
+    """The fp32 factor exists for diagonal R only: refused cleanly with a dense R.  (fp64: every size and every weight is solved --
+    beyond the matrix-core kernels by the generic kernel's workspace instance, tests/test_gpu_any_size.py.)"""
     model = pkg.synthetic.make_model(65, 144, 4)
-    Qd = np.array(model["Q"], dtype=float)
-    Qd[0, 1] = Qd[1, 0] = 1e-3 * Qd[0, 0]
-    dense = dict(model, Q=Qd)
-    h = handle_from_model(pkg, dense)
+    Rd = np.array(model["R"], dtype=float)
+    Rd[0, 1] = Rd[1, 0] = 1e-3 * Rd[0, 0]
+    h = handle_from_model(pkg, dict(model, R=Rd))
     with pytest.raises(pkg.FastMPCError) as e:
-        h.set_precision("f64")                            # dense Q: no fp64 kernel at n = 65
+        h.set_precision("f32")
     assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
+    h.set_precision("f64")
     h.close()
     h = handle_from_model(pkg, model)
     h.set_precision("f64"); h.set_precision("f32"); h.set_precision("f64")     # diagonal weights: both, back and forth
-    h.close()
-    model = pkg.synthetic.make_model(80, 16, 4)
-    Qd = np.array(model["Q"], dtype=float)
-    Qd[0, 1] = Qd[1, 0] = 1e-3 * Qd[0, 0]
     with pytest.raises(pkg.FastMPCError) as e:
-        handle_from_model(pkg, dict(model, Q=Qd))
-    assert e.value.code == pkg._lib.FMPC_E_UNSUPPORTED
-    handle_from_model(pkg, model).close()
+        h.set_precision(7)
+    assert e.value.code == pkg._lib.FMPC_E_DIM
+    h.close()
+    handle_from_model(pkg, pkg.synthetic.make_model(80, 16, 4)).close()
 
 
 def test_tiled_repeated_solves_alternating_wave_counts(pkg, gpu, tiled_env, monkeypatch):
@@ -250,7 +246,8 @@ def test_dense_spd_state_weights(pkg, gpu, n, m, T, xf, nw, umax):
 
 @pytest.mark.parametrize("n,m,T,xf,nw,umax,denseq", [(8, 5, 10, False, 5, 2.0, False), (8, 5, 10, True, 5, 2.0, True),
                                                      (8, 5, 10, False, 8, 0.3, False), (27, 144, 10, False, 3, None, False),
-                                                     (27, 144, 4, False, 2, None, True), (20, 33, 5, False, 4, 2.0, False)])
+                                                     (27, 144, 4, False, 2, None, True), (20, 33, 5, False, 4, 2.0, False),
+                                                     (40, 30, 4, False, 3, 2.0, False), (47, 20, 3, False, 3, 2.0, True)])   # n + 1 > 32 columns (round 5 fix)
 def test_dense_spd_input_weight(pkg, gpu, n, m, T, xf, nw, umax, denseq):
     """Random symmetric positive definite R (fast_mpc_objective.m:51-54 takes any square R): the u block of Phi,
     2R + k diag(1/s+^2 + 1/s-^2), is a dense m x m matrix per stage and Newton step (inf_newton_KKT_H.m:13), factored in LDS
