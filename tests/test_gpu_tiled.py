@@ -178,6 +178,26 @@ def test_tiled_fp32_random_models_over_the_block_sizes(pkg, gpu, n, m, T, var, x
     print(f"fp32 factor, random model n={n} m={m} T={T}: max rel err on z {err:.2e}")
 
 
+@pytest.mark.parametrize("n,m,T,var,xf", [(50, 30, 4, 2, False), (65, 70, 3, 1, True), (79, 40, 3, 2, False), (27, 144, 6, 2, False)])
+def test_tiled_fp32_dense_state_weights(pkg, gpu, n, m, T, var, xf):
+    """Dense Q, Qf with the fp32 factor (the default arithmetic for 47 < n <= 79; round 5: no test had this combination): three
+    Newton steps against the structured oracle at the fp32 tolerance, and against the fp64 answer of the same library (the generic
+    kernel's workspace instance)."""
+    from tests.test_property_random import random_problem
+    model, data = random_problem(8000 + n, n, m, T, var, True, False, xf and m >= n, True, batch=4)
+    err = _compare32(pkg, model, data, 3, 1e-1)
+    h = handle_from_model(pkg, model)
+    h.set_precision("f32")
+    z32 = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=3, k=1e-1, check=False)
+    if n > 47:
+        h.set_precision("f64")
+        z64 = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=3, k=1e-1, check=False)
+        assert h.last_dispatch()[0] == pkg.FMPC_PATH_GENERIC
+        assert rel_err(z32, z64) <= TOL32
+    h.close()
+    print(f"fp32 factor, dense Q, n={n}: max rel err on z {err:.2e}")
+
+
 def test_precision_switch_errors(pkg, gpu):
     """The fp32 factor exists for diagonal R only: refused cleanly with a dense R.  (fp64: every size and every weight is solved --
     beyond the matrix-core kernels by the generic kernel's workspace instance, tests/test_gpu_any_size.py.)"""
@@ -223,7 +243,8 @@ def _spd(n, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("n,m,T,xf,nw,umax", [(8, 5, 10, False, 5, 2.0), (8, 5, 10, True, 5, 2.0), (8, 5, 10, False, 8, 0.3),
-                                              (27, 144, 10, False, 3, None), (20, 33, 5, False, 4, 2.0)])
+                                              (27, 144, 10, False, 3, None), (20, 33, 5, False, 4, 2.0),
+                                              (40, 30, 4, False, 3, 2.0), (47, 50, 3, True, 3, 2.0)])          # three blocks of 16 (round 5)
 def test_dense_spd_state_weights(pkg, gpu, n, m, T, xf, nw, umax):
     """Random symmetric positive definite Q and Qf (R diagonal): Phi and Phi^-1 on the states are dense blocks, the
     constant Y blocks carry (2Q)^-1; handled by the tiled kernel whatever n.  Oracle: the structured restatement with the
