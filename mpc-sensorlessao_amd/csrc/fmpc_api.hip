@@ -1770,7 +1770,6 @@ extern "C" int fmpc_ao_step_device(fmpc_handle h, int batch, const double* x0, c
 static int fmpc_loop_run_walk(fmpc_handle h, int batch, int steps, int upto, const double* a, const double* nu0,
                               const double* ub1, const double* ub2, int have_x0_last, double k,
                               double* x0, double* x0_pre, double* w, double* U0, double* X0, int* status, int* iters, hipStream_t stream) {
-    const size_t sn = (size_t)batch * h->n, sm = (size_t)batch * h->m, snu = (size_t)batch * h->nb * h->n;
     std::vector<int> start(batch, 0), stop(batch, 0), idx, stp;      // (host sides of asynchronous copies: alive until the function returns)
     std::vector<std::vector<int>> keep;                              // index lists of the stepwise mode (no synchronisation between its copies)
     // Every walk costs a synchronisation, and every stop a gather + one-step call + scatter + a new batch-wide launch: on a stretch

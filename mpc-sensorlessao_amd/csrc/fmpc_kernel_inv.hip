@@ -168,7 +168,7 @@ __global__ void __launch_bounds__((KSPLIT == 16 ? 16 : 4) * 64) fmpc_cold_inv(Fp
     const FpParams Q = Pv;
     const FpParams* P = &Q;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
-    const int T = P->T, nb = P->nb, batch = P->batch, npanels = P->npanels, TN = T * FP_N;
+    const int nb = P->nb, batch = P->batch, npanels = P->npanels;
     const int nrow = nb * FP_N;
     const int nrt = (nrow + 15) / 16, npg = (npanels + PB - 1) / PB, rt8 = (nrt + 7) / 8;
     const int qcount = rt8 * npg;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(64 * RT * KS) fmpc_cold_inv_rg(FpParams Pv) {
 #ifdef FW_TIMING
     unsigned long long _tr[4] = {(unsigned long long)wall_clock64(), 0, 0, 0};
 #endif
-    const int T = P->T, nb = P->nb, batch = P->batch, npanels = P->npanels, TN = T * FP_N;
+    const int nb = P->nb, batch = P->batch, npanels = P->npanels;
     const int nrow = nb * FP_N;
     const int nrt = (nrow + 15) / 16, nrg = (nrt + RT - 1) / RT, npg = (npanels + PB - 1) / PB, rg8 = (nrg + 7) / 8;
     const int gemm_blocks = 8 * rg8 * npg;
