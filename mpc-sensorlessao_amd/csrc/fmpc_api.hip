@@ -140,6 +140,8 @@ struct fmpc_handle_s {
     std::vector<double> hm_R2, hm_rl, hm_umin, hm_umax, hm_umid, hm_xmid, hm_bt, hm_a1, hm_a2;   // host copies
     // tiled kernel (fmpc_kernel_tiled.hip): workgroup per problem, any n <= 79; images per arithmetic type, built on first use
     int generic_ok;                      // the generic kernel's LDS tiles fit (n <= 64), or generic_big
+    int prefer_tiled;                    // the fp64 tiled kernel exists for this size: it is 1.3 (n = 4) to 9 (n = 45) times faster than the
+                                         // generic kernel at every batch size (round 5 measurement): the default; FMPC_FORCE_GENERIC=1: generic
     int generic_big;                     // sizes no other kernel takes (n > 79 ...), diagonal weights: the generic kernel with its tiles in the workspace
     int prec;                            // FMPC_PREC_F64 / FMPC_PREC_F32_MIXED of the per-problem-factor path
     int force_tiled;                     // FMPC_TILED=1: route every solve through the tiled kernel (tests, profiles)
@@ -332,6 +334,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->rc_ws = nullptr; h->rc_ws_doubles = 0; h->rc_nu = nullptr; h->rc_si = nullptr; h->rc_cap = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
     h->generic_ok = generic_ok ? 1 : 0; h->generic_big = generic_big ? 1 : 0;
+    { const char* fg = getenv("FMPC_FORCE_GENERIC"); h->prefer_tiled = (tiled64 && !generic_big && !(fg && fg[0] == '1')) ? 1 : 0; }
     h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
@@ -1261,7 +1264,8 @@ static int fmpc_solve_device_inner(fmpc_handle h, int batch,
     const int zld = (!z_null && !fmpc_tl_contiguous_z && fmpc_effective_zld(h) > h->T * (h->n + h->m)) ? fmpc_effective_zld(h) : 0;
     if (zld && (w != nullptr || z_init != nullptr || max_iter != 1 || h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || h->denseQ ||
                 h->denseR || !h->use_wave || !h->sh_enabled || !h->pn_enabled)) return FMPC_E_UNSUPPORTED;
-    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || ((h->denseQ || h->denseR) && !h->generic_big) || (!h->use_wave && !h->generic_ok))
+    if (h->prec == FMPC_PREC_F32_MIXED || h->force_tiled || ((h->denseQ || h->denseR) && !h->generic_big) ||
+        (!h->use_wave && (!h->generic_ok || h->prefer_tiled)))
         return fmpc_solve_tiled(h, h->prec == FMPC_PREC_F32_MIXED ? 1 : 0, batch, x0, x0_pre, w, z_init, nu0, n_newton, k,
                                 z_out, nu_out, status, iters, step, u0_out, (hipStream_t)stream);
     if (h->use_wave) {

@@ -311,7 +311,7 @@ def test_solve_with_first_move_output(pkg, gpu, case):
     path, handed = h.last_dispatch()
     want = {"panel": pkg.FMPC_PATH_PANEL, "panel_budget3": pkg.FMPC_PATH_PANEL, "handed_over": pkg.FMPC_PATH_PANEL,
             "warm_start": pkg._lib.FMPC_PATH_TILED, "warm_start_wave": pkg.FMPC_PATH_WAVE, "no_shared": pkg.FMPC_PATH_WAVE,
-            "generic_n8": pkg.FMPC_PATH_GENERIC}[case]
+            "generic_n8": pkg._lib.FMPC_PATH_TILED}[case]          # (n = 8: the tiled kernel is the default wherever it exists, round 5)
     assert path == want and (handed > 0) == (case == "handed_over")
     assert torch.equal(z, z_ref) and torch.equal(st, st_ref) and torch.equal(it, it_ref)
     assert torch.equal(u0, z[:, :m])

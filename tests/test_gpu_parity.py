@@ -10,6 +10,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 
 
+@pytest.fixture(autouse=True, params=["default", "generic"])
+def kernel_choice(request, monkeypatch):
+    """Every case of this file runs twice: on the kernel the library picks (n = 27: wave / panel / affine forms; other n: the tiled
+    kernel where it exists, round 5) and with FMPC_FORCE_GENERIC=1 on the generic kernel (the LDS instance of fmpc_newton_generic)."""
+    if request.param == "generic":
+        monkeypatch.setenv("FMPC_FORCE_GENERIC", "1")
+    return request.param
+
+
 def _run(pkg, model, data, nw, k, z_init=None):
     h = handle_from_model(pkg, model)
     z, info = h.solve(data["x0"], data.get("x0_pre"), data.get("w"), z_init=z_init,
@@ -112,10 +121,12 @@ def test_unpack(pkg, gpu):
 
 
 @pytest.mark.parametrize("nw", [1, 4])
-def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw):
+def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw, kernel_choice):
     """From an explicit start every problem factors its own Schur complement: up to 1024 problems the tiled kernel (2 or 4
     wavefronts per problem), beyond that the one-wavefront kernel (8 problems per CU); FMPC_NO_SMALL_TILED=1 keeps the
     one-wavefront kernel.  All three against the oracle, and against each other to 1e-11."""
+    if kernel_choice == "generic":
+        pytest.skip("the dispatch among the n = 27 kernels")
     import os
     model = pkg.synthetic.make_model(27, 144, 10)
     model["u_min"] = -0.1 * np.ones(144); model["u_max"] = 0.1 * np.ones(144)
@@ -161,12 +172,14 @@ def test_per_problem_factor_dispatch_by_batch_size(pkg, gpu, nw):
 
 
 @pytest.mark.parametrize("want_nu", [True, False])
-def test_explicit_start_budget5_large_batch_first_step_then_compacted_continuation(pkg, gpu, want_nu):
+def test_explicit_start_budget5_large_batch_first_step_then_compacted_continuation(pkg, gpu, want_nu, kernel_choice):
     """Explicit start, more problems than the tiled kernel takes (> 1024), Newton budget 5 (test_fast_mpc.m:53,59): the
     one-wavefront kernel takes the first step of every problem and the next exit test (inf_newton_solver.m:19-22), the problems
     that go on are compacted into a list and finished by the tiled kernel.  Starts near the bounds for some problems: 2 to 5
     steps per problem, and first steps whose line search collapses.  Against the oracle problem by problem (z, nu, iteration
     counts, status, step lengths) and against the single launch (FMPC_NO_GENERAL_SPLIT=1)."""
+    if kernel_choice == "generic":
+        pytest.skip("the dispatch among the n = 27 kernels")
     import os
     import torch
     model = pkg.synthetic.make_model(27, 144, 8)
