@@ -581,22 +581,37 @@ def _main(real_out):
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "newton_iters_per_problem": it4b / B4,
             "note": "exit test of inf_newton_solver.m:19-22 (absolute 1e-6): an fp32 factor step leaves ||r|| ~ 1e-3 where the exact step "
                     "leaves 1e-9, so the fp32 path uses more of the budget than the fp64 oracle (DESIGN.md, tiled kernel)"}
-        # the same problems in fp64 through the size fallback (fmpc_newton_generic<true>, tiles in the HBM workspace): what "any size"
-        # costs, and the fp64 answer the fp32 step is measured against on the device
+        # the same problems in fp64 on request (fmpc_set_precision): the eight-wavefront fp64 instance of the same kernel
+        # (fmpc_newton_tiled<double,5,8>, round 5) -- the fp64 answer the fp32 step is measured against, on the matrix cores
         h4.set_precision("f64")
-        B4g = 256
-        r4g = Replay(h4, to_dev(d4["x0"][:B4g]), to_dev(d4["x0_pre"][:B4g]), to_dev(d4["nu0"][:B4g]), 1)
-        e_, s_, k_ = timed(r4g.step, 2, 1, min_ms=0.0)
-        r4g.check()
+        r4g = Replay(h4, to_dev(d4["x0"]), to_dev(d4["x0_pre"]), to_dev(d4["nu0"]), 1)
+        e_, s_, k_ = timed(r4g.step, 3, 1)
+        it4g = r4g.check()
+        p4g = h4.last_dispatch()[0]
         z64 = r4g.z.clone()
         h4.set_precision("f32")
         r4g.step(); torch.cuda.synchronize(dev)
-        extra["any_size_fallback_n65_fp64"] = {
-            "what": "configs[4]'s model, %d problems, fp64 on request (fmpc_set_precision): the generic kernel's workspace instance, the path of "
-                    "every n > 79 with diagonal weights; no speed claim" % B4g,
-            "value": B4g * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": pkg.FMPC_PATH_GENERIC,
+        extra["configs4_fp64_on_request"] = {
+            "what": "configs[4]'s model and batch with everything in fp64 (fmpc_set_precision(FMPC_PREC_F64): fmpc_newton_tiled<double,5,8>, one "
+                    "workgroup of 8 wavefronts per CU)",
+            "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": p4g, "dtype": "f64",
+            "roofline": {"bound": "mfma", "achieved": fl4 * it4g / (k_ * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl4 * it4g / (k_ * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "fp32_factor_step_vs_this": float((r4g.z - z64).norm() / z64.norm())}
         h4.close()
+        # ------------------------------------------------------------------ a size no matrix-core kernel takes (n > 79): the generic kernel's
+        # workspace instance -- correctness at any size, no speed claim
+        mb_ = pkg.synthetic.make_model(96, m, 30)
+        Bb = 128
+        db = pkg.synthetic.make_replay_batch(mb_, r=5, steps=Bb)
+        hb = make_handle(md=mb_)
+        rb_ = Replay(hb, to_dev(db["x0"]), to_dev(db["x0_pre"]), to_dev(db["nu0"]), 1)
+        e_, s_, k_ = timed(rb_.step, 2, 1, min_ms=0.0)
+        rb_.check()
+        extra["any_size_fallback_n96"] = {"what": "VAR(2), n = 96, m = %d, T = 30, %d problems, one Newton step: fmpc_newton_generic<true> (tiles in the HBM "
+                                                  "workspace), the path of every n > 79" % (m, Bb),
+                                          "value": Bb * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": hb.last_dispatch()[0]}
+        hb.close()
         # ------------------------------------------------------------------ tiled kernel at (27,144,30) in both arithmetic types
         for tag, prec in (("tiled_fp32_budget1", "f32"),):
             ht = make_handle(env={"FMPC_TILED": "1"}, prec=prec)

@@ -326,8 +326,9 @@ int fmpc_var_identify_device(int n, int num_train, int num_samples, int batch, c
  *                        cores; the residuals r_d, r_p (:12-17), the right-hand side (:28-29), d_z, the line search
  *                        and the iterate z, nu stay fp64, so every Newton step refines the fp32 KKT solve of the
  *                        previous one against fp64 residuals.  Default where no matrix-core fp64 kernel exists and this one
- *                        does (47 < n <= 79, and smaller n whose fp64 tiles do not fit); FMPC_PREC_F64 is accepted there too
- *                        with diagonal weights and selects the generic kernel with its tiles in the workspace (slow, exact).
+ *                        does (47 < n <= 79, and smaller n whose fp64 tiles do not fit); FMPC_PREC_F64 is accepted there too:
+ *                        the eight-wavefront fp64 instances of the same kernel (configs[4]'s problems: 12.6 ms per 1024 against
+ *                        5.8 ms with the fp32 factor), or -- a dense R, tiles beyond the LDS -- the generic kernel's workspace instance.
  * FMPC_E_UNSUPPORTED when the handle's size has no kernel of that type.
  */
 #define FMPC_PREC_F64        0

@@ -305,7 +305,11 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     size_t lds = fmpc_generic_lds_bytes(n, m);
     bool generic_ok = !denseQ && !denseR && n <= 64 && lds <= FMPC_LDS_LIMIT;
     const int nb_ = T + (xf ? 1 : 0);
-    const bool tiled64 = fmpc_tiled_supports(n, m, nb_, 0, nullptr, nullptr, denseR), tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr, denseR);
+    // (fp64 tiled instances of 4 and 5 blocks of 16 exist too -- 47 < n <= 79, round 5 -- but only on request, fmpc_set_precision:
+    //  the default arithmetic at those sizes stays the fp32 factor of BASELINE configs[4])
+    int NB64 = 0;
+    const bool tiled64_any = fmpc_tiled_supports(n, m, nb_, 0, &NB64, nullptr, denseR);
+    const bool tiled64 = tiled64_any && NB64 <= 3, tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr, denseR);
     // Any other size with diagonal weights (the reference checks shapes only, fast_mpc_objective.m:17-47): the generic kernel
     // with its tiles in the HBM workspace ("big": a size fallback, fp64, no speed claim).  FMPC_GENERIC_BIG=1 forces it (tests).
     bool generic_big = false;
@@ -334,7 +338,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->rc_ws = nullptr; h->rc_ws_doubles = 0; h->rc_nu = nullptr; h->rc_si = nullptr; h->rc_cap = 0;
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
     h->generic_ok = generic_ok ? 1 : 0; h->generic_big = generic_big ? 1 : 0;
-    { const char* fg = getenv("FMPC_FORCE_GENERIC"); h->prefer_tiled = (tiled64 && !generic_big && !(fg && fg[0] == '1')) ? 1 : 0; }
+    { const char* fg = getenv("FMPC_FORCE_GENERIC"); h->prefer_tiled = (tiled64_any && !generic_big && !(fg && fg[0] == '1')) ? 1 : 0; }
     h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
@@ -899,9 +903,9 @@ extern "C" int fmpc_set_precision(fmpc_handle h, int mode) {
     if (mode != FMPC_PREC_F64 && mode != FMPC_PREC_F32_MIXED) return FMPC_E_DIM;
     if (mode == FMPC_PREC_F32_MIXED && !fmpc_tiled_supports(h->n, h->m, h->nb, 1, nullptr, nullptr, h->denseR)) return FMPC_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr)) {
-        // sizes whose default is the fp32 factor (47 < n <= 79, diagonal weights): fp64 on request through the generic kernel
-        // with its tiles in the workspace (slow; the fp64 answer on the device for a configs[4]-sized problem)
+    if (mode == FMPC_PREC_F64 && !h->generic_ok && !fmpc_tiled_supports(h->n, h->m, h->nb, 0, nullptr, nullptr, h->denseR)) {
+        // no fp64 tiled instance (a dense R beyond n = 47, B too large for the fp64 tiles): fp64 on request through the generic
+        // kernel with its tiles in the workspace (slow, exact)
         const size_t lds = fmpc_generic_big_lds_bytes(h->n, h->m);
         if (lds > FMPC_LDS_LIMIT) return FMPC_E_UNSUPPORTED;
         if (fmpc_generic_prepare(lds, 1) != hipSuccess) return FMPC_E_HIP;

@@ -1299,6 +1299,9 @@ static hipError_t ft_prepare(size_t lds) {
         if (NB == 1 && NW == 4) return fn<double, 1, 4>(__VA_ARGS__);                          \
         if (NB == 2 && NW == 4) return fn<double, 2, 4>(__VA_ARGS__);                          \
         if (NB == 3 && NW == 4) return fn<double, 3, 4>(__VA_ARGS__);                          \
+        /* fp64 on request where the fp32 factor is the default (47 < n <= 79, fmpc_set_precision): one workgroup of 8 per CU */ \
+        if (NB == 4 && NW == 8) return fn<double, 4, 8>(__VA_ARGS__);                          \
+        if (NB == 5 && NW == 8) return fn<double, 5, 8>(__VA_ARGS__);                          \
     } else {                                                                                   \
         if (NB == 1 && NW == 2) return fn<float, 1, 2>(__VA_ARGS__);                           \
         if (NB == 2 && NW == 2) return fn<float, 2, 2>(__VA_ARGS__);                           \
@@ -1317,12 +1320,12 @@ static int ft_default_nw(int NB, int is_float) {
     // (n = 65, NB = 5: since the factor phase keeps two U slots instead of three its LDS is 70 KB, so TWO workgroups of 4
     // wavefronts share a CU -- one problem's pivot chains and barriers overlap the other's products: 7.98 ms per Newton step
     // of BASELINE configs[4] against 9.11 ms with one workgroup of 8)
-    int NW = is_float ? (NB == 5 ? 4 : (NB >= 4 ? 8 : (NB >= 2 ? 4 : 2))) : (NB >= 3 ? 4 : 2);
+    int NW = is_float ? (NB == 5 ? 4 : (NB >= 4 ? 8 : (NB >= 2 ? 4 : 2))) : (NB >= 4 ? 8 : (NB >= 3 ? 4 : 2));
     const char* e = getenv("FMPC_TILED_NW");                      // experiments
     if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8')) {
         const int w = e[0] - '0';
         const bool ok = is_float ? ((NB <= 2 && w == 2) || (NB >= 2 && NB <= 5 && w == 4) || (NB >= 4 && w == 8))
-                                 : (w == 2 || w == 4);
+                                 : (NB <= 3 && (w == 2 || w == 4));
         if (ok) NW = w;
     }
     return NW;
@@ -1330,8 +1333,8 @@ static int ft_default_nw(int NB, int is_float) {
 
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR) {
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
-    if (NB > (is_float ? 5 : 3)) return false;
-    if (denseR && is_float) return false;
+    if (NB > 5) return false;
+    if (denseR && (is_float || NB > 3)) return false;
     const int NW = denseR ? 8 : ft_default_nw(NB, is_float);
     const int mb = (m + 15) / 16;
     if (ft_lds_layout(NB, mb, NW, is_float ? 4 : 8, nb, denseR ? ft_pr_doubles(n, m) : 0).total > 160 * 1024) return false;

@@ -52,6 +52,7 @@ def test_sizes_beyond_the_specialised_kernels(pkg, gpu, n, m, T, var_order, xf):
     dual start included.  n = 70 (default there: the fp32 factor) takes the same path when fp64 is asked for."""
     model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + m, xf=xf, var_order=var_order, batch=3)
     for nw in (1, 4):
+        # (n = 70: fp64 on request takes the eight-wavefront fp64 instance of the tiled kernel where its tiles fit the LDS -- m = 300 does not)
         _compare(pkg, model, data, nw, 0.01, expect_path=pkg.FMPC_PATH_GENERIC, prec="f64" if n <= 79 else None)
 
 
@@ -71,14 +72,15 @@ def test_first_moves_and_device_entry_at_a_big_size(pkg, gpu):
 
 def test_dense_state_weights_at_any_size(pkg, gpu, monkeypatch):
     """Dense symmetric positive definite Q, Qf (fast_mpc_objective.m:52-55) beyond the tiled kernel's sizes: the workspace
-    instance applies 2Q, 2Qf and their inverses as matrices.  Also forced on a small model, and fp64 on request at n = 60."""
+    instance applies 2Q, 2Qf and their inverses as matrices.  Also forced on a small model; fp64 on request at n = 60 (tiled instance and, forced, the workspace instance)."""
     from tests.test_property_random import random_problem
     for (seed, n, m, T, var, xf, lin) in ((11, 90, 30, 4, 2, False, True), (12, 84, 100, 3, 1, True, False)):
         model, data = random_problem(seed, n, m, T, var, True, False, xf, lin, batch=3)
         _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC)
     model, data = random_problem(13, 60, 20, 4, 2, True, False, False, True, batch=2)
-    _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC, prec="f64")
+    _compare(pkg, model, data, 3, 0.1, expect_path=pkg._lib.FMPC_PATH_TILED, prec="f64")        # (n = 60: the fp64 tiled instance of 4 blocks)
     monkeypatch.setenv("FMPC_GENERIC_BIG", "1")
+    _compare(pkg, model, data, 3, 0.1, expect_path=pkg.FMPC_PATH_GENERIC)                        # (the same in the workspace instance)
     model, data = random_problem(14, 9, 6, 5, 2, True, False, True, True, batch=4)
     _compare(pkg, model, data, 4, 0.01, expect_path=pkg.FMPC_PATH_GENERIC)
 
@@ -124,3 +126,16 @@ def test_closed_loop_step_at_a_big_size(pkg, gpu):
     z_ref = h.solve(a + bu1, xl, w_ref, n_newton=3, k=0.01)
     assert rel_err(z.cpu().numpy(), z_ref) <= 1e-10 and np.array_equal(u0.cpu().numpy(), z.cpu().numpy()[:, :m])
     h.close()
+
+
+@pytest.mark.parametrize("n,m,T,var_order,xf,dq", [(50, 30, 4, 2, False, False), (65, 144, 6, 2, False, False), (79, 40, 3, 1, False, True),
+                                                   (64, 80, 3, 2, True, False), (50, 20, 5, 2, False, False)])
+def test_fp64_tiled_instances_of_four_and_five_blocks(pkg, gpu, n, m, T, var_order, xf, dq):
+    """47 < n <= 79: fp64 on request (fmpc_set_precision; the default there is the fp32 factor) runs on the matrix cores too --
+    fmpc_newton_tiled<double, 4 | 5, 8> -- to the fp64 parity bar; n = 50 with m = 20 (the generic kernel's LDS tiles fit: fp64 is
+    the default) takes it without asking."""
+    from tests.test_property_random import random_problem, random_interior_start
+    model, data = random_problem(300 + n, n, m, T, var_order, dq, False, xf, True, batch=4)
+    zi = random_interior_start(n, model, 4)
+    _compare(pkg, model, data, 1, 0.1, expect_path=pkg._lib.FMPC_PATH_TILED, prec=None if (n, m) == (50, 20) else "f64")
+    _compare(pkg, model, data, 4, 1.0, z_init=zi, expect_path=pkg._lib.FMPC_PATH_TILED, prec=None if (n, m) == (50, 20) else "f64")

@@ -192,7 +192,7 @@ def test_tiled_fp32_dense_state_weights(pkg, gpu, n, m, T, var, xf):
     if n > 47:
         h.set_precision("f64")
         z64 = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=3, k=1e-1, check=False)
-        assert h.last_dispatch()[0] == pkg.FMPC_PATH_GENERIC
+        assert h.last_dispatch()[0] == pkg._lib.FMPC_PATH_TILED          # (the fp64 instance of 4 / 5 blocks, round 5)
         assert rel_err(z32, z64) <= TOL32
     h.close()
     print(f"fp32 factor, dense Q, n={n}: max rel err on z {err:.2e}")
