@@ -611,6 +611,13 @@ def _main(real_out):
         extra["any_size_fallback_n96"] = {"what": "VAR(2), n = 96, m = %d, T = 30, %d problems, one Newton step: fmpc_newton_generic<true> (tiles in the HBM "
                                                   "workspace), the path of every n > 79" % (m, Bb),
                                           "value": Bb * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": hb.last_dispatch()[0]}
+        zb64 = rb_.z.clone()
+        hb.set_precision("f32")                        # 79 < n <= 111: the fp32 factor on request (fmpc_newton_tiled<float,6,8>)
+        e_, s_, k_ = timed(rb_.step, 3, 1)
+        rb_.check()
+        extra["any_size_fallback_n96"]["fp32_factor_on_request"] = {
+            "value": Bb * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": hb.last_dispatch()[0],
+            "step_vs_fp64": float((rb_.z - zb64).norm() / zb64.norm())}
         hb.close()
         # ------------------------------------------------------------------ tiled kernel at (27,144,30) in both arithmetic types
         for tag, prec in (("tiled_fp32_budget1", "f32"),):

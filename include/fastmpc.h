@@ -67,8 +67,9 @@ const char* fmpc_strerror(int code);
  * fast_mpc_ineq_const.m:46-56).
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
- *   n          any.  Specialised kernels: n = 27 (the AO configuration), n <= 47 in fp64 and n <= 79 with the fp32 factor + fp64
- *              residuals (fmpc_set_precision) on the matrix cores; every other size (the reference checks shapes only,
+ *   n          any.  Specialised kernels: n = 27 (the AO configuration), n <= 79 in fp64 and n <= 111 with the fp32 factor + fp64
+ *              residuals on the matrix cores (defaults: fp64 up to n = 47, the fp32 factor for 47 < n <= 79, fmpc_set_precision for
+ *              the other arithmetic and for the fp32 factor at 79 < n <= 111); every other size (the reference checks shapes only,
  *              fast_mpc_objective.m:17-47) is solved in fp64 by the generic kernel with its tiles in the HBM workspace -- a size
  *              fallback without a speed claim (tests/test_gpu_any_size.py: n = 83 .. 140).
  *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices, at any size.  Dense Q

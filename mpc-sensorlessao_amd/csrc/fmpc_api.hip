@@ -309,7 +309,10 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     //  the default arithmetic at those sizes stays the fp32 factor of BASELINE configs[4])
     int NB64 = 0;
     const bool tiled64_any = fmpc_tiled_supports(n, m, nb_, 0, &NB64, nullptr, denseR);
-    const bool tiled64 = tiled64_any && NB64 <= 3, tiled32 = fmpc_tiled_supports(n, m, nb_, 1, nullptr, nullptr, denseR);
+    // (likewise the fp32-factor instances of 6 and 7 blocks, 79 < n <= 111: on request; the default beyond n = 79 is the exact fp64 fallback)
+    int NB32 = 0;
+    const bool tiled32_any = fmpc_tiled_supports(n, m, nb_, 1, &NB32, nullptr, denseR);
+    const bool tiled64 = tiled64_any && NB64 <= 3, tiled32 = tiled32_any && NB32 <= 5;
     // Any other size with diagonal weights (the reference checks shapes only, fast_mpc_objective.m:17-47): the generic kernel
     // with its tiles in the HBM workspace ("big": a size fallback, fp64, no speed claim).  FMPC_GENERIC_BIG=1 forces it (tests).
     bool generic_big = false;

@@ -1274,7 +1274,7 @@ static hipError_t ft_prepare(size_t lds) {
     return hipFuncSetAttribute((const void*)fmpc_newton_tiled<R, NB, NW, NL, DR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-// instantiations: fp64 for n <= 47 (NB <= 3), fp32 for n <= 79 (NB <= 5); NW wavefronts per problem
+// instantiations: fp64 for n <= 79 (NB <= 5; 4 and 5 on request), fp32 for n <= 111 (NB <= 7; 6 and 7 on request); NW wavefronts per problem
 #define FT_DISPATCH(fn, ...)                                                                   \
     /* dense R: fp64, eight wavefronts (the per-stage m x m factorisation is workgroup-wide vector work) */                  \
     if (denseR) {                                                                              \
@@ -1311,6 +1311,9 @@ static hipError_t ft_prepare(size_t lds) {
         if (NB == 4 && NW == 8) return fn<float, 4, 8>(__VA_ARGS__);                           \
         if (NB == 5 && NW == 4) return fn<float, 5, 4>(__VA_ARGS__);                           \
         if (NB == 5 && NW == 8) return fn<float, 5, 8>(__VA_ARGS__);                           \
+        /* 79 < n <= 111 with the fp32 factor, on request (round 5): one workgroup of 8 per CU */ \
+        if (NB == 6 && NW == 8) return fn<float, 6, 8>(__VA_ARGS__);                           \
+        if (NB == 7 && NW == 8) return fn<float, 7, 8>(__VA_ARGS__);                           \
     }                                                                                          \
     return hipErrorInvalidValue;
 
@@ -1324,7 +1327,7 @@ static int ft_default_nw(int NB, int is_float) {
     const char* e = getenv("FMPC_TILED_NW");                      // experiments
     if (e && (e[0] == '2' || e[0] == '4' || e[0] == '8')) {
         const int w = e[0] - '0';
-        const bool ok = is_float ? ((NB <= 2 && w == 2) || (NB >= 2 && NB <= 5 && w == 4) || (NB >= 4 && w == 8))
+        const bool ok = is_float ? ((NB <= 2 && w == 2) || (NB >= 2 && NB <= 5 && w == 4) || (NB >= 4 && w == 8))        /* (NB = 6, 7: 8 only) */
                                  : (NB <= 3 && (w == 2 || w == 4));
         if (ok) NW = w;
     }
@@ -1333,7 +1336,7 @@ static int ft_default_nw(int NB, int is_float) {
 
 bool fmpc_tiled_supports(int n, int m, int nb, int is_float, int* NB_out, int* NW_out, int denseR) {
     const int NB = n / 16 + 1;                                     // 16 NB >= n + 1
-    if (NB > 5) return false;
+    if (NB > (is_float ? 7 : 5)) return false;
     if (denseR && (is_float || NB > 3)) return false;
     const int NW = denseR ? 8 : ft_default_nw(NB, is_float);
     const int mb = (m + 15) / 16;

@@ -383,3 +383,21 @@ def test_many_seed_stress_of_the_production_instances(pkg, gpu, monkeypatch):
     for h in hs.values():
         h.close()
     print("worst relative difference between the three kernels over 24 seeds x 96 problems: %.2e" % worst)
+
+
+@pytest.mark.parametrize("n,m,T,var,xf,dq", [(83, 40, 4, 2, False, False), (96, 144, 6, 2, False, False), (111, 30, 3, 1, False, True), (100, 120, 3, 2, True, False)])
+def test_tiled_fp32_instances_of_six_and_seven_blocks(pkg, gpu, n, m, T, var, xf, dq):
+    """79 < n <= 111: the fp32 factor on request (fmpc_set_precision; the default there is the exact fp64 fallback,
+    tests/test_gpu_any_size.py) -- fmpc_newton_tiled<float, 6 | 7, 8> -- against the oracle at the fp32 tolerance after three Newton
+    steps, and against the fp64 answer of the same library."""
+    from tests.test_property_random import random_problem
+    model, data = random_problem(400 + n, n, m, T, var, dq, False, xf, True, batch=3)
+    err = _compare32(pkg, model, data, 3, 1e-1)
+    h = handle_from_model(pkg, model)
+    z64 = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=3, k=1e-1, check=False)
+    assert h.last_dispatch()[0] == pkg.FMPC_PATH_GENERIC
+    h.set_precision("f32")
+    z32 = h.solve(data["x0"], data["x0_pre"], data["w"], nu0=data["nu0"], n_newton=3, k=1e-1, check=False)
+    assert h.last_dispatch()[0] == pkg._lib.FMPC_PATH_TILED_F32 and rel_err(z32, z64) <= TOL32
+    h.close()
+    print(f"fp32 factor, n={n}: max rel err on z {err:.2e}")
