@@ -558,7 +558,7 @@ def _main(real_out):
         n4, T4, B4 = 65, 60, 1024
         m4 = pkg.synthetic.make_model(n4, m, T4)
         d4 = pkg.synthetic.make_replay_batch(m4, r=4, steps=B4)
-        h4 = make_handle(md=m4)
+        h4 = make_handle(md=m4, prec="f32")                      # (the fp32 factor of BASELINE configs[4]; the default at n = 65 is fp64)
         r4 = Replay(h4, to_dev(d4["x0"]), to_dev(d4["x0_pre"]), to_dev(d4["nu0"]), 1)
         e_, s_, k_ = timed(r4.step, 5, 2)
         it4 = r4.check()
@@ -581,7 +581,7 @@ def _main(real_out):
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "newton_iters_per_problem": it4b / B4,
             "note": "exit test of inf_newton_solver.m:19-22 (absolute 1e-6): an fp32 factor step leaves ||r|| ~ 1e-3 where the exact step "
                     "leaves 1e-9, so the fp32 path uses more of the budget than the fp64 oracle (DESIGN.md, tiled kernel)"}
-        # the same problems in fp64 on request (fmpc_set_precision): the eight-wavefront fp64 instance of the same kernel
+        # the same problems in fp64 (the default arithmetic; set back with fmpc_set_precision): the eight-wavefront fp64 instance of the same kernel
         # (fmpc_newton_tiled<double,5,8>, round 5) -- the fp64 answer the fp32 step is measured against, on the matrix cores
         h4.set_precision("f64")
         r4g = Replay(h4, to_dev(d4["x0"]), to_dev(d4["x0_pre"]), to_dev(d4["nu0"]), 1)
@@ -592,7 +592,7 @@ def _main(real_out):
         h4.set_precision("f32")
         r4g.step(); torch.cuda.synchronize(dev)
         extra["configs4_fp64_on_request"] = {
-            "what": "configs[4]'s model and batch with everything in fp64 (fmpc_set_precision(FMPC_PREC_F64): fmpc_newton_tiled<double,5,8>, one "
+            "what": "configs[4]'s model and batch with everything in fp64 (the library's default arithmetic: fmpc_newton_tiled<double,5,8>, one "
                     "workgroup of 8 wavefronts per CU)",
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": p4g, "dtype": "f64",
             "roofline": {"bound": "mfma", "achieved": fl4 * it4g / (k_ * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

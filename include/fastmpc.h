@@ -68,8 +68,7 @@ const char* fmpc_strerror(int code);
  *   var_order  2: VAR(2) (Fast_MPC/VAR_2).  1: VAR(1) intended dynamics = VAR_2 code with
  *              A2 = 0 (A2 may be NULL); ramp-rate rows of VAR_1 are not built.
  *   n          any.  Specialised kernels: n = 27 (the AO configuration), n <= 79 in fp64 and n <= 111 with the fp32 factor + fp64
- *              residuals on the matrix cores (defaults: fp64 up to n = 47, the fp32 factor for 47 < n <= 79, fmpc_set_precision for
- *              the other arithmetic and for the fp32 factor at 79 < n <= 111); every other size (the reference checks shapes only,
+ *              residuals on the matrix cores (default: fp64; fmpc_set_precision for the fp32 factor); every other size (the reference checks shapes only,
  *              fast_mpc_objective.m:17-47) is solved in fp64 by the generic kernel with its tiles in the HBM workspace -- a size
  *              fallback without a speed claim (tests/test_gpu_any_size.py: n = 83 .. 140).
  *   Q,R,Qf     n x n, m x m, n x n (fast_mpc_objective.m:51-55): any symmetric positive definite matrices, at any size.  Dense Q
@@ -321,15 +320,17 @@ int fmpc_var_identify_device(int n, int num_train, int num_samples, int batch, c
 
 /*
  * Arithmetic of the per-problem-factor path (no counterpart in the reference, which is fp64 throughout).
- *   FMPC_PREC_F64        everything in fp64 (default wherever an fp64 kernel exists: n <= 64)
+ *   FMPC_PREC_F64        everything in fp64: the default wherever an fp64 kernel on the matrix cores exists (n <= 79; round 5 --
+ *                        the reference is fp64 throughout and the literal call fmpc_solve_once has no precision argument) and
+ *                        beyond (the generic kernel's workspace instance: exact, slow).
  *   FMPC_PREC_F32_MIXED  "fp32 mixed precision" (BASELINE configs[4]): Y = C Phi^-1 C', its block Cholesky factor
  *                        (inf_newton_solver.m:27,30) and the two triangular sweeps (:31-32) in fp32 on the matrix
  *                        cores; the residuals r_d, r_p (:12-17), the right-hand side (:28-29), d_z, the line search
  *                        and the iterate z, nu stay fp64, so every Newton step refines the fp32 KKT solve of the
- *                        previous one against fp64 residuals.  Default where no matrix-core fp64 kernel exists and this one
- *                        does (47 < n <= 79, and smaller n whose fp64 tiles do not fit); FMPC_PREC_F64 is accepted there too:
- *                        the eight-wavefront fp64 instances of the same kernel (configs[4]'s problems: 12.6 ms per 1024 against
- *                        5.8 ms with the fp32 factor), or -- a dense R, tiles beyond the LDS -- the generic kernel's workspace instance.
+ *                        previous one against fp64 residuals.  On request, n <= 111 with a diagonal R: 2.2 x faster than fp64
+ *                        at configs[4] (n = 65), 35 x faster than the exact fallback at n = 96; a step differs from the
+ *                        fp64 one by ~1e-6.  The default only where it is the only matrix-core kernel that fits (fp64 tiles
+ *                        beyond the LDS: very large m).
  * FMPC_E_UNSUPPORTED when the handle's size has no kernel of that type.
  */
 #define FMPC_PREC_F64        0

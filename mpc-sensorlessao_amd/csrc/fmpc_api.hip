@@ -305,8 +305,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     size_t lds = fmpc_generic_lds_bytes(n, m);
     bool generic_ok = !denseQ && !denseR && n <= 64 && lds <= FMPC_LDS_LIMIT;
     const int nb_ = T + (xf ? 1 : 0);
-    // (fp64 tiled instances of 4 and 5 blocks of 16 exist too -- 47 < n <= 79, round 5 -- but only on request, fmpc_set_precision:
-    //  the default arithmetic at those sizes stays the fp32 factor of BASELINE configs[4])
+    // (fp64 tiled instances of 4 and 5 blocks of 16, 47 < n <= 79: round 5)
     int NB64 = 0;
     const bool tiled64_any = fmpc_tiled_supports(n, m, nb_, 0, &NB64, nullptr, denseR);
     // (likewise the fp32-factor instances of 6 and 7 blocks, 79 < n <= 111: on request; the default beyond n = 79 is the exact fp64 fallback)
@@ -342,7 +341,9 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     h->ev = nullptr; h->ev_valid = 0; h->last_stream = nullptr;
     h->generic_ok = generic_ok ? 1 : 0; h->generic_big = generic_big ? 1 : 0;
     { const char* fg = getenv("FMPC_FORCE_GENERIC"); h->prefer_tiled = (tiled64_any && !generic_big && !(fg && fg[0] == '1')) ? 1 : 0; }
-    h->prec = (generic_ok || tiled64) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
+    // fp64 wherever an fp64 kernel on the matrix cores (or the generic kernel) exists -- the reference is fp64 throughout and the literal
+    // drop-in call (fmpc_solve_once) has no precision argument; the fp32 factor (BASELINE configs[4]) is a request since round 5
+    h->prec = (generic_ok || tiled64_any) ? FMPC_PREC_F64 : FMPC_PREC_F32_MIXED;
     { const char* ft = getenv("FMPC_TILED"); h->force_tiled = (ft && ft[0] == '1') ? 1 : 0; }
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
     { const char* ns = getenv("FMPC_NO_SMALL_TILED"); h->small_tiled = (ns && ns[0] == '1') ? 0 : 1; }

@@ -349,6 +349,8 @@ def test_first_moves_only_output(pkg, gpu, case):
     finally:
         for v in ("FMPC_NO_SHARED", "FMPC_NO_SMALL_TILED", "FMPC_NO_INV"):
             os.environ.pop(v, None)
+    if case == "tiled_f32_n65":
+        h.set_precision("f32")
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     x0, x0p, w, nu0 = t(data["x0"]), t(data["x0_pre"]), t(data.get("w")), t(data["nu0"])
     nw = 3 if case == "panel_budget3" else 2 if case == "tiled_f32_n65" else 1

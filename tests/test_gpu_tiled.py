@@ -147,10 +147,11 @@ def test_tiled_fp32_config4_n65_T60(pkg, gpu, nw, waves, monkeypatch):
     model = pkg.synthetic.make_model(65, 144, 60)
     data = pkg.synthetic.make_replay_batch(model, r=4, steps=6)
     h = handle_from_model(pkg, model)
+    h.set_precision("f32")                                # (the default at n = 65 is fp64 since round 5: the fp32 factor is a request)
     z, info = h.solve(data["x0"], data["x0_pre"], None, nu0=data["nu0"], n_newton=nw, k=1e-2, return_info=True)
     path, _ = h.last_dispatch()
     h.close()
-    assert path == pkg._lib.FMPC_PATH_TILED_F32          # the only path at n = 65: default precision there
+    assert path == pkg._lib.FMPC_PATH_TILED_F32
     zo, nuo, ito, sto, _ = oracle_batch(model, data, nw, 1e-2)
     assert np.array_equal(info["status"], sto) and np.all(info["iters"] >= ito), (info["iters"], ito)
     errs = [rel_err(z[p], zo[p]) for p in range(6)]
