@@ -591,7 +591,7 @@ def _main(real_out):
         z64 = r4g.z.clone()
         h4.set_precision("f32")
         r4g.step(); torch.cuda.synchronize(dev)
-        extra["configs4_fp64_on_request"] = {
+        extra["configs4_fp64"] = {
             "what": "configs[4]'s model and batch with everything in fp64 (the library's default arithmetic: fmpc_newton_tiled<double,5,8>, one "
                     "workgroup of 8 wavefronts per CU)",
             "value": B4 * s_ / e_, "unit": "MPC steps/s", "kernel_ms": k_, "path": p4g, "dtype": "f64",
