@@ -49,7 +49,8 @@ def test_big_instance_on_the_reference_demo_config(pkg, gpu, monkeypatch, xf, va
 @pytest.mark.parametrize("n,m,T,var_order,xf", [(100, 40, 5, 2, True), (130, 150, 4, 1, False), (83, 7, 3, 2, False), (70, 300, 2, 2, False)])
 def test_sizes_beyond_the_specialised_kernels(pkg, gpu, n, m, T, var_order, xf):
     """n > 79 (the tiled kernel's limit) with diagonal weights: solved, by the generic path, to the parity bar; w and an explicit
-    dual start included.  n = 70 (default there: the fp32 factor) takes the same path when fp64 is asked for."""
+    dual start included.  n = 70 with m = 300 (the fp64 tiles of the matrix-core kernel do not fit the LDS: the fp32 factor is the default
+    there) takes the same path when fp64 is asked for."""
     model, data = pkg.synthetic.make_test_problem(n, m, T, seed=n + m, xf=xf, var_order=var_order, batch=3)
     for nw in (1, 4):
         # (n = 70: fp64 on request takes the eight-wavefront fp64 instance of the tiled kernel where its tiles fit the LDS -- m = 300 does not)
@@ -131,7 +132,7 @@ def test_closed_loop_step_at_a_big_size(pkg, gpu):
 @pytest.mark.parametrize("n,m,T,var_order,xf,dq", [(50, 30, 4, 2, False, False), (65, 144, 6, 2, False, False), (79, 40, 3, 1, False, True),
                                                    (64, 80, 3, 2, True, False), (50, 20, 5, 2, False, False)])
 def test_fp64_tiled_instances_of_four_and_five_blocks(pkg, gpu, n, m, T, var_order, xf, dq):
-    """47 < n <= 79: fp64 on request (fmpc_set_precision; the default there is the fp32 factor) runs on the matrix cores too --
+    """47 < n <= 79: fp64 (the default since round 5; also asked for explicitly here) runs on the matrix cores too --
     fmpc_newton_tiled<double, 4 | 5, 8> -- to the fp64 parity bar; n = 50 with m = 20 (the generic kernel's LDS tiles fit: fp64 is
     the default) takes it without asking."""
     from tests.test_property_random import random_problem, random_interior_start
