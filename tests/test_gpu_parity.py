@@ -226,3 +226,16 @@ def test_explicit_start_budget5_large_batch_first_step_then_compacted_continuati
             assert np.array_equal(canon(stp[p]), canon(ts)), (tag, p, stp[p], ts)
         assert np.array_equal(u0, z[:, :144])
     assert max(rel_err(outs["split"][0][p], outs["one_launch"][0][p]) for p in range(B)) <= 1e-11
+
+
+def test_small_sizes_beyond_512_problems(pkg, gpu, kernel_choice):
+    """n <= 31 (other than 27): up to 512 problems take four wavefronts each on the tiled kernel, more take two -- both sides of that
+    switch in one handle (520 and 40 problems of the reference demo's configuration)."""
+    model, data = pkg.synthetic.make_test_problem(8, 5, 10, seed=21, batch=520)
+    h = handle_from_model(pkg, model)
+    zo, nuo, ito, sto, steps = oracle_batch(model, data, 3, 0.01)
+    for sl in (slice(0, 520), slice(100, 140)):
+        z, info = h.solve(data["x0"][sl], data["x0_pre"][sl], data["w"][sl], nu0=data["nu0"][sl], n_newton=3, k=0.01, return_info=True, check=False)
+        assert np.array_equal(info["status"], sto[sl]) and np.array_equal(info["iters"], ito[sl])
+        assert max(rel_err(z[p], zo[sl][p]) for p in range(z.shape[0])) <= TOL
+    h.close()
