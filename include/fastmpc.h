@@ -404,12 +404,13 @@ unsigned long long fmpc_alloc_generation(void);
 int fmpc_set_z_ld(fmpc_handle h, int ldz);
 
 /* n = 27: explicit-start batches of at most 1024 problems and the continuation of a Newton budget > 1 (a few hundred problems)
- * run on the tiled kernel with TWO wavefronts per problem (tiled = 1, default: lowest latency of ONE call) or on the
- * one-wavefront kernel (tiled = 0: its single wavefronts share the chip better when many handles have solves in flight at the
- * same time; bench.py `budget5_in_flight_12`).  tiled = 4 opts in to FOUR wavefronts per problem for batches of at most 512
- * and for continuations (about 10 % lower latency of one call; not the default since round 4: a sibling instance of the
- * four-wavefront fp64 kernel was miscompiled by an earlier build and the cause was never established -- DESIGN.md).
- * Environment at create time: FMPC_NO_SMALL_TILED=1 = tiled 0, FMPC_SMALL_TILED_NW=4 = tiled 4. */
+ * run on the tiled kernel (tiled = 1, default: lowest latency of ONE call) or on the one-wavefront kernel (tiled = 0: its single
+ * wavefronts share the chip better when many handles have solves in flight at the same time; bench.py `budget5_in_flight_12`).
+ * On the tiled kernel batches of at most 512 problems and continuations take FOUR wavefronts per problem (19 % lower latency than
+ * two; tiled = 1 or 4), larger ones two; tiled = 2 selects two throughout.  (Round 4 had made two the default after a compile-time
+ * sibling instance <double,2,4,11> was miscompiled by round 2's build; that instance is gone since round 5, the run-time
+ * four-wavefront form is what every n <= 31 takes up to 512 problems, under the 24-seed stress test and a 192-case sweep.)
+ * Environment at create time: FMPC_NO_SMALL_TILED=1 = tiled 0, FMPC_SMALL_TILED_NW=2 = tiled 2. */
 int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled);
 int fmpc_last_dual_form(fmpc_handle h);
 

@@ -150,7 +150,7 @@ struct fmpc_handle_s {
     int tl_last_nw;                       // wavefronts per problem of the last tiled launch (diagnostic)
     int z_ld;                             // fmpc_set_z_ld: doubles between the z rows of consecutive problems (0: T (n + m))
     int small_tiled;                      // per-problem-factor solves of few problems go to the tiled kernel (FMPC_NO_SMALL_TILED=1: off)
-    int small_nw;                         // ... with this many wavefronts per problem: 2 (default) or 4 (FMPC_SMALL_TILED_NW=4 /
+    int small_nw;                         // ... with this many wavefronts per problem: 4 (default since round 5) or 2 (FMPC_SMALL_TILED_NW=2 /
                                           // fmpc_set_small_batch_kernel(h, 4): opt-in, see the note at FT_DISPATCH in fmpc_kernel_tiled.hip)
     std::vector<double> hm_b;            // B row-major n x m
     std::vector<double> hm_a1f, hm_a2f;  // A1, A2 row-major (always kept: the tiled kernel's images)
@@ -348,7 +348,7 @@ extern "C" int fmpc_create(fmpc_handle* out, int n, int m, int T, int var_order,
     memset(h->tl, 0, sizeof(h->tl)); h->tl_ws = nullptr; h->tl_ws_doubles = 0; h->tl_prepared = 0;
     { const char* ns = getenv("FMPC_NO_SMALL_TILED"); h->small_tiled = (ns && ns[0] == '1') ? 0 : 1; }
     h->z_ld = 0;
-    { const char* nw = getenv("FMPC_SMALL_TILED_NW"); h->small_nw = (nw && nw[0] == '4') ? 4 : 2; }
+    { const char* nw = getenv("FMPC_SMALL_TILED_NW"); h->small_nw = (nw && nw[0] == '2') ? 2 : 4; }      // (four: the default again, round 5)
     h->use_wave = 0; h->wave_pool_d = nullptr; h->wave_pool_i = nullptr; h->wave_lds = 0;
     h->sh_fac = nullptr; h->sh_rs = nullptr; h->sh_ok = nullptr; h->sh_scratch = nullptr; h->sh_k = 0.0; h->sh_valid = 0; h->sh_enabled = 0; h->cold_d = nullptr;
     h->last_path = 0; h->pn_sched = nullptr; h->pn_nsf = 0; h->pn_nsb = 0; h->pn_limg_cap = 0; h->pn_enabled = 0; h->pn_valid = 0; h->pn_mp = 0; h->pn_lds = 0; h->pn_pool = nullptr;
@@ -1941,7 +1941,7 @@ extern "C" int fmpc_set_small_batch_kernel(fmpc_handle h, int tiled) {
     if (!h) return FMPC_E_NULL;
     std::lock_guard<std::mutex> lk(h->mu);
     h->small_tiled = tiled ? 1 : 0;
-    if (tiled) h->small_nw = tiled == 4 ? 4 : 2;
+    if (tiled) h->small_nw = tiled == 2 ? 2 : 4;
     return FMPC_OK;
 }
 

@@ -179,10 +179,10 @@ class FastMPCHandle:
             raise FastMPCError(rc, "fmpc_set_dense_form")
 
     def set_small_batch_kernel(self, tiled):
-        """fmpc_set_small_batch_kernel: tiled kernel (True, default: lowest latency of one call) or the one-wavefront kernel
-        (False: better when many handles have solves in flight) for small per-problem-factor batches and budget continuations;
-        4: the tiled kernel with four wavefronts per problem (opt-in, include/fastmpc.h)."""
-        rc = self._lib.fmpc_set_small_batch_kernel(self._h, 4 if tiled == 4 and tiled is not True else int(bool(tiled)))
+        """fmpc_set_small_batch_kernel: tiled kernel (True, default: lowest latency of one call; four wavefronts per problem up to 512
+        problems) or the one-wavefront kernel (False: better when many handles have solves in flight) for small per-problem-factor
+        batches and budget continuations; 2: the tiled kernel with two wavefronts per problem throughout (include/fastmpc.h)."""
+        rc = self._lib.fmpc_set_small_batch_kernel(self._h, 2 if (tiled == 2 and tiled is not True) else (4 if tiled == 4 and tiled is not True else int(bool(tiled))))
         if rc != _lib.FMPC_OK:
             raise FastMPCError(rc, "fmpc_set_small_batch_kernel")
 

@@ -346,11 +346,11 @@ def test_many_seed_stress_of_the_production_instances(pkg, gpu, monkeypatch):
     # (a handle created with FMPC_SMALL_TILED_NW=4 takes the tiled kernel with FOUR wavefronts per problem for explicit-start batches <= 512; FMPC_TILED=1
     #  forces the tiled kernel with its default of two.  FMPC_TILED_NW is read at the first tiled solve, not at create time.)
     # (Round 5: the compile-time instance <double,2,4,11> and its switch are gone; four wavefronts per problem = the run-time form.)
-    # Round 4: the default for small batches is TWO wavefronts per problem ("default": what production takes); four are opt-in
-    # (FMPC_SMALL_TILED_NW=4 at create time / fmpc_set_small_batch_kernel(h, 4)) and stay under this stress test.
-    hs = {"default": make({}), "tiled_nw4": make({"FMPC_SMALL_TILED_NW": "4"}),
+    # Round 5: the default for small batches is FOUR wavefronts per problem again ("default": what production takes, the run-time form);
+    # two are FMPC_SMALL_TILED_NW=2 at create time / fmpc_set_small_batch_kernel(h, 2).  Both stay under this stress test.
+    hs = {"default": make({}), "tiled_nw4": make({"FMPC_SMALL_TILED_NW": "2"}),
           "tiled_nw2": make({"FMPC_TILED": "1"}), "wave": make({"FMPC_NO_SMALL_TILED": "1"})}
-    want_nw = {"default": 2, "tiled_nw4": 4, "tiled_nw2": 2}
+    want_nw = {"default": 4, "tiled_nw4": 2, "tiled_nw2": 2}
     worst = 0.0
     for seed in range(24):
         rng = np.random.default_rng(1000 + seed)
